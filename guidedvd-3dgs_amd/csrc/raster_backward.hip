@@ -1,0 +1,474 @@
+// raster_backward.hip -- backward pass of the MI355X-native Gaussian rasterizer (gfx950, wave64).
+//
+//   k_render_bwd   one workgroup per 16x16 tile, back-to-front replay (backward.cu:415-601).
+//                  The reference issues 10 global float atomics per (pixel, Gaussian) hit; on
+//                  MI355X same-address device-scope atomics serialise at ~11 ns each, so instead
+//                  every wave reduces its 64 pixels with DPP (no LDS traffic), the 4 waves'
+//                  results meet in LDS, and ONE 48-byte partial record per (Gaussian, tile)
+//                  instance is written to HBM at the instance's slot in Gaussian order
+//                  (slot = point_offsets[id-1] + row-major index of the tile inside the rect).
+//   k_gather_bwd   per Gaussian: sums its contiguous run of partial records in a fixed order
+//                  (=> deterministic gradients, no atomics), then the reference's
+//                  computeCov2DCUDA (backward.cu:144-274), preprocessCUDA-bwd (:346-412),
+//                  SH bwd (:20-139) and cov3D bwd (:278-341) in one pass.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "raster_kernels.h"
+#include "raster_layout.h"
+#include "raster_math.h"
+
+namespace gvd {
+
+constexpr int kNV = 10;  // reduced values per (Gaussian, tile)
+
+__global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
+{
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float4 s_cd[256];
+    __shared__ uint32_t s_ord[256];
+    __shared__ float s_part[4][256][kNV];
+    __shared__ uint32_t s_wcount[4];
+    __shared__ uint32_t s_max;
+
+    const int tile = blockIdx.x;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int px = tx * 16 + (lane & 15);
+    const int py = ty * 16 + w * 4 + (lane >> 4);
+    const bool inside = px < a.W && py < a.H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
+    const size_t pid = (size_t)py * a.W + px;
+    const size_t HW = (size_t)a.H * a.W;
+
+    const uint32_t r0 = a.ranges[2 * tile];
+    uint32_t r1 = a.ranges[2 * tile + 1];
+    if (r1 > a.capacity) r1 = r0;
+
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+
+    const float T_final = inside ? (1.f - a.alphas[pid]) : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? a.n_contrib[pid] : 0u;
+    float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
+    if (inside) {
+        dLp0 = a.dL_dpix[pid];
+        dLp1 = a.dL_dpix[HW + pid];
+        dLp2 = a.dL_dpix[2 * HW + pid];
+        dLd = a.dL_dpix_depth[pid];
+        dLa = a.dL_dalphas[pid];
+    }
+    float bg_dot = 0.f;  // backward.cu:575-577 accumulation order
+    bg_dot += a.bg[0] * dLp0;
+    bg_dot += a.bg[1] * dLp1;
+    bg_dot += a.bg[2] * dLp2;
+
+    {
+        uint32_t m = last_contributor;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if (lane == 0 && m) atomicMax(&s_max, m);
+    }
+    __syncthreads();
+    const uint32_t tile_max = min(s_max, r1 - r0);
+    if (tile_max == 0) return;
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_d = 0.f, acc_a = 0.f;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+
+    for (uint32_t bdone = 0; bdone < tile_max; bdone += 256) {
+        // ---- stage (descending list order) + cull + compact ----
+        bool keep = false;
+        float2 xy;
+        float4 co, cd;
+        uint32_t id = 0, ord = 0;
+        if (bdone + tid < tile_max) {
+            ord = tile_max - 1 - bdone - tid;  // value of `contributor` after its decrement
+            id = a.point_list[r0 + ord];
+            xy = reinterpret_cast<const float2*>(a.means2D)[id];
+            co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
+            cd = reinterpret_cast<const float4*>(a.rgbd)[id];
+            keep = tile_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
+        }
+        {
+            float4* z = reinterpret_cast<float4*>(&s_part[0][0][0]);
+#pragma unroll
+            for (int i = 0; i < (4 * 256 * kNV / 4) / 256; i++) z[i * 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wcount[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t wbase = 0, n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t c = s_wcount[i];
+            if (i < w) wbase += c;
+            n += c;
+        }
+        const uint32_t slot = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (keep) {
+            s_xy[slot] = xy;
+            s_co[slot] = co;
+            s_cd[slot] = cd;
+            s_ord[slot] = ord;
+        }
+        __syncthreads();
+
+        // ---- per-pixel gradient terms, wave-reduced per Gaussian ----
+        for (uint32_t j = 0; j < n; j++) {
+            const float2 gxy = s_xy[j];
+            const float4 con_o = s_co[j];
+            const float dx = gxy.x - pixfx, dy = gxy.y - pixfy;
+            const float power = gauss_power(con_o.x, con_o.y, con_o.z, dx, dy);
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, con_o.w * G);
+            const bool act = (s_ord[j] < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (!__any(act)) continue;  // wave-uniform
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
+            if (act) {
+                const float4 c = s_cd[j];
+                T = T / (1.f - alpha);
+                const float dchannel_dcolor = alpha * T;
+                float dL_dopa = 0.0f;
+                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                lc0 = c.x;
+                dL_dopa += (c.x - acc0) * dLp0;
+                v6 = dchannel_dcolor * dLp0;
+                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                lc1 = c.y;
+                dL_dopa += (c.y - acc1) * dLp1;
+                v7 = dchannel_dcolor * dLp1;
+                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                lc2 = c.z;
+                dL_dopa += (c.z - acc2) * dLp2;
+                v8 = dchannel_dcolor * dLp2;
+                acc_d = last_alpha * last_depth + (1.f - last_alpha) * acc_d;
+                last_depth = c.w;
+                dL_dopa += (c.w - acc_d) * dLd;
+                v9 = dchannel_dcolor * dLd;
+                acc_a = last_alpha + (1.f - last_alpha) * acc_a;
+                dL_dopa += (1.f - acc_a) * dLa;
+                dL_dopa *= T;
+                last_alpha = alpha;
+                dL_dopa += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = con_o.w * dL_dopa;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * con_o.x - gdy * con_o.y;
+                const float dG_ddely = -gdy * con_o.z - gdx * con_o.y;
+                v0 = dL_dG * dG_ddelx * ddelx_dx;
+                v1 = dL_dG * dG_ddely * ddely_dy;
+                v2 = -0.5f * gdx * dx * dL_dG;
+                v3 = -0.5f * gdx * dy * dL_dG;
+                v4 = -0.5f * gdy * dy * dL_dG;
+                v5 = G * dL_dopa;
+            }
+            v0 = wave_sum_to_lane63(v0);
+            v1 = wave_sum_to_lane63(v1);
+            v2 = wave_sum_to_lane63(v2);
+            v3 = wave_sum_to_lane63(v3);
+            v4 = wave_sum_to_lane63(v4);
+            v5 = wave_sum_to_lane63(v5);
+            v6 = wave_sum_to_lane63(v6);
+            v7 = wave_sum_to_lane63(v7);
+            v8 = wave_sum_to_lane63(v8);
+            v9 = wave_sum_to_lane63(v9);
+            if (lane == 63) {
+                float* o = &s_part[w][j][0];
+                o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
+                o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8; o[9] = v9;
+            }
+        }
+        __syncthreads();
+
+        // ---- one partial record per kept (Gaussian, tile) instance, at its Gaussian-order slot ----
+        if (keep) {
+            const int4 r = get_rect(xy.x, xy.y, a.radii[id], a.gx, a.gy);
+            const uint32_t k = (uint32_t)((ty - r.y) * (r.z - r.x) + (tx - r.x));
+            const uint32_t g = (id ? a.point_offsets[id - 1] : 0u) + k;
+            float o[kNV];
+#pragma unroll
+            for (int q = 0; q < kNV; q++)
+                o[q] = ((s_part[0][slot][q] + s_part[1][slot][q]) + s_part[2][slot][q]) + s_part[3][slot][q];
+            float4* dst = reinterpret_cast<float4*>(a.partials + (size_t)g * kPartialStride);
+            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+            dst[2] = make_float4(o[8], o[9], 0.f, 0.f);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    const bool visible = a.radii[idx] > 0;
+    float s[kNV];
+#pragma unroll
+    for (int q = 0; q < kNV; q++) s[q] = 0.f;
+    if (visible) {
+        const uint32_t beg = idx ? a.point_offsets[idx - 1] : 0u;
+        const uint32_t end = a.point_offsets[idx];
+        for (uint32_t g = beg; g < end; g++) {
+            const float4* rec = reinterpret_cast<const float4*>(a.partials + (size_t)g * kPartialStride);
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
+            s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;
+            s[8] += r2.x; s[9] += r2.y;
+        }
+    }
+    a.dL_dmean2D[3 * idx] = s[0];
+    a.dL_dmean2D[3 * idx + 1] = s[1];
+    a.dL_dmean2D[3 * idx + 2] = 0.f;
+    reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(s[2], s[3], 0.f, s[4]);
+    a.dL_dopacity[idx] = s[5];
+    a.dL_dcolor[3 * idx] = s[6];
+    a.dL_dcolor[3 * idx + 1] = s[7];
+    a.dL_dcolor[3 * idx + 2] = s[8];
+    a.dL_ddepth[idx] = s[9];
+
+    float* dm = a.dL_dmean3D + 3 * idx;
+    float* dcov = a.dL_dcov3D + 6 * idx;
+    float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+    float* ds = a.dL_dscale + 3 * idx;
+    float* dq = a.dL_drot + 4 * idx;
+    if (!visible) {
+        dm[0] = dm[1] = dm[2] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) dcov[i] = 0.f;
+        for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
+        ds[0] = ds[1] = ds[2] = 0.f;
+        dq[0] = dq[1] = dq[2] = dq[3] = 0.f;
+        return;
+    }
+    const float* view = a.viewmatrix;
+    const float* proj = a.projmatrix;
+    // ---------------- computeCov2DCUDA (backward.cu:144-274) ----------------
+    const float* cov3D = a.cov3D + 6 * idx;
+    const float m0 = a.means3D[3 * idx], m1 = a.means3D[3 * idx + 1], m2 = a.means3D[3 * idx + 2];
+    const float dcx = s[2], dcy = s[3], dcz = s[4];
+    float t0 = view[0] * m0 + view[4] * m1 + view[8] * m2 + view[12];
+    float t1 = view[1] * m0 + view[5] * m1 + view[9] * m2 + view[13];
+    const float t2 = view[2] * m0 + view[6] * m1 + view[10] * m2 + view[14];
+    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    const float txtz = t0 / t2, tytz = t1 / t2;
+    t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+    t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+    const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float fx = a.focal_x, fy = a.focal_y;
+    // GLM column-major X[c][r]
+    const float J[3][3] = { { fx / t2, 0.0f, -(fx * t0) / (t2 * t2) }, { 0.0f, fy / t2, -(fy * t1) / (t2 * t2) }, { 0.f, 0.f, 0.f } };
+    const float Wm[3][3] = { { view[0], view[4], view[8] }, { view[1], view[5], view[9] }, { view[2], view[6], view[10] } };
+    const float Vrk[3][3] = { { cov3D[0], cov3D[1], cov3D[2] }, { cov3D[1], cov3D[3], cov3D[4] }, { cov3D[2], cov3D[4], cov3D[5] } };
+    float T[3][3], A[3][3], c2[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) T[j][i] = Wm[0][i] * J[j][0] + Wm[1][i] * J[j][1] + Wm[2][i] * J[j][2];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) A[j][i] = T[i][0] * Vrk[0][j] + T[i][1] * Vrk[1][j] + T[i][2] * Vrk[2][j];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) c2[j][i] = A[0][i] * T[j][0] + A[1][i] * T[j][1] + A[2][i] * T[j][2];
+    const float ca = c2[0][0] + 0.3f, cb = c2[0][1], cc = c2[1][1] + 0.3f;
+    const float denom = ca * cc - cb * cb;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+        dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+        dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+        dcov[0] = (T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc);
+        dcov[3] = (T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc);
+        dcov[5] = (T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc);
+        dcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][1] * dL_dc;
+        dcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][2] * dL_dc;
+        dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) dcov[i] = 0;
+    }
+    const float dL_dT00 = 2 * (T[0][0] * Vrk[0][0] + T[0][1] * Vrk[0][1] + T[0][2] * Vrk[0][2]) * dL_da +
+                          (T[1][0] * Vrk[0][0] + T[1][1] * Vrk[0][1] + T[1][2] * Vrk[0][2]) * dL_db;
+    const float dL_dT01 = 2 * (T[0][0] * Vrk[1][0] + T[0][1] * Vrk[1][1] + T[0][2] * Vrk[1][2]) * dL_da +
+                          (T[1][0] * Vrk[1][0] + T[1][1] * Vrk[1][1] + T[1][2] * Vrk[1][2]) * dL_db;
+    const float dL_dT02 = 2 * (T[0][0] * Vrk[2][0] + T[0][1] * Vrk[2][1] + T[0][2] * Vrk[2][2]) * dL_da +
+                          (T[1][0] * Vrk[2][0] + T[1][1] * Vrk[2][1] + T[1][2] * Vrk[2][2]) * dL_db;
+    const float dL_dT10 = 2 * (T[1][0] * Vrk[0][0] + T[1][1] * Vrk[0][1] + T[1][2] * Vrk[0][2]) * dL_dc +
+                          (T[0][0] * Vrk[0][0] + T[0][1] * Vrk[0][1] + T[0][2] * Vrk[0][2]) * dL_db;
+    const float dL_dT11 = 2 * (T[1][0] * Vrk[1][0] + T[1][1] * Vrk[1][1] + T[1][2] * Vrk[1][2]) * dL_dc +
+                          (T[0][0] * Vrk[1][0] + T[0][1] * Vrk[1][1] + T[0][2] * Vrk[1][2]) * dL_db;
+    const float dL_dT12 = 2 * (T[1][0] * Vrk[2][0] + T[1][1] * Vrk[2][1] + T[1][2] * Vrk[2][2]) * dL_dc +
+                          (T[0][0] * Vrk[2][0] + T[0][1] * Vrk[2][1] + T[0][2] * Vrk[2][2]) * dL_db;
+    const float dL_dJ00 = Wm[0][0] * dL_dT00 + Wm[0][1] * dL_dT01 + Wm[0][2] * dL_dT02;
+    const float dL_dJ02 = Wm[2][0] * dL_dT00 + Wm[2][1] * dL_dT01 + Wm[2][2] * dL_dT02;
+    const float dL_dJ11 = Wm[1][0] * dL_dT10 + Wm[1][1] * dL_dT11 + Wm[1][2] * dL_dT12;
+    const float dL_dJ12 = Wm[2][0] * dL_dT10 + Wm[2][1] * dL_dT11 + Wm[2][2] * dL_dT12;
+    const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -fx * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
+    const float dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * t0) * tz3 * dL_dJ02 + (2 * fy * t1) * tz3 * dL_dJ12;
+    float g0 = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;  // assigned, backward.cu:273
+    float g1 = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
+    float g2 = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+
+    // ---------------- preprocessCUDA backward (backward.cu:346-412) ----------------
+    const float m_hom_w = proj[3] * m0 + proj[7] * m1 + proj[11] * m2 + proj[15];
+    const float m_w = 1.0f / (m_hom_w + 0.0000001f);
+    const float mul1 = (proj[0] * m0 + proj[4] * m1 + proj[8] * m2 + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * m0 + proj[5] * m1 + proj[9] * m2 + proj[13]) * m_w * m_w;
+    const float g2x = s[0], g2y = s[1];
+    g0 += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+    g1 += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+    g2 += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    const float mul3 = view[2] * m0 + view[6] * m1 + view[10] * m2 + view[14];
+    const float gd = s[9];
+    g0 += (view[2] - view[3] * mul3) * gd;
+    g1 += (view[6] - view[7] * mul3) * gd;
+    g2 += (view[10] - view[11] * mul3) * gd;
+
+    // ---------------- SH backward (backward.cu:20-139) ----------------
+    if (a.has_sh) {
+        const float dox = m0 - a.campos[0], doy = m1 - a.campos[1], doz = m2 - a.campos[2];
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        const float* sh = a.shs + (size_t)idx * a.M * 3;
+        const uint32_t cl = a.clamped[idx];
+        float dRGB[3] = { s[6] * ((cl & 1u) ? 0.f : 1.f), s[7] * ((cl & 2u) ? 0.f : 1.f), s[8] * ((cl & 4u) ? 0.f : 1.f) };
+        float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+        const int D = a.D;
+#define SHV(k, ch) sh[3 * (k) + (ch)]
+#define DSH(k, wgt) { const float w_ = (wgt); dsh[3 * (k)] = w_ * dRGB[0]; dsh[3 * (k) + 1] = w_ * dRGB[1]; dsh[3 * (k) + 2] = w_ * dRGB[2]; }
+        DSH(0, SH_C0);
+        int written = 1;
+        if (D > 0) {
+            DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
+            written = 4;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                dRGBdx[ch] = -SH_C1 * SHV(3, ch);
+                dRGBdy[ch] = -SH_C1 * SHV(1, ch);
+                dRGBdz[ch] = SH_C1 * SHV(2, ch);
+            }
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                DSH(4, SH_C2_0 * xy); DSH(5, SH_C2_1 * yz); DSH(6, SH_C2_2 * (2.f * zz - xx - yy));
+                DSH(7, SH_C2_3 * xz); DSH(8, SH_C2_4 * (xx - yy));
+                written = 9;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] += SH_C2_0 * y * SHV(4, ch) + SH_C2_2 * 2.f * -x * SHV(6, ch) + SH_C2_3 * z * SHV(7, ch) + SH_C2_4 * 2.f * x * SHV(8, ch);
+                    dRGBdy[ch] += SH_C2_0 * x * SHV(4, ch) + SH_C2_1 * z * SHV(5, ch) + SH_C2_2 * 2.f * -y * SHV(6, ch) + SH_C2_4 * 2.f * -y * SHV(8, ch);
+                    dRGBdz[ch] += SH_C2_1 * y * SHV(5, ch) + SH_C2_2 * 2.f * 2.f * z * SHV(6, ch) + SH_C2_3 * x * SHV(7, ch);
+                }
+                if (D > 2) {
+                    DSH(9, SH_C3_0 * y * (3.f * xx - yy));
+                    DSH(10, SH_C3_1 * xy * z);
+                    DSH(11, SH_C3_2 * y * (4.f * zz - xx - yy));
+                    DSH(12, SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                    DSH(13, SH_C3_4 * x * (4.f * zz - xx - yy));
+                    DSH(14, SH_C3_5 * z * (xx - yy));
+                    DSH(15, SH_C3_6 * x * (xx - 3.f * yy));
+                    written = 16;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dRGBdx[ch] += (SH_C3_0 * SHV(9, ch) * 3.f * 2.f * xy +
+                                       SH_C3_1 * SHV(10, ch) * yz +
+                                       SH_C3_2 * SHV(11, ch) * -2.f * xy +
+                                       SH_C3_3 * SHV(12, ch) * -3.f * 2.f * xz +
+                                       SH_C3_4 * SHV(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                                       SH_C3_5 * SHV(14, ch) * 2.f * xz +
+                                       SH_C3_6 * SHV(15, ch) * 3.f * (xx - yy));
+                        dRGBdy[ch] += (SH_C3_0 * SHV(9, ch) * 3.f * (xx - yy) +
+                                       SH_C3_1 * SHV(10, ch) * xz +
+                                       SH_C3_2 * SHV(11, ch) * (-3.f * yy + 4.f * zz - xx) +
+                                       SH_C3_3 * SHV(12, ch) * -3.f * 2.f * yz +
+                                       SH_C3_4 * SHV(13, ch) * -2.f * xy +
+                                       SH_C3_5 * SHV(14, ch) * -2.f * yz +
+                                       SH_C3_6 * SHV(15, ch) * -3.f * 2.f * xy);
+                        dRGBdz[ch] += (SH_C3_1 * SHV(10, ch) * xy +
+                                       SH_C3_2 * SHV(11, ch) * 4.f * 2.f * yz +
+                                       SH_C3_3 * SHV(12, ch) * 3.f * (2.f * zz - xx - yy) +
+                                       SH_C3_4 * SHV(13, ch) * 4.f * 2.f * xz +
+                                       SH_C3_5 * SHV(14, ch) * (xx - yy));
+                    }
+                }
+            }
+        }
+#undef SHV
+#undef DSH
+        for (int k = written; k < a.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+        const float ddx = dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2];
+        const float ddy = dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2];
+        const float ddz = dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2];
+        const float sum2 = dox * dox + doy * doy + doz * doz;  // dnormvdv, auxiliary.h:107-117
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        g0 += ((+sum2 - dox * dox) * ddx - doy * dox * ddy - doz * dox * ddz) * invsum32;
+        g1 += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
+        g2 += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
+    } else {
+        for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
+    }
+    dm[0] = g0; dm[1] = g1; dm[2] = g2;
+
+    // ---------------- cov3D backward (backward.cu:278-341) ----------------
+    if (a.has_scales) {
+        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        const float R[3][3] = { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
+                                { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
+                                { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } };
+        const float sv[3] = { a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1], a.scale_modifier * a.scales[3 * idx + 2] };
+        float Mm[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) Mm[j][i] = sv[i] * R[j][i];
+        const float dS[3][3] = { { dcov[0], 0.5f * dcov[1], 0.5f * dcov[2] }, { 0.5f * dcov[1], dcov[3], 0.5f * dcov[4] }, { 0.5f * dcov[2], 0.5f * dcov[4], dcov[5] } };
+        float dM[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                dM[j][i] = (2.0f * Mm[0][i]) * dS[j][0] + (2.0f * Mm[1][i]) * dS[j][1] + (2.0f * Mm[2][i]) * dS[j][2];
+        float Rt[3][3], dMt[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) { Rt[j][i] = R[i][j]; dMt[j][i] = dM[i][j]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) ds[k] = Rt[k][0] * dMt[k][0] + Rt[k][1] * dMt[k][1] + Rt[k][2] * dMt[k][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) dMt[k][i] *= sv[k];
+        dq[0] = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
+        dq[1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
+        dq[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
+        dq[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+    } else {
+        ds[0] = ds[1] = ds[2] = 0.f;
+        dq[0] = dq[1] = dq[2] = dq[3] = 0.f;
+    }
+}
+
+void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(256), 0, s, a);
+}
+void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace gvd

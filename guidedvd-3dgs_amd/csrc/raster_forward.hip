@@ -1,0 +1,521 @@
+// raster_forward.hip -- forward pass of the MI355X-native Gaussian rasterizer (gfx950, wave64).
+//
+// Pipeline (one view):
+//   k_preprocess   per Gaussian: project, cov3D/cov2D, conic, radius, tile rect, SH->RGB
+//                  (forward.cu:155-256) + per-block LDS histogram of touched tiles
+//   k_colscan      per tile: exclusive prefix of the block histograms -> per-(block,tile) bases
+//   k_tilescan     exclusive scan over tiles -> ranges[tile] (rasterizer_impl.cu:116-138 result),
+//                  num_rendered, per-block instance bases (the InclusiveSum of rasterizer_impl.cu:278)
+//   k_scatter      per Gaussian: emit (depth bits<<32 | id) into its tile bucket (counting sort by
+//                  tile, LDS cursors) + point_offsets           (duplicateWithKeys, rasterizer_impl.cu:70-111)
+//   k_sort_tiles   one workgroup per tile: bitonic sort of the bucket in LDS by (depth bits, id)
+//                  == the stable radix sort on (tile|depth) of rasterizer_impl.cu:304-309
+//   k_render_fwd   one workgroup per 16x16 tile: LDS-staged, culled, compacted tile list;
+//                  front-to-back alpha blend (forward.cu:261-381)
+//
+// Why not a global radix sort: the key's high word is the tile id, so a counting sort by tile
+// followed by an LDS-resident per-tile sort moves ~20 B/instance through HBM instead of
+// ~6 passes x 24 B/instance.  The sorted order is identical: (tile, depth bits, Gaussian id)
+// is a total order and equals the stable-sort order of the reference's emission sequence.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "raster_kernels.h"
+#include "raster_math.h"
+
+namespace gvd {
+
+// ------------------------------------------------------------------------------------------------
+// small wave/block helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_preprocess
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(256) k_preprocess(PreprocessArgs a)
+{
+    extern __shared__ uint32_t s_hist[];  // T counters (LDS_HIST)
+    __shared__ uint32_t s_total;
+    const int tid = threadIdx.x;
+    if (LDS_HIST) {
+        for (int t = tid; t < a.T; t += 256) s_hist[t] = 0;
+    }
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+
+    const float3 campos = make_float3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]);
+    uint32_t my_total = 0;
+    const int base = blockIdx.x * a.items_per_block;
+    for (int it = 0; it < a.items_per_block; it += 256) {
+        const int idx = base + it + tid;
+        if (idx >= a.P) break;
+        int radius_out = 0;
+        uint32_t touched = 0;
+        do {
+            const float3 p = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+            // in_frustum (auxiliary.h:139-164)
+            const float4 ph = xform4x4(p, a.projmatrix);
+            const float p_w = 1.0f / (ph.w + 0.0000001f);
+            const float projx = ph.x * p_w, projy = ph.y * p_w;
+            const float3 pv = xform4x3(p, a.viewmatrix);
+            if (pv.z <= 0.2f) {
+                if (a.prefiltered) {  // auxiliary.h:156-160
+                    printf("Point is filtered although prefiltered is set. This shouldn't happen!");
+                    __builtin_trap();
+                }
+                break;
+            }
+            float c3[6];
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * idx + k];
+            } else {
+                const float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+                const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+                cov3d_from_scale_rot(sc, a.scale_modifier, q, c3);
+#pragma unroll
+                for (int k = 0; k < 6; k++) a.cov3D[6 * idx + k] = c3[k];
+            }
+            const float3 cov = cov2d(pv, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.viewmatrix);
+            const float det = fmaf(cov.x, cov.z, -(cov.y * cov.y));
+            if (det == 0.0f) break;
+            const float det_inv = 1.f / det;
+            const float conx = cov.z * det_inv, cony = -cov.y * det_inv, conz = cov.x * det_inv;
+            const float mid = 0.5f * (cov.x + cov.z);
+            const float disc = sqrtf(fmaxf(0.1f, fmaf(mid, mid, -det)));
+            const float lambda1 = mid + disc;
+            const float lambda2 = mid - disc;
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float pix_x = ndc2pix(projx, a.W), pix_y = ndc2pix(projy, a.H);
+            const int ri = f2i_rz(my_radius);
+            const int4 r = get_rect(pix_x, pix_y, ri, a.gx, a.gy);
+            const int area = (r.z - r.x) * (r.w - r.y);
+            if (area == 0) break;
+
+            float3 rgb;
+            uint32_t clamp_bits = 0;
+            if (a.colors_precomp == nullptr) {
+                rgb = sh_to_rgb(a.D, p, campos, a.shs + (size_t)idx * a.M * 3, &clamp_bits);
+            } else {
+                rgb = make_float3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+            }
+            a.clamped[idx] = clamp_bits;
+            a.depths[idx] = pv.z;
+            reinterpret_cast<float2*>(a.means2D)[idx] = make_float2(pix_x, pix_y);
+            reinterpret_cast<float4*>(a.conic_opacity)[idx] = make_float4(conx, cony, conz, a.opacities[idx]);
+            reinterpret_cast<float4*>(a.rgbd)[idx] = make_float4(rgb.x, rgb.y, rgb.z, pv.z);
+            radius_out = ri;
+            touched = (uint32_t)area;
+            // tile histogram
+            for (int y = r.y; y < r.w; y++)
+                for (int x = r.x; x < r.z; x++) {
+                    if (LDS_HIST) atomicAdd(&s_hist[y * a.gx + x], 1u);
+                    else atomicAdd(&a.hist[y * a.gx + x], 1u);
+                }
+        } while (0);
+        a.radii[idx] = radius_out;
+        a.tiles_touched[idx] = touched;
+        my_total += touched;
+    }
+    my_total = wave_sum_u32(my_total);
+    if (lane_id() == 0 && my_total) atomicAdd(&s_total, my_total);
+    __syncthreads();
+    if (LDS_HIST) {
+        uint32_t* row = a.hist + (size_t)blockIdx.x * a.T;
+        for (int t = tid; t < a.T; t += 256) row[t] = s_hist[t];
+    }
+    if (tid == 0) a.block_total[blockIdx.x] = s_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_colscan: hist[b][t] -> exclusive prefix over b (in place); tile_count[t] = column total.
+// Block = 1024 threads = 16 b-segments x 64 tiles; grid = ceil(T/64).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_count, int B, int T)
+{
+    __shared__ uint32_t s_seg[16][64];
+    const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const int per = (B + 15) / 16;
+    const int b0 = seg * per, b1 = min(B, b0 + per);
+    uint32_t sum = 0;
+    if (t < T)
+        for (int b = b0; b < b1; b++) sum += hist[(size_t)b * T + t];
+    s_seg[seg][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int s = 0; s < seg; s++) run += s_seg[s][tl];
+    if (t < T) {
+        for (int b = b0; b < b1; b++) {
+            const uint32_t v = hist[(size_t)b * T + t];
+            hist[(size_t)b * T + t] = run;
+            run += v;
+        }
+        if (seg == 15) tile_count[t] = run;  // per*16 >= B so the last segment ends at B
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tilescan: single block (1024 threads).  ranges, num_rendered, max list length, chunk_base.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w /*16*/, uint32_t* total)
+{
+    const uint32_t incl = wave_incl_scan_u32(v);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int i = 0; i < 16; i++) {
+        const uint32_t x = s_w[i];
+        if (i < w) wbase += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return wbase + incl - v;
+}
+
+__global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    // ---- tiles ----
+    const int per = (a.T + 1023) / 1024;
+    const int t0 = tid * per, t1 = min(a.T, t0 + per);
+    uint32_t local = 0, lmax = 0;
+    for (int t = t0; t < t1; t++) {
+        const uint32_t c = a.tile_count[t];
+        local += c;
+        lmax = max(lmax, c);
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan_1024(local, s_w, &total);
+    for (int t = t0; t < t1; t++) {
+        const uint32_t c = a.tile_count[t];
+        a.ranges[2 * t] = run;
+        a.ranges[2 * t + 1] = run + c;
+        if (a.cursor) a.cursor[t] = run;
+        run += c;
+    }
+    if (lmax) atomicMax(&s_max, lmax);
+    // ---- per-block instance bases (exclusive scan of block_total) ----
+    const int perb = (a.B + 1023) / 1024;
+    const int b0 = tid * perb, b1 = min(a.B, b0 + perb);
+    uint32_t lb = 0;
+    for (int b = b0; b < b1; b++) lb += a.block_total[b];
+    uint32_t totb;
+    uint32_t runb = block_excl_scan_1024(lb, s_w, &totb);
+    for (int b = b0; b < b1; b++) {
+        a.chunk_base[b] = runb;
+        runb += a.block_total[b];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.scalars[0] = total;  // num_rendered
+        a.scalars[1] = s_max;  // longest tile list
+        a.scalars[2] = (total > a.capacity) ? 1u : 0u;
+        if (a.d_status) *a.d_status = (total > a.capacity) ? -4 : 0;
+        if (a.host_mirror) { a.host_mirror[0] = total; a.host_mirror[1] = s_max; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scatter
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(256) k_scatter(ScatterArgs a)
+{
+    extern __shared__ uint32_t s_cur[];  // T cursors (LDS_HIST)
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x;
+    if (LDS_HIST) {
+        const uint32_t* row = a.hist + (size_t)blockIdx.x * a.T;
+        for (int t = tid; t < a.T; t += 256) s_cur[t] = a.ranges[2 * t] + row[t];
+    }
+    __syncthreads();
+    uint32_t carry = a.chunk_base[blockIdx.x];
+    const int base = blockIdx.x * a.items_per_block;
+    for (int it = 0; it < a.items_per_block; it += 256) {
+        if (base + it >= a.P) break;  // uniform
+        const int idx = base + it + tid;
+        const uint32_t touched = (idx < a.P) ? a.tiles_touched[idx] : 0u;
+        // block inclusive scan (4 waves)
+        const uint32_t incl = wave_incl_scan_u32(touched);
+        const int w = tid >> 6;
+        if (lane_id() == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = s_w[i];
+            if (i < w) wbase += x;
+            tot += x;
+        }
+        if (idx < a.P) a.point_offsets[idx] = carry + wbase + incl;
+        carry += tot;
+        if (touched) {
+            const float2 xy = reinterpret_cast<const float2*>(a.means2D)[idx];
+            const int4 r = get_rect(xy.x, xy.y, a.radii[idx], a.gx, a.gy);
+            const uint64_t hi = ((uint64_t)__float_as_uint(a.depths[idx])) << 32;
+            const uint64_t entry = hi | (uint32_t)idx;
+            for (int y = r.y; y < r.w; y++)
+                for (int x = r.x; x < r.z; x++) {
+                    const int t = y * a.gx + x;
+                    const uint32_t pos = LDS_HIST ? atomicAdd(&s_cur[t], 1u) : atomicAdd(&a.cursor[t], 1u);
+                    if (pos < a.capacity) a.bucket[pos] = entry;
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sort_tiles: ascending sort of bucket[range) as u64 = (depth bits << 32 | gaussian id).
+// Sorting network: bitonic "flip + disperse" with every comparator ascending, so a list of any
+// length n is sorted by treating indices >= n as +inf (comparators touching them are no-ops).
+// CLASS 0: n <= 2048, LDS, 256 threads.  CLASS 1: n <= 16384, LDS (128 KiB), 1024 threads.
+// CLASS 2: n > 16384, in global memory, 1024 threads (rare; correctness path).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_u64(uint64_t* d, uint32_t n)
+{
+    uint32_t npad = 1;
+    while (npad < n) npad <<= 1;
+    const uint32_t half = npad >> 1;
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        // flip: i-th comparator of each k-block pairs l with k-1-l
+        {
+            const uint32_t hk = k >> 1;
+            for (uint32_t i = threadIdx.x; i < half; i += NT) {
+                const uint32_t blk = i / hk, l = i - blk * hk;
+                const uint32_t lo = blk * k + l, hi = blk * k + (k - 1 - l);
+                if (hi < n) {
+                    const uint64_t x = d[lo], y = d[hi];
+                    if (x > y) { d[lo] = y; d[hi] = x; }
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < half; i += NT) {
+                const uint32_t lo = 2 * j * (i / j) + (i % j), hi = lo + j;
+                if (hi < n) {
+                    const uint64_t x = d[lo], y = d[hi];
+                    if (x > y) { d[lo] = y; d[hi] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int CLASS>
+__global__ void __launch_bounds__(CLASS == 0 ? 256 : 1024) k_sort_tiles(SortArgs a)
+{
+    constexpr int NT = (CLASS == 0) ? 256 : 1024;
+    extern __shared__ uint64_t s_keys[];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+    if (r1 > a.capacity || r1 < r0) return;  // overflowed forward: leave untouched
+    const uint32_t n = r1 - r0;
+    if (CLASS == 0) { if (n > 2048) return; }
+    if (CLASS == 1) { if (n <= 2048 || n > 16384) return; }
+    if (CLASS == 2) { if (n <= 16384) return; }
+    if (n == 0) return;
+    uint64_t* g = a.bucket + r0;
+    uint64_t* d;
+    if (CLASS == 2) {
+        d = g;
+    } else {
+        d = s_keys;
+        for (uint32_t i = threadIdx.x; i < n; i += NT) d[i] = g[i];
+        __syncthreads();
+    }
+    bitonic_sort_u64<NT>(d, n);
+    const uint64_t thi = ((uint64_t)tile) << 32;
+    for (uint32_t i = threadIdx.x; i < n; i += NT) {
+        const uint64_t e = d[i];
+        if (CLASS != 2) g[i] = e;
+        a.point_list[r0 + i] = (uint32_t)e;
+        a.keys[r0 + i] = thi | (e >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_render_fwd: one workgroup (4 waves) per 16x16 tile; wave w owns the 16x4 pixel strip
+// rows 4w..4w+3 (x fastest, so output stores are 64-byte row segments).
+// Per batch of 256 list entries: each thread fetches one entry (id -> xy, conic/opacity, rgb+depth),
+// runs the conservative tile test, and the survivors are compacted into LDS with a wave ballot +
+// prefix (order preserved, original list position kept for n_contrib).  Every pixel then walks the
+// compacted batch from LDS (broadcast reads) with the reference's exact per-pixel sequence
+// (forward.cu:329-368).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
+{
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float4 s_cd[256];
+    __shared__ uint32_t s_pos[256];
+    __shared__ uint32_t s_wcount[4];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int px = tx * 16 + (lane & 15);
+    const int py = ty * 16 + w * 4 + (lane >> 4);
+    const bool inside = px < a.W && py < a.H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
+
+    const uint32_t r0 = a.ranges[2 * tile];
+    uint32_t r1 = a.ranges[2 * tile + 1];
+    if (r1 > a.capacity) r1 = r0;  // overflowed forward: render background, status already flagged
+
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, D = 0.f;
+    uint32_t last_contributor = 0;
+
+    for (uint32_t b = r0; b < r1; b += 256) {
+        const int num_done = __syncthreads_count(done);
+        if (num_done == 256) break;
+        // ---- stage + cull + compact ----
+        const uint32_t e = b + tid;
+        bool keep = false;
+        float2 xy;
+        float4 co, cd;
+        if (e < r1) {
+            const uint32_t id = a.point_list[e];
+            xy = reinterpret_cast<const float2*>(a.means2D)[id];
+            co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
+            cd = reinterpret_cast<const float4*>(a.rgbd)[id];
+            keep = tile_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wcount[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t wbase = 0, n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t c = s_wcount[i];
+            if (i < w) wbase += c;
+            n += c;
+        }
+        if (keep) {
+            const uint32_t slot = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            s_xy[slot] = xy;
+            s_co[slot] = co;
+            s_cd[slot] = cd;
+            s_pos[slot] = e - r0 + 1;  // value of `contributor` when this entry is visited
+        }
+        __syncthreads();
+        // ---- blend ----
+        if (!done) {
+            for (uint32_t j = 0; j < n; j++) {
+                const float2 gxy = s_xy[j];
+                const float4 con_o = s_co[j];
+                const float dx = gxy.x - pixfx, dy = gxy.y - pixfy;
+                const float power = gauss_power(con_o.x, con_o.y, con_o.z, dx, dy);
+                if (power > 0.0f) continue;
+                const float alpha = fminf(0.99f, con_o.w * __expf(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T * (1.f - alpha);
+                if (test_T < 0.0001f) { done = true; break; }
+                const float4 c = s_cd[j];
+                C0 = fmaf(c.x * alpha, T, C0);
+                C1 = fmaf(c.y * alpha, T, C1);
+                C2 = fmaf(c.z * alpha, T, C2);
+                weight = fmaf(alpha, T, weight);
+                D = fmaf(c.w * alpha, T, D);
+                T = test_T;
+                last_contributor = s_pos[j];
+            }
+        }
+    }
+    if (inside) {
+        const size_t pid = (size_t)py * a.W + px;
+        const size_t HW = (size_t)a.H * a.W;
+        a.n_contrib[pid] = last_contributor;
+        a.out_color[pid] = fmaf(T, a.bg[0], C0);
+        a.out_color[HW + pid] = fmaf(T, a.bg[1], C1);
+        a.out_color[2 * HW + pid] = fmaf(T, a.bg[2], C2);
+        a.out_alpha[pid] = weight;
+        a.out_depth[pid] = D;
+    }
+}
+
+// rasterizer_impl.cu:54-66 (checkFrustum)
+__global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __restrict__ means3D,
+                                                      const float* __restrict__ viewmatrix, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 pv = xform4x3(p, viewmatrix);
+    present[idx] = pv.z > 0.2f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from capi.hip)
+// ------------------------------------------------------------------------------------------------
+void launch_preprocess(const PreprocessArgs& a, int blocks, bool lds_hist, hipStream_t s)
+{
+    if (lds_hist) hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), (size_t)a.T * 4, s, a);
+    else hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_colscan(uint32_t* hist, uint32_t* tile_count, int B, int T, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_colscan, dim3((T + 63) / 64), dim3(1024), 0, s, hist, tile_count, B, T);
+}
+void launch_tilescan(const TileScanArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, a);
+}
+void launch_scatter(const ScatterArgs& a, int blocks, bool lds_hist, hipStream_t s)
+{
+    if (lds_hist) hipLaunchKernelGGL(k_scatter<true>, dim3(blocks), dim3(256), (size_t)a.T * 4, s, a);
+    else hipLaunchKernelGGL(k_scatter<false>, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_sort_tiles(const SortArgs& a, int T, int max_class, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sort_tiles<0>, dim3(T), dim3(256), 2048 * 8, s, a);
+    if (max_class >= 1) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(T), dim3(1024), 16384 * 8, s, a);
+    if (max_class >= 2) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(T), dim3(1024), 0, s, a);
+}
+void launch_render_fwd(const RenderArgs& a, int T, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), 0, s, a);
+}
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}
+
+}  // namespace gvd

@@ -1,0 +1,87 @@
+// raster_kernels.h -- kernel argument blocks and launcher prototypes shared by the .hip units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gvd {
+
+struct PreprocessArgs {
+    int P, D, M, W, H, gx, gy, T, items_per_block, prefiltered;
+    float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
+    const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
+    const float *viewmatrix, *projmatrix, *cam_pos;
+    int* radii;
+    float *means2D, *depths, *cov3D, *rgbd, *conic_opacity;
+    uint32_t *clamped, *tiles_touched, *hist, *block_total;
+};
+
+struct TileScanArgs {
+    int T, B;
+    uint32_t capacity;
+    const uint32_t* tile_count;
+    const uint32_t* block_total;
+    uint32_t *ranges, *cursor, *chunk_base, *scalars;
+    int32_t* d_status;
+    volatile uint32_t* host_mirror;
+};
+
+struct ScatterArgs {
+    int P, gx, gy, T, items_per_block;
+    uint32_t capacity;
+    const uint32_t *tiles_touched, *hist, *ranges, *chunk_base;
+    const float *means2D, *depths;
+    const int* radii;
+    uint32_t *cursor, *point_offsets;
+    uint64_t* bucket;
+};
+
+struct SortArgs {
+    uint32_t capacity;
+    const uint32_t* ranges;
+    uint64_t* bucket;
+    uint32_t* point_list;
+    uint64_t* keys;
+};
+
+struct RenderArgs {
+    int W, H, gx, gy;
+    uint32_t capacity;
+    const uint32_t *ranges, *point_list;
+    const float *means2D, *conic_opacity, *rgbd, *bg;
+    float *out_color, *out_depth, *out_alpha;
+    uint32_t* n_contrib;
+};
+
+struct RenderBwdArgs {
+    int W, H, gx, gy;
+    uint32_t capacity;
+    const uint32_t *ranges, *point_list, *n_contrib, *point_offsets;
+    const int* radii;
+    const float *means2D, *conic_opacity, *rgbd, *bg, *alphas;
+    const float *dL_dpix, *dL_dpix_depth, *dL_dalphas;
+    float* partials;  // [R][12]
+};
+
+struct GatherBwdArgs {
+    int P, D, M, W, H;
+    float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
+    const float *means3D, *shs, *scales, *rotations, *cov3D, *viewmatrix, *projmatrix, *campos;
+    const int* radii;
+    const uint32_t *clamped, *point_offsets;
+    const float* partials;
+    int has_sh, has_scales;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_ddepth;
+    float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+
+void launch_preprocess(const PreprocessArgs& a, int blocks, bool lds_hist, hipStream_t s);
+void launch_colscan(uint32_t* hist, uint32_t* tile_count, int B, int T, hipStream_t s);
+void launch_tilescan(const TileScanArgs& a, hipStream_t s);
+void launch_scatter(const ScatterArgs& a, int blocks, bool lds_hist, hipStream_t s);
+void launch_sort_tiles(const SortArgs& a, int T, int max_class, hipStream_t s);
+void launch_render_fwd(const RenderArgs& a, int T, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s);
+void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s);
+
+}  // namespace gvd

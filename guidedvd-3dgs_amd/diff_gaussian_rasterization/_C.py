@@ -1,0 +1,214 @@
+"""ctypes binding of libgvd_raster.so (include/gvd_raster.h) exposing the three entry points of
+the reference's pybind module (ext.cpp:15-18) with the same argument order and return tuples
+(rasterize_points.h:19-70):
+
+    rasterize_gaussians(...)          -> (num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer)
+    rasterize_gaussians_backward(...) -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]
+
+There is NO CPU fallback: tensors must live on a ROCm device and the HIP library must be built
+(python __graft_entry__.py build); anything else raises.
+"""
+import ctypes
+import os
+
+import torch  # must be imported before the .so so that ONE libamdhip64 (torch's) serves both
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_raster.so")
+_lib = None
+
+_ALLOC = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+_F = ctypes.c_float
+_I = ctypes.c_int
+_P = ctypes.c_void_p
+
+
+class _ChunkLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_size_t) for n in (
+        "depths", "means2D", "conic_opacity", "rgbd", "cov3D", "clamped", "internal_radii", "tiles_touched",
+        "point_offsets", "scalars", "ranges", "n_contrib", "point_list_keys", "point_list", "bucket")]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: build the HIP extension first "
+                               f"(python -c 'import __graft_entry__ as g; g.build()')")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.gvd_last_error.restype = ctypes.c_char_p
+        L.gvd_version.restype = ctypes.c_char_p
+        L.gvd_raster_geometry_bytes.restype = ctypes.c_size_t
+        L.gvd_raster_image_bytes.restype = ctypes.c_size_t
+        L.gvd_raster_binning_bytes.restype = ctypes.c_size_t
+        L.gvd_raster_binning_bytes.argtypes = [ctypes.c_uint32]
+        L.gvd_raster_forward.restype = _I
+        L.gvd_raster_forward.argtypes = [_ALLOC, _P, _ALLOC, _P, _ALLOC, _P, _I, _I, _I, _P, _I, _I,
+                                         _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _F, _I,
+                                         _P, _P, _P, _P, _I, _P]
+        L.gvd_raster_forward_capped.restype = _I
+        L.gvd_raster_forward_capped.argtypes = [_P, _P, _P, ctypes.c_uint32, _I, _I, _I, _P, _I, _I,
+                                                _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _F, _I,
+                                                _P, _P, _P, _P, _P, _I, _P]
+        L.gvd_raster_backward.restype = _I
+        L.gvd_raster_backward.argtypes = [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P,
+                                          _F, _F, _P, _P, _P, _P, _P, _P, _P,
+                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]
+        L.gvd_raster_mark_visible.restype = _I
+        L.gvd_raster_mark_visible.argtypes = [_I, _P, _P, _P, _P, _P]
+        L.gvd_raster_chunk_layout.argtypes = [_I, _I, _I, ctypes.c_uint32, ctypes.POINTER(_ChunkLayout)]
+        L.gvd_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]
+        _lib = L
+    return _lib
+
+
+def _err(code):
+    msg = lib().gvd_last_error()
+    return RuntimeError(f"gvd_raster error {code}: {msg.decode() if msg else '?'}")
+
+
+def _dev_f32(t, name, device):
+    """float32 contiguous tensor on `device`, or None for an empty ('absent') tensor."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device} (no CPU path in this build)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Chunk:
+    """Allocator callback target: a torch uint8 tensor sized on demand (resizeFunctional,
+    rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _ALLOC(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a ROCm device; got " + str(dev))
+    L = lib()
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    with torch.cuda.device(dev):
+        f = lambda t, n: _dev_f32(t, n, dev)
+        bg, m3, col, opa, sc, rot, cov, vm, pm, shs, cam = (
+            f(background, "bg"), f(means3D, "means3D"), f(colors, "colors_precomp"), f(opacity, "opacities"),
+            f(scales, "scales"), f(rotations, "rotations"), f(cov3D_precomp, "cov3D_precomp"), f(viewmatrix, "viewmatrix"),
+            f(projmatrix, "projmatrix"), f(sh, "sh"), f(campos, "campos"))
+        M = 0 if shs is None else shs.size(1)
+        out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        out_alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom, binning, img = _Chunk(dev), _Chunk(dev), _Chunk(dev)
+        rc = L.gvd_raster_forward(geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H,
+                                  _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot),
+                                  _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cam), float(tan_fovx), float(tan_fovy),
+                                  int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
+                                  radii.data_ptr() if P > 0 else None, int(bool(debug)), _stream())
+        if rc < 0:
+            raise _err(rc)
+    return rc, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug):
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a ROCm device; got " + str(dev))
+    L = lib()
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    with torch.cuda.device(dev):
+        f = lambda t, n: _dev_f32(t, n, dev)
+        bg, m3, col, sc, rot, cov, vm, pm, shs, cam = (
+            f(background, "bg"), f(means3D, "means3D"), f(colors, "colors_precomp"), f(scales, "scales"),
+            f(rotations, "rotations"), f(cov3D_precomp, "cov3D_precomp"), f(viewmatrix, "viewmatrix"),
+            f(projmatrix, "projmatrix"), f(sh, "sh"), f(campos, "campos"))
+        gC, gD, gA, al = f(dL_dout_color, "dL_dout_color"), f(dL_dout_depth, "dL_dout_depth"), f(dL_dout_alpha, "dL_dout_alpha"), f(alphas, "alphas")
+        M = 0 if shs is None else shs.size(1)
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = mk(P, 3), mk(P, 3), mk(P, 3), mk(P, 1)
+        dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh = mk(P, 2, 2), mk(P, 1), mk(P, 6), mk(P, M, 3)
+        dL_dscales, dL_drotations = mk(P, 3), mk(P, 4)
+        if P != 0:
+            rc = L.gvd_raster_backward(P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shs), _ptr(col), _ptr(al),
+                                       _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cam),
+                                       float(tan_fovx), float(tan_fovy), radii.contiguous().data_ptr(),
+                                       geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
+                                       _ptr(gC), _ptr(gD), _ptr(gA), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
+                                       dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_ddepths.data_ptr(),
+                                       dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M > 0 else None,
+                                       dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)), _stream())
+            if rc < 0:
+                raise _err(rc)
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a ROCm device; got " + str(dev))
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        with torch.cuda.device(dev):
+            rc = lib().gvd_raster_mark_visible(P, _dev_f32(means3D, "means3D", dev).data_ptr(),
+                                               _dev_f32(viewmatrix, "viewmatrix", dev).data_ptr(),
+                                               _dev_f32(projmatrix, "projmatrix", dev).data_ptr(),
+                                               present.data_ptr(), _stream())
+            if rc < 0:
+                raise _err(rc)
+    return present
+
+
+def chunk_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):
+    """Typed views of the internal scratch arrays (tests / debugging only)."""
+    lay = _ChunkLayout()
+    lib().gvd_raster_chunk_layout(P, W, H, R, ctypes.byref(lay))
+
+    def view(buf, off, nbytes, dtype):
+        base = buf.data_ptr()
+        a = (-base) % 128
+        return buf[a + off:a + off + nbytes].view(dtype)
+
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    g, b, i = geomBuffer, binningBuffer, imgBuffer
+    return dict(
+        depths=view(g, lay.depths, 4 * P, torch.float32),
+        means2D=view(g, lay.means2D, 8 * P, torch.float32).view(P, 2),
+        conic_opacity=view(g, lay.conic_opacity, 16 * P, torch.float32).view(P, 4),
+        rgbd=view(g, lay.rgbd, 16 * P, torch.float32).view(P, 4),
+        cov3D=view(g, lay.cov3D, 24 * P, torch.float32).view(P, 6),
+        clamped=view(g, lay.clamped, 4 * P, torch.int32),
+        tiles_touched=view(g, lay.tiles_touched, 4 * P, torch.int32),
+        point_offsets=view(g, lay.point_offsets, 4 * P, torch.int32),
+        scalars=view(g, lay.scalars, 32, torch.int32),
+        ranges=view(i, lay.ranges, 8 * T, torch.int32).view(T, 2),
+        n_contrib=view(i, lay.n_contrib, 4 * W * H, torch.int32).view(H, W),
+        point_list_keys=view(b, lay.point_list_keys, 8 * R, torch.int64) if R > 0 else None,
+        point_list=view(b, lay.point_list, 4 * R, torch.int32) if R > 0 else None,
+    )
