@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- hot-path benchmark of the MI355X-native Gaussian rasterizer.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Replica-like room, ~200k Gaussians, 640x480, 6 ring cameras,
+SH degree 3; one step = one training-view rasterization forward + backward through the drop-in
+operator (GaussianRasterizer + autograd), RGB-only loss gradient, inputs resident in HBM.
+N > 1: per-camera shards -- every rank owns a replica of the Gaussians and renders its own view
+(weak scaling, no data-path collective); value = views/s over all ranks.
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel, HIP-event timed inside the
+timed region) and `cpu_baseline` (the C oracle on the host cores; baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "guidedvd-3dgs_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=200_000)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import synthetic as syn
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+
+    sc = syn.scene_c2(P=args.points, W=args.width, H=args.height, sh_degree=args.sh_degree)
+    W, H, P = args.width, args.height, args.points
+    t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev, requires_grad=rg)
+    means3D, opac = t(sc["means3D"], True), t(sc["opacities"], True)
+    scales, rots, shs = t(sc["scales"], True), t(sc["rotations"], True), t(sc["shs"], True)
+    bg = t(sc["bg"])
+    conf = torch.ones((P, 1), device=dev)
+    means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+    cams = []
+    for c in sc["cameras"]:
+        cams.append(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+            viewmatrix=t(c["viewmatrix"]), projmatrix=t(c["projmatrix"]), sh_degree=args.sh_degree,
+            campos=t(c["campos"]), prefiltered=False, debug=False, confidence=conf))
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    gC = torch.randn((3, H, W), device=dev, generator=gen) / (H * W)
+    params = [means3D, opac, scales, rots, shs, means2D]
+
+    R_seen = []
+
+    def step(i):
+        s = cams[(i * world + rank) % len(cams)]
+        color, radii, depth, alpha = GaussianRasterizer(s)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
+                                                           scales=scales, rotations=rots)
+        for p_ in params:
+            p_.grad = None
+        torch.autograd.backward([color], [gC])
+        return color
+
+    L = _C.lib()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    L.gvd_profile_reset()
+    L.gvd_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.gvd_profile_enable(0)
+    if world > 1:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+
+    # ---- per-kernel HIP-event times (rank 0's stream) ----
+    import ctypes
+    kern = {}
+    for name in ("preprocess", "colscan", "tilescan", "scatter", "sort_tiles", "render_fwd", "render_bwd", "gather_bwd"):
+        ms, n = ctypes.c_double(0), ctypes.c_int(0)
+        L.gvd_profile_read(name.encode(), ctypes.byref(ms), ctypes.byref(n))
+        if n.value:
+            kern[name] = dict(avg_us=1e3 * ms.value / n.value, launches=n.value)
+    L.gvd_profile_reset()
+
+    if rank == 0:
+        # workload statistics for the algorithmic byte counts (mean over the cameras rank 0 used)
+        Rs, vis = [], []
+        with torch.no_grad():
+            for s in cams:
+                out = _C.rasterize_gaussians(bg, means3D.detach(), torch.Tensor([]), opac.detach(), scales.detach(), rots.detach(),
+                                             1.0, torch.Tensor([]), s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, H, W,
+                                             shs.detach(), args.sh_degree, s.campos, False, False)
+                Rs.append(int(out[0]))
+                vis.append(int((out[4] > 0).sum().item()))
+        used = [(i * world) % len(cams) for i in range(args.warmup, args.warmup + args.steps)]
+        R_mean = float(np.mean([Rs[u] for u in used]))
+        vis_mean = float(np.mean([vis[u] for u in used]))
+        HW = H * W
+        # SURVEY.md section 8(d) per-unit figures, restricted to the dominant kernel (DESIGN.md "roofline")
+        alg_bytes = {
+            "render_fwd": R_mean * 28 + HW * 24,
+            "render_bwd": R_mean * (28 + 16) + HW * (20 + 4 + 4) + vis_mean * (12 + 4 + 16 + 4 + 12),
+        }
+        dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k]["avg_us"], default=None)
+        roofline = None
+        if dom:
+            achieved = alg_bytes[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dom)
+                except Exception:
+                    traffic = None
+            roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                            avg_us=round(kern[dom]["avg_us"], 2), alg_bytes=int(alg_bytes[dom]))
+
+        cpu_baseline = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu_baseline = cpu_leg(sc, args, np)
+
+        value = args.steps * world / elapsed
+        line = {
+            "metric": "3dgs_raster_train_iters_per_s", "value": round(value, 2), "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Replica-like room, raster fwd+bwd only",
+                       "gaussians": P, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cams),
+                       "num_rendered_mean": int(R_mean), "visible_mean": int(vis_mean),
+                       "mean_tile_list": round(R_mean / (((W + 15) // 16) * ((H + 15) // 16)), 1),
+                       "parallelism": f"per-camera shards x{world}"},
+            "roofline": roofline,
+            "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_leg(sc, args, np):
+    """The C oracle (a port: the reference has no CPU rasterizer) on the host cores, bounded sample."""
+    from oracle import raster_oracle as ro
+    ncores = os.cpu_count() or 1
+    H, W = args.height, args.width
+    rng = np.random.default_rng(1234)
+    gC = rng.normal(size=(3, H, W)) / (H * W)
+    z = np.zeros((H, W), np.float32)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cam = sc["cameras"][n % len(sc["cameras"])]
+        st = ro.forward(sc["means3D"], sc["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"], sc["bg"],
+                        W, H, cam["tanfovx"], cam["tanfovy"], shs=sc["shs"], scales=sc["scales"],
+                        rotations=sc["rotations"], sh_degree=args.sh_degree)
+        ro.backward(st, gC, z, z)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or n >= 24:
+            break
+    return dict(value=round(n / el, 4), unit="iters/s", cores=ncores, kind="port",
+                sample=f"{n} fwd+bwd iterations of the same workload (OpenMP, {ncores} threads, incl. Python/ctypes marshalling)")
+
+
+if __name__ == "__main__":
+    main()

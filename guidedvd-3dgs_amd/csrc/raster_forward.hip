@@ -213,8 +213,9 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
     uint32_t run = block_excl_scan_1024(local, s_w, &total);
     for (int t = t0; t < t1; t++) {
         const uint32_t c = a.tile_count[t];
-        a.ranges[2 * t] = run;
-        a.ranges[2 * t + 1] = run + c;
+        // untouched tiles stay (0,0) like the reference's memset (rasterizer_impl.cu:311)
+        a.ranges[2 * t] = c ? run : 0u;
+        a.ranges[2 * t + 1] = c ? run + c : 0u;
         if (a.cursor) a.cursor[t] = run;
         run += c;
     }

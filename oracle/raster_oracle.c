@@ -771,3 +771,15 @@ void gvdo_preprocess_backward(int P, int D, int M, const float* means3D, const i
         }
     }
 }
+
+/* Unit-test entry points for the two pieces the reference's own Python can pin
+ * (tests/test_oracle_golden.py): SH->RGB (forward.cu:20-71) and cov3D (forward.cu:118-152). */
+void gvdo_sh_to_rgb_batch(int N, int deg, const float* pos, const float* campos, const float* sh,
+                          float* rgb, uint8_t* clamped)
+{
+    for (int i = 0; i < N; i++) sh_to_rgb(deg, pos + 3 * i, campos, sh + (size_t)i * 48, rgb + 3 * i, clamped + 3 * i);
+}
+void gvdo_cov3d_batch(int N, const float* scales, float mod, const float* rots, float* cov)
+{
+    for (int i = 0; i < N; i++) cov3d_from_scale_rot(scales + 3 * i, mod, rots + 4 * i, cov + 6 * i);
+}

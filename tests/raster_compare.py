@@ -30,7 +30,8 @@ def run_oracle(sc, cam, grads=None, colors_precomp=None, cov3D_precomp=None):
     return st, g
 
 
-def run_hip(sc, cam, grads=None, colors_precomp=None, cov3D_precomp=None, device="cuda:0", debug=False):
+def run_hip(sc, cam, grads=None, colors_precomp=None, cov3D_precomp=None, device="cuda:0", debug=False,
+            alpha_override=None):
     """Calls the native boundary directly (no autograd) and returns numpy state + grads."""
     import torch
     from diff_gaussian_rasterization import _C
@@ -59,6 +60,8 @@ def run_hip(sc, cam, grads=None, colors_precomp=None, cov3D_precomp=None, device
     g = None
     if grads is not None:
         gC, gD, gA = (t(x) for x in grads)
+        if alpha_override is not None:  # isolate the backward kernels from forward rounding differences
+            alpha = t(alpha_override).reshape(1, H, W)
         res = _C.rasterize_gaussians_backward(bg, m3, radii, col, scales, rots, 1.0, cov, vm, pm, cam["tanfovx"],
                                               cam["tanfovy"], gC.reshape(3, H, W), gD.reshape(1, H, W), gA.reshape(1, H, W),
                                               sh, sc["sh_degree"], cp, gb, R, bb, ib, alpha, debug)
@@ -69,6 +72,8 @@ def run_hip(sc, cam, grads=None, colors_precomp=None, cov3D_precomp=None, device
 
 def rel_to_max(a, b):
     """max |a-b| relative to max |b| (the gradient tolerance metric, see tests)."""
+    if b.size == 0:
+        return 0.0 if a.shape == b.shape else float("inf")
     s = float(np.abs(b).max())
     return float(np.abs(a - b).max()) / (s if s > 0 else 1.0)
 
@@ -128,6 +133,10 @@ def _main():
             st_h, g_h = run_hip(sc, cam, grads, debug=True)
             print(f"== {name} cam{ci}: P={st_o['P']} R={st_o['R']} oracle {t1 - t0:.2f}s hip {time.time() - t1:.2f}s")
             compare(st_h, st_o, g_h, g_o)
+            _, g_h2 = run_hip(sc, cam, grads, alpha_override=st_o["alpha"])
+            print("  -- backward fed with the oracle's alpha image:")
+            for k in g_h2:
+                print(f"  grad_{k:27s} {rel_to_max(g_h2[k], g_o[k])}")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,297 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP rasterizer, called through the
+C-ABI (ctypes binding `_C`) and through the drop-in operator, against the CPU oracle.
+
+Tolerances (DESIGN.md "parity bar"):
+  * integer/byte/index state -- radii, tiles_touched, point_offsets, (tile|depth) keys, sorted point
+    list, tile ranges, n_contrib, and the fp32 BITS of depth / means2D / conic / cov3D / rgb:
+    bit-exact (both sides follow one explicit fmaf sequence, -ffp-contract=off);
+  * rendered color/depth/alpha: |a-b| <= 1e-4*max(1,|b|) at every pixel (device v_exp_f32 vs libm
+    expf is the only difference);
+  * gradients: max|a-b| <= 1e-4*max|b| per tensor when backward is fed the same alpha image;
+    end-to-end (each side's own forward) 2e-3, because the reference recovers the final
+    transmittance as 1 - out_alpha (backward.cu:463), which turns a 5e-7 forward difference into
+    up to ~5e-3 relative on saturated pixels -- a property of the reference algorithm itself.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic as syn
+from raster_compare import compare, rel_to_max, run_hip, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+EXACT = ("R_equal", "radii_equal", "depth_bits_equal", "means2D_bits_equal", "tiles_touched_equal",
+         "point_offsets_equal", "ranges_equal", "conic_bits_equal", "rgb_bits_equal", "keys_equal", "point_list_equal")
+
+
+def _grads(H, W, seed, depth_alpha=True):
+    rng = np.random.default_rng(seed)
+    gC = rng.normal(size=(3, H, W)) / (H * W)
+    if depth_alpha:
+        return gC, rng.normal(size=(H, W)) / (H * W), rng.normal(size=(H, W)) / (H * W)
+    return gC, np.zeros((H, W)), np.zeros((H, W))
+
+
+def _check(rep, exact=EXACT, grad_tol=2e-3, img_outliers=0.0):
+    for k in exact:
+        if k in rep:
+            assert rep[k] is True, (k, rep)
+    assert rep.get("n_contrib_mismatch_frac", 0.0) <= img_outliers, rep
+    for k in ("color", "depth", "alpha"):
+        assert rep[k + "_outlier_frac"] <= img_outliers, (k, rep)
+    for k, v in rep.items():
+        if k.startswith("grad_"):
+            assert v < grad_tol, (k, v)
+
+
+def _tiny(seed, P=300, W=100, H=70, deg=3, spread=1.0):
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(-1.0, 1.0, size=(P, 3)) * spread
+    xyz[:, 2] = xyz[:, 2] * 1.5 + 3.5
+    xyz[: P // 20, 2] = -1.0
+    scales = np.exp(rng.normal(math.log(0.08), 0.5, size=(P, 3))).astype(np.float32)
+    q = rng.normal(size=(P, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    opac = (1 / (1 + np.exp(-rng.normal(0.0, 1.5, size=(P, 1))))).astype(np.float32)
+    sh = rng.normal(0, 0.25, size=(P, 16, 3)).astype(np.float32)
+    sh[:, 0] = syn.rgb2sh(rng.uniform(0, 1, size=(P, 3)))
+    cam = syn.make_camera(syn.look_at((0.1, -0.05, 0.0), (0.0, 0.1, 3.0)), math.radians(70), math.radians(55), W, H)
+    return dict(means3D=xyz.astype(np.float32), scales=scales, rotations=q, opacities=opac, shs=sh, sh_degree=deg,
+                bg=np.array([0.1, 0.4, 0.8], np.float32), cameras=[cam])
+
+
+def test_c1_bit_exact_keys_and_golden_fixture():
+    import os
+    sc = syn.scene_c1()
+    cam = sc["cameras"][0]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster_c1_oracle.npz"))
+    grads = (z["gC"], z["gD"], z["gA"])
+    st_o, g_o = run_oracle(sc, cam, grads)
+    st_h, g_h = run_hip(sc, cam, grads, debug=True)
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=1e-4)
+    # and directly against the committed fixture (no oracle code involved)
+    assert st_h["R"] == int(z["R"])
+    assert np.array_equal(st_h["point_list_keys"].view(np.uint64), z["keys"])
+    assert np.array_equal(st_h["point_list"].view(np.uint32), z["point_list"])
+    assert np.array_equal(st_h["ranges"].view(np.uint32), z["ranges"])
+    assert np.array_equal(st_h["radii"], z["radii"])
+    np.testing.assert_allclose(st_h["color"], z["color"], atol=1e-5, rtol=0)
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dopacity"):
+        assert rel_to_max(g_h[k], z[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("cam_id", [0, 3])
+def test_c2_full_size_parity(cam_id):
+    sc = syn.scene_c2()
+    cam = sc["cameras"][cam_id]
+    H, W = cam["image_height"], cam["image_width"]
+    grads = _grads(H, W, 11 + cam_id)
+    st_o, g_o = run_oracle(sc, cam, grads)
+    st_h, g_h = run_hip(sc, cam, grads)
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, img_outliers=2e-5)
+    # backward kernels in isolation: same alpha image on both sides -> 1e-4
+    _, g_h2 = run_hip(sc, cam, grads, alpha_override=st_o["alpha"])
+    for k in g_h2:
+        assert rel_to_max(g_h2[k], g_o[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_degrees_and_ragged_image(deg):
+    sc = _tiny(deg, deg=deg)  # 100x70: not a multiple of 16
+    cam = sc["cameras"][0]
+    grads = _grads(70, 100, deg)
+    st_o, g_o = run_oracle(sc, cam, grads)
+    st_h, g_h = run_hip(sc, cam, grads, debug=True)
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=5e-4)
+    ncoef = (deg + 1) ** 2
+    assert np.all(g_h["dL_dsh"][:, ncoef:] == 0)  # quirk 7
+
+
+def test_precomputed_colors_and_cov3d():
+    sc = _tiny(5)
+    cam = sc["cameras"][0]
+    st_ref, _ = run_oracle(sc, cam)
+    colors = np.random.default_rng(3).uniform(0, 1, size=(sc["means3D"].shape[0], 3)).astype(np.float32)
+    cov = st_ref["cov3D"].copy()
+    # invisible Gaussians never had their cov3D written: give them something finite
+    cov[st_ref["radii"] <= 0] = np.array([1e-2, 0, 0, 1e-2, 0, 1e-2], np.float32)
+    grads = _grads(70, 100, 5)
+    st_o, g_o = run_oracle(sc, cam, grads, colors_precomp=colors, cov3D_precomp=cov)
+    st_h, g_h = run_hip(sc, cam, grads, colors_precomp=colors, cov3D_precomp=cov, debug=True)
+    rep = compare(st_h, st_o, g_h, g_o, verbose=False)
+    _check(rep, grad_tol=5e-4)
+    assert g_h["dL_dsh"].shape == (sc["means3D"].shape[0], 0, 3)
+    assert np.all(g_h["dL_dscales"] == 0) and np.all(g_h["dL_drotations"] == 0)
+    assert np.abs(g_h["dL_dcov3D"]).max() > 0 and np.abs(g_h["dL_dcolors"]).max() > 0
+
+
+def test_empty_and_fully_culled():
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    e = torch.Tensor([])
+    bg = torch.tensor([0.3, 0.6, 0.9], device=dev)
+    cam = syn.make_camera(syn.look_at((0, 0, 0), (0, 0, 1)), 1.0, 1.0, 40, 24)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+    # P == 0: zero images, num_rendered 0 (rasterize_points.cu:81)
+    out = _C.rasterize_gaussians(bg, torch.zeros((0, 3), device=dev), e, torch.zeros((0, 1), device=dev), torch.zeros((0, 3), device=dev),
+                                 torch.zeros((0, 4), device=dev), 1.0, e, t(cam["viewmatrix"]), t(cam["projmatrix"]), 1.0, 1.0, 24, 40,
+                                 torch.zeros((0, 16, 3), device=dev), 0, t(cam["campos"]), False, False)
+    assert out[0] == 0 and float(out[1].abs().max()) == 0.0 and out[4].numel() == 0
+    # every Gaussian behind the camera: background everywhere, alpha 0, radii 0
+    P = 50
+    m = torch.randn(P, 3, device=dev)
+    m[:, 2] = -2.0
+    out = _C.rasterize_gaussians(bg, m, e, torch.full((P, 1), 0.5, device=dev), torch.full((P, 3), 0.1, device=dev),
+                                 torch.nn.functional.normalize(torch.randn(P, 4, device=dev)), 1.0, e, t(cam["viewmatrix"]),
+                                 t(cam["projmatrix"]), 1.0, 1.0, 24, 40, torch.zeros((P, 16, 3), device=dev), 0, t(cam["campos"]), False, True)
+    assert out[0] == 0
+    assert torch.allclose(out[1], bg[:, None, None].expand(3, 24, 40))
+    assert float(out[3].abs().max()) == 0.0 and int(out[4].abs().max()) == 0
+    g = _C.rasterize_gaussians_backward(bg, m, out[4], e, torch.full((P, 3), 0.1, device=dev),
+                                        torch.nn.functional.normalize(torch.randn(P, 4, device=dev)), 1.0, e, t(cam["viewmatrix"]),
+                                        t(cam["projmatrix"]), 1.0, 1.0, torch.ones(3, 24, 40, device=dev), torch.ones(1, 24, 40, device=dev),
+                                        torch.ones(1, 24, 40, device=dev), torch.zeros((P, 16, 3), device=dev), 0, t(cam["campos"]),
+                                        out[5], out[0], out[6], out[7], out[3], True)
+    assert all(float(x.abs().max()) == 0.0 for x in g if x.numel())
+
+
+@pytest.mark.parametrize("P,expect_max", [(3000, 2048), (18000, 16384)])
+def test_long_tile_lists_exercise_lds_and_global_sort(P, expect_max):
+    # many Gaussians piled into a 32x32 image: tile lists longer than the 2048-entry (LDS class 0)
+    # and 16384-entry (LDS class 1) sorters; includes exact depth ties (duplicated points).
+    sc = _tiny(9, P=P, W=32, H=32, deg=0, spread=0.15)
+    sc["means3D"][1::2] = sc["means3D"][0::2][: len(sc["means3D"][1::2])]  # ties: resolved by id (stable sort)
+    sc["opacities"][:] = 0.02
+    cam = sc["cameras"][0]
+    grads = _grads(32, 32, 9)
+    st_o, g_o = run_oracle(sc, cam, grads)
+    lens = st_o["ranges"][:, 1] - st_o["ranges"][:, 0]
+    assert lens.max() > expect_max
+    st_h, g_h = run_hip(sc, cam, grads, debug=True)
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, img_outliers=2e-3)
+
+
+def test_huge_splats_many_tiles():
+    # a few Gaussians covering the whole 640x480 frame (1200 tiles each) + small ones
+    sc = _tiny(13, P=400, W=640, H=480, deg=1)
+    sc["scales"][20:26] = 3.0  # (the first P//20 are behind the camera)
+    cam = sc["cameras"][0]
+    grads = _grads(480, 640, 13)
+    st_o, g_o = run_oracle(sc, cam, grads)
+    assert st_o["tiles_touched"].max() == 1200
+    st_h, g_h = run_hip(sc, cam, grads, debug=True)
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, img_outliers=1e-5)
+
+
+def test_operator_autograd_confidence_and_determinism():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = _tiny(21, P=500)
+    cam = sc["cameras"][0]
+    H, W, P = 70, 100, 500
+    t = lambda a, rg=False: torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=rg)
+    conf = torch.rand(P, 1, device=dev) * 2.0
+
+    def run(confidence):
+        leaves = dict(m=t(sc["means3D"], True), o=t(sc["opacities"], True), s=t(sc["scales"], True), r=t(sc["rotations"], True),
+                      sh=t(sc["shs"], True), m2=torch.zeros(P, 3, device=dev, requires_grad=True))
+        s = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], t(sc["bg"]), 1.0, t(cam["viewmatrix"]),
+                                          t(cam["projmatrix"]), 3, t(cam["campos"]), False, False, confidence)
+        color, radii, depth, alpha = GaussianRasterizer(s)(means3D=leaves["m"], means2D=leaves["m2"], opacities=leaves["o"],
+                                                           shs=leaves["sh"], scales=leaves["s"], rotations=leaves["r"])
+        assert color.shape == (3, H, W) and depth.shape == (1, H, W) and alpha.shape == (1, H, W)
+        assert radii.dtype == torch.int32 and radii.shape == (P,)
+        g = torch.Generator(device=dev).manual_seed(5)
+        loss = (color * torch.randn(3, H, W, device=dev, generator=g)).sum() + 0.3 * depth.sum() + (alpha ** 2).sum()
+        loss.backward()
+        return {k: v.grad.clone() for k, v in leaves.items()}, color
+
+    g1, c1 = run(torch.ones(P, 1, device=dev))
+    gc, c2 = run(conf)
+    g1b, _ = run(torch.ones(P, 1, device=dev))
+    assert torch.equal(c1, c2)
+    for k in g1:  # no float atomics anywhere: bitwise reproducible
+        assert torch.equal(g1[k], g1b[k]), k
+    assert torch.equal(gc["m2"], g1["m2"])  # screen-space gradient is NOT scaled (ref __init__.py:149)
+    assert float(g1["m2"][:, 2].abs().max()) == 0.0 and float(g1["m2"][:, :2].abs().max()) > 0  # quirk 8
+    for k in ("m", "o", "s", "r"):
+        assert torch.allclose(gc[k], g1[k] * conf, rtol=1e-6, atol=0), k
+    assert torch.allclose(gc["sh"], g1["sh"] * conf[..., None], rtol=1e-6, atol=0)
+
+
+def test_mark_visible_matches_oracle(oracle):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = syn.scene_c2(P=5000)
+    cam = sc["cameras"][1]
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    s = GaussianRasterizationSettings(480, 640, cam["tanfovx"], cam["tanfovy"], t(sc["bg"]), 1.0, t(cam["viewmatrix"]),
+                                      t(cam["projmatrix"]), 0, t(cam["campos"]), False, False, torch.ones(5000, 1, device=dev))
+    vis = GaussianRasterizer(s).markVisible(t(sc["means3D"]))
+    assert vis.dtype == torch.bool
+    assert np.array_equal(vis.cpu().numpy(), oracle.mark_visible(sc["means3D"], cam["viewmatrix"], cam["projmatrix"]))
+
+
+def test_capped_forward_no_sync_and_overflow_flag():
+    """gvd_raster_forward_capped: same images without the host sync; overflow is flagged, not UB."""
+    import ctypes
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    sc = syn.scene_c1()
+    cam = sc["cameras"][0]
+    st_h, _ = run_hip(sc, cam)
+    L = _C.lib()
+    P, W, H = 1000, 128, 128
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    m3, op, scl, rot, sh = t(sc["means3D"]), t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"]), t(sc["shs"])
+    vm, pm, cp, bg = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["campos"]), t(sc["bg"])
+    for cap, expect in ((10000, 0), (1000, -4)):
+        geom = torch.empty(L.gvd_raster_geometry_bytes(P, W, H), dtype=torch.uint8, device=dev)
+        img = torch.empty(L.gvd_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        binb = torch.empty(L.gvd_raster_binning_bytes(cap), dtype=torch.uint8, device=dev)
+        color, depth, alpha = (torch.empty(n, H, W, device=dev) for n in (3, 1, 1))
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        status = torch.full((1,), 123, dtype=torch.int32, device=dev)
+        rc = L.gvd_raster_forward_capped(geom.data_ptr(), binb.data_ptr(), img.data_ptr(), cap, P, 3, 16, bg.data_ptr(), W, H,
+                                         m3.data_ptr(), sh.data_ptr(), None, op.data_ptr(), scl.data_ptr(), 1.0, rot.data_ptr(), None,
+                                         vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), cam["tanfovx"], cam["tanfovy"], 0,
+                                         color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), status.data_ptr(), 0,
+                                         torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(status.item()) == expect
+        if expect == 0:
+            assert np.array_equal(color.cpu().numpy(), st_h["color"])
+            assert np.array_equal(alpha.cpu().numpy(), st_h["alpha"])
+
+
+def test_full_size_properties():
+    """Size-independent properties at BASELINE's full size (C2): sorted keys, ranges partition [0,R),
+    alpha/T bounds, and linearity of the backward in the incoming pixel gradients."""
+    sc = syn.scene_c2()
+    cam = sc["cameras"][5]
+    H, W = 480, 640
+    g1, g2 = _grads(H, W, 31), _grads(H, W, 32)
+    st, ga = run_hip(sc, cam, g1)
+    _, gb = run_hip(sc, cam, g2)
+    mix = tuple(0.7 * a - 1.3 * b for a, b in zip(g1, g2))
+    _, gm = run_hip(sc, cam, mix)
+    k = st["point_list_keys"].view(np.uint64)
+    assert np.all(k[1:] >= k[:-1])
+    r = st["ranges"].view(np.uint32).astype(np.int64)
+    lens = r[:, 1] - r[:, 0]
+    assert lens.sum() == st["R"] and np.all(lens >= 0)
+    nz = lens > 0
+    order = np.argsort(r[nz, 0])  # non-empty tiles laid end to end in tile order
+    assert np.array_equal(r[nz, 0][order][1:], r[nz, 1][order][:-1]) and r[nz, 0].min() == 0
+    assert np.array_equal(order, np.arange(order.size))
+    tiles = (k >> np.uint64(32)).astype(np.int64)
+    assert np.array_equal(np.bincount(tiles, minlength=r.shape[0]), lens)
+    assert st["alpha"].min() >= 0.0 and st["alpha"].max() <= 1.0 + 1e-5
+    assert np.all(st["n_contrib"].view(np.uint32).reshape(-1) <= np.repeat(lens.reshape(30, 40), 16, 0).repeat(16, 1).reshape(-1))
+    for key in ga:
+        lin = 0.7 * ga[key] - 1.3 * gb[key]
+        assert rel_to_max(gm[key], lin) < 1e-4, key  # fp32 rounding of the cancelling rotation/scale terms
