@@ -136,6 +136,7 @@ int forward_stage1(const FwdIn& in, const gvd::Layout& L, char* geom, char* img,
     ta.cursor = L.lds_hist ? nullptr : (uint32_t*)(geom + L.cursor);
     ta.chunk_base = (uint32_t*)(geom + L.chunk_base);
     ta.scalars = (uint32_t*)(geom + L.scalars);
+    ta.tile_order = (uint32_t*)(img + L.tile_order);
     ta.d_status = d_status;
     ta.host_mirror = mirror;
     {
@@ -179,6 +180,7 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = in.background;
     ra.out_color = in.out_color; ra.out_depth = in.out_depth; ra.out_alpha = in.out_alpha;
     ra.n_contrib = (uint32_t*)(img + L.n_contrib);
+    ra.tile_order = (const uint32_t*)(img + L.tile_order);
     {
         ProfScope ps("render_fwd", stream);
         launch_render_fwd(ra, L.T, stream);
@@ -337,6 +339,7 @@ int gvd_raster_backward(
     RenderBwdArgs ra{};
     ra.W = width; ra.H = height; ra.gx = L.gx; ra.gy = L.gy; ra.capacity = (uint32_t)R;
     ra.ranges = (const uint32_t*)(img + L.ranges); ra.point_list = (const uint32_t*)(bin + L.point_list);
+    ra.tile_order = (const uint32_t*)(img + L.tile_order);
     ra.n_contrib = (const uint32_t*)(img + L.n_contrib); ra.point_offsets = (const uint32_t*)(geom + L.point_offsets);
     ra.radii = radii; ra.means2D = (const float*)(geom + L.means2D); ra.conic_opacity = (const float*)(geom + L.conic_opacity);
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = background; ra.alphas = alphas;

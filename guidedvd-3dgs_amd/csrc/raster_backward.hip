@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     __shared__ uint32_t s_wcount[4];
     __shared__ uint32_t s_max;
 
-    const int tile = blockIdx.x;
+    const int tile = (int)a.tile_order[blockIdx.x];
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             if (!__any(act)) continue;  // wave-uniform
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
             if (act) {
+#pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
                 const float4 c = s_cd[j];
                 T = T / (1.f - alpha);
                 const float dchannel_dcolor = alpha * T;
@@ -167,20 +168,10 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                 v4 = -0.5f * gdy * dy * dL_dG;
                 v5 = G * dL_dopa;
             }
-            v0 = wave_sum_to_lane63(v0);
-            v1 = wave_sum_to_lane63(v1);
-            v2 = wave_sum_to_lane63(v2);
-            v3 = wave_sum_to_lane63(v3);
-            v4 = wave_sum_to_lane63(v4);
-            v5 = wave_sum_to_lane63(v5);
-            v6 = wave_sum_to_lane63(v6);
-            v7 = wave_sum_to_lane63(v7);
-            v8 = wave_sum_to_lane63(v8);
-            v9 = wave_sum_to_lane63(v9);
-            if (lane == 63) {
-                float* o = &s_part[w][j][0];
+            wave_reduce10(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+            if ((lane & 31) == 31) {  // lane 31: totals of values 0..4, lane 63: totals of values 5..9
+                float* o = &s_part[w][j][(lane >> 5) * 5];
                 o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
-                o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8; o[9] = v9;
             }
         }
         __syncthreads();

@@ -19,6 +19,7 @@
 // is a total order and equals the stable-sort order of the reference's emission sequence.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "raster_kernels.h"
 #include "raster_math.h"
@@ -194,12 +195,25 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s
     return wbase + incl - v;
 }
 
+// 256 buckets, descending in list length, ~6 % relative resolution (4-bit mantissa).
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t c)
+{
+    const uint32_t v = c + 1u;
+    const int e = 31 - __clz((int)v);                     // 0..31
+    const uint32_t m = e >= 4 ? ((v >> (e - 4)) & 15u) : ((v << (4 - e)) & 15u);
+    const uint32_t k = min(255u, (uint32_t)e * 16u + m);  // ascending in c
+    return 255u - k;
+}
+
 __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
+    __shared__ uint32_t s_bins[256];
     const int tid = threadIdx.x;
     if (tid == 0) s_max = 0;
+    if (tid < 256) s_bins[tid] = 0;
+    __syncthreads();
     // ---- tiles ----
     const int per = (a.T + 1023) / 1024;
     const int t0 = tid * per, t1 = min(a.T, t0 + per);
@@ -218,8 +232,23 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
         a.ranges[2 * t + 1] = c ? run + c : 0u;
         if (a.cursor) a.cursor[t] = run;
         run += c;
+        atomicAdd(&s_bins[cost_bucket(c)], 1u);
     }
     if (lmax) atomicMax(&s_max, lmax);
+    // ---- tile_order: tiles in (coarsely) descending list length, so that the blend kernels'
+    //      workgroups are dispatched longest-first (LPT) and the tail of the launch is short ----
+    __syncthreads();
+    {
+        uint32_t tb;
+        const uint32_t mine = tid < 256 ? s_bins[tid] : 0u;
+        const uint32_t excl = block_excl_scan_1024(mine, s_w, &tb);
+        if (tid < 256) s_bins[tid] = excl;
+        __syncthreads();
+        for (int t = t0; t < t1; t++) {
+            const uint32_t pos = atomicAdd(&s_bins[cost_bucket(a.tile_count[t])], 1u);
+            a.tile_order[pos] = (uint32_t)t;
+        }
+    }
     // ---- per-block instance bases (exclusive scan of block_total) ----
     const int perb = (a.B + 1023) / 1024;
     const int b0 = tid * perb, b1 = min(a.B, b0 + perb);
@@ -380,7 +409,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     __shared__ uint32_t s_pos[256];
     __shared__ uint32_t s_wcount[4];
 
-    const int tile = blockIdx.x;
+    const int tile = (int)a.tile_order[blockIdx.x];
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -432,27 +461,50 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         }
         __syncthreads();
         // ---- blend ----
-        if (!done) {
-            for (uint32_t j = 0; j < n; j++) {
-                const float2 gxy = s_xy[j];
-                const float4 con_o = s_co[j];
-                const float dx = gxy.x - pixfx, dy = gxy.y - pixfy;
-                const float power = gauss_power(con_o.x, con_o.y, con_o.z, dx, dy);
-                if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, con_o.w * __expf(power));
-                if (alpha < 1.0f / 255.0f) continue;
-                const float test_T = T * (1.f - alpha);
-                if (test_T < 0.0001f) { done = true; break; }
-                const float4 c = s_cd[j];
-                C0 = fmaf(c.x * alpha, T, C0);
-                C1 = fmaf(c.y * alpha, T, C1);
-                C2 = fmaf(c.z * alpha, T, C2);
-                weight = fmaf(alpha, T, weight);
-                D = fmaf(c.w * alpha, T, D);
-                T = test_T;
-                last_contributor = s_pos[j];
-            }
+        // Branch-free, 4 entries per trip: the per-entry geometry (power, exp, alpha) of the 4 entries
+        // is independent work the scheduler can overlap with the LDS latency, and only the short
+        // T-recurrence is serial.  Per-pixel semantics are exactly forward.cu:329-368: an entry
+        // contributes iff power<=0, alpha>=1/255 and the pixel is not done; the first entry with
+        // T*(1-alpha) < 1e-4 marks the pixel done and is not blended.
+#define GVD_BLEND_ONE(XY, CO, CD, POS)                                                            \
+        {                                                                                         \
+            const float dx = (XY).x - pixfx, dy = (XY).y - pixfy;                                 \
+            const float power = gauss_power((CO).x, (CO).y, (CO).z, dx, dy);                      \
+            const float alpha = fminf(0.99f, (CO).w * __expf(power));                             \
+            const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);              \
+            const float test_T = T * (1.f - alpha);                                               \
+            const bool stop = valid && (test_T < 0.0001f);                                        \
+            const bool contrib = valid && !stop;                                                  \
+            done = done || stop;                                                                  \
+            const float Tc = contrib ? T : 0.0f;                                                  \
+            C0 = fmaf((CD).x * alpha, Tc, C0);                                                    \
+            C1 = fmaf((CD).y * alpha, Tc, C1);                                                    \
+            C2 = fmaf((CD).z * alpha, Tc, C2);                                                    \
+            weight = fmaf(alpha, Tc, weight);                                                     \
+            D = fmaf((CD).w * alpha, Tc, D);                                                      \
+            T = contrib ? test_T : T;                                                             \
+            last_contributor = contrib ? (POS) : last_contributor;                                \
         }
+        uint32_t j = 0;
+        for (; j + 4 <= n; j += 4) {
+            if (__all(done)) break;  // wave-uniform: this strip is finished
+            const float2 xy0 = s_xy[j], xy1 = s_xy[j + 1], xy2 = s_xy[j + 2], xy3 = s_xy[j + 3];
+            const float4 co0 = s_co[j], co1 = s_co[j + 1], co2 = s_co[j + 2], co3 = s_co[j + 3];
+            const float4 cd0 = s_cd[j], cd1 = s_cd[j + 1], cd2 = s_cd[j + 2], cd3 = s_cd[j + 3];
+            const uint32_t p0 = s_pos[j], p1 = s_pos[j + 1], p2 = s_pos[j + 2], p3 = s_pos[j + 3];
+            GVD_BLEND_ONE(xy0, co0, cd0, p0)
+            GVD_BLEND_ONE(xy1, co1, cd1, p1)
+            GVD_BLEND_ONE(xy2, co2, cd2, p2)
+            GVD_BLEND_ONE(xy3, co3, cd3, p3)
+        }
+        for (; j < n; j++) {
+            const float2 xy0 = s_xy[j];
+            const float4 co0 = s_co[j];
+            const float4 cd0 = s_cd[j];
+            const uint32_t p0 = s_pos[j];
+            GVD_BLEND_ONE(xy0, co0, cd0, p0)
+        }
+#undef GVD_BLEND_ONE
     }
     if (inside) {
         const size_t pid = (size_t)py * a.W + px;
@@ -510,9 +562,17 @@ void launch_sort_tiles(const SortArgs& a, int T, int max_class, hipStream_t s)
     if (max_class >= 1) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(T), dim3(1024), 16384 * 8, s, a);
     if (max_class >= 2) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(T), dim3(1024), 0, s, a);
 }
+static size_t env_bytes(const char* name, size_t dflt)
+{
+    const char* e = getenv(name);
+    return e ? (size_t)atol(e) : dflt;
+}
 void launch_render_fwd(const RenderArgs& a, int T, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), 0, s, a);
+    // Extra (unused) dynamic LDS caps the resident workgroups per CU so that the hardware dispatcher
+    // hands out the LPT-ordered tiles dynamically instead of placing every tile at t=0.
+    static const size_t pad = env_bytes("GVD_FWD_LDS_PAD", 0);
+    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), pad, s, a);
 }
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
 {

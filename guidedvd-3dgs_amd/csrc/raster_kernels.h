@@ -20,7 +20,7 @@ struct TileScanArgs {
     uint32_t capacity;
     const uint32_t* tile_count;
     const uint32_t* block_total;
-    uint32_t *ranges, *cursor, *chunk_base, *scalars;
+    uint32_t *ranges, *cursor, *chunk_base, *scalars, *tile_order;
     int32_t* d_status;
     volatile uint32_t* host_mirror;
 };
@@ -46,7 +46,7 @@ struct SortArgs {
 struct RenderArgs {
     int W, H, gx, gy;
     uint32_t capacity;
-    const uint32_t *ranges, *point_list;
+    const uint32_t *ranges, *point_list, *tile_order;
     const float *means2D, *conic_opacity, *rgbd, *bg;
     float *out_color, *out_depth, *out_alpha;
     uint32_t* n_contrib;
@@ -55,7 +55,7 @@ struct RenderArgs {
 struct RenderBwdArgs {
     int W, H, gx, gy;
     uint32_t capacity;
-    const uint32_t *ranges, *point_list, *n_contrib, *point_offsets;
+    const uint32_t *ranges, *point_list, *n_contrib, *point_offsets, *tile_order;
     const int* radii;
     const float *means2D, *conic_opacity, *rgbd, *bg, *alphas;
     const float *dL_dpix, *dL_dpix_depth, *dL_dalphas;

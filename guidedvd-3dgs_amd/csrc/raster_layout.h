@@ -22,7 +22,7 @@ struct Layout {
         point_offsets, scalars, hist, block_total, chunk_base, tile_count, cursor;
     size_t geom_bytes;
     // image chunk
-    size_t ranges, n_contrib;
+    size_t ranges, n_contrib, tile_order;
     size_t img_bytes;
     // binning chunk (depends on capacity R)
     size_t keys, point_list, bucket, partials;
@@ -69,6 +69,7 @@ inline Layout make_layout(int P, int W, int H, uint32_t R)
     c = 0;
     L.ranges = carve(c, (size_t)L.T * 8);
     L.n_contrib = carve(c, (size_t)W * H * 4);
+    L.tile_order = carve(c, (size_t)L.T * 4);
     L.img_bytes = c + kAlign;
     c = 0;
     const size_t Rz = (size_t)(R > 0 ? R : 1);

@@ -226,19 +226,56 @@ __device__ __forceinline__ bool tile_may_contribute(float mx, float my, float co
     return !(qmin > tau + margin);
 }
 
-// 64-lane sum, result valid in lane 63 (DPP: quad_perm, row_ror, row_bcast15/31; gfx9 family).
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+// Sum of 10 per-lane values over the 64 lanes of a wave, 36 instructions in one hand-scheduled block:
+//   phase 1  v_permlane32_swap pairs (v[k], v[k+5]): after one add, lanes 0-31 carry the lane-pair sums
+//            of v[0..4] and lanes 32-63 those of v[5..9]  (5 swaps + 5 adds instead of 10 x 1 DPP step);
+//   phase 2  5 values x {quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_ror:4, row_ror:8, row_bcast:15}
+//            fused v_add_f32_dpp, interleaved over the 5 values so that every DPP read is >= 4
+//            instructions behind the VALU write of its source (DPP needs 2 wait states).
+// On return v[k] holds, in lane 31, the wave total of input v[k] and, in lane 63, the total of input
+// v[k+5]  (k = 0..4).  v[5..9] are clobbered.  All 64 lanes must be active.
+__device__ __forceinline__ void wave_reduce10(float& v0, float& v1, float& v2, float& v3, float& v4,
+                                              float& v5, float& v6, float& v7, float& v8, float& v9)
 {
-#define GVD_DPP_ADD(ctrl, rmask)                                                                     \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
-    GVD_DPP_ADD(0xb1, 0xf);   // quad_perm:[1,0,3,2]
-    GVD_DPP_ADD(0x4e, 0xf);   // quad_perm:[2,3,0,1]
-    GVD_DPP_ADD(0x124, 0xf);  // row_ror:4
-    GVD_DPP_ADD(0x128, 0xf);  // row_ror:8
-    GVD_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1,3
-    GVD_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2,3
-#undef GVD_DPP_ADD
-    return v;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %5\n\t"
+        "v_permlane32_swap_b32 %1, %6\n\t"
+        "v_permlane32_swap_b32 %2, %7\n\t"
+        "v_permlane32_swap_b32 %3, %8\n\t"
+        "v_permlane32_swap_b32 %4, %9\n\t"
+        "v_add_f32 %0, %0, %5\n\t"
+        "v_add_f32 %1, %1, %6\n\t"
+        "v_add_f32 %2, %2, %7\n\t"
+        "v_add_f32 %3, %3, %8\n\t"
+        "v_add_f32 %4, %4, %9\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
 }
 
 }  // namespace gvd
