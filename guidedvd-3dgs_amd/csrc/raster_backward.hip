@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_d = 0.f, acc_a = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);  // uniform; x + (-0)*.. == x
 
     for (uint32_t bdone = 0; bdone < tile_max; bdone += 256) {
         // ---- stage (descending list order) + cull + compact ----
@@ -120,60 +121,100 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         __syncthreads();
 
         // ---- per-pixel gradient terms, wave-reduced per Gaussian ----
-        for (uint32_t j = 0; j < n; j++) {
-            const float2 gxy = s_xy[j];
-            const float4 con_o = s_co[j];
-            const float dx = gxy.x - pixfx, dy = gxy.y - pixfy;
-            const float power = gauss_power(con_o.x, con_o.y, con_o.z, dx, dy);
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, con_o.w * G);
-            const bool act = (s_ord[j] < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (!__any(act)) continue;  // wave-uniform
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
-            if (act) {
+        // Two entries per trip: geometry (power, exp, alpha, 1/(1-alpha)) of both is independent of the
+        // per-pixel recurrences (T, accum_rec*, last_*), whose loop-carried part is one multiply/fma
+        // each; the bodies are predicated (no divergent branches) so the scheduler can overlap entry
+        // j+1's geometry with entry j's gradient terms and reduction.
+#define GVD_BWD_GEOM(J, DX, DY, G, ALPHA, ACT)                                                    \
+        const float2 gxy##J = s_xy[j + J];                                                        \
+        const float4 con##J = s_co[j + J];                                                        \
+        const float DX = gxy##J.x - pixfx, DY = gxy##J.y - pixfy;                                 \
+        const float pw##J = gauss_power(con##J.x, con##J.y, con##J.z, DX, DY);                    \
+        const float G = __expf(pw##J);                                                            \
+        const float ALPHA = fminf(0.99f, con##J.w * G);                                           \
+        const bool ACT = (s_ord[j + J] < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);
+// Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the value the next
+// active entry would have formed (pushing (last_alpha=0, .) is the identity: fmaf(1, acc, 0*c) == acc
+// bit-exactly) and all ten terms are exactly 0 -- no per-variable selects needed.
+#define GVD_BWD_TERMS(J, DX, DY, G, ALPHA, ACT, V)                                                \
+        float V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9;                         \
+        {                                                                                         \
+            const float4 c = s_cd[j + J];                                                         \
+            const float am = ACT ? ALPHA : 0.f;                                                   \
+            const float gm = ACT ? G : 0.f;                                                       \
+            const float one_m_a = 1.f - am;                                                       \
+            T = T / one_m_a; /* IEEE division as backward.cu:510: v_rcp's 1 ulp doubles dL_dscale error */ \
+            const float dchannel_dcolor = am * T;                                                 \
+            const float oml = 1.f - last_alpha;                                                   \
+            acc0 = fmaf(oml, acc0, last_alpha * lc0);                                             \
+            acc1 = fmaf(oml, acc1, last_alpha * lc1);                                             \
+            acc2 = fmaf(oml, acc2, last_alpha * lc2);                                             \
+            acc_d = fmaf(oml, acc_d, last_alpha * last_depth);                                    \
+            acc_a = fmaf(oml, acc_a, last_alpha);                                                 \
+            float dL_dopa = (c.x - acc0) * dLp0;                                                  \
+            dL_dopa = fmaf(c.y - acc1, dLp1, dL_dopa);                                            \
+            dL_dopa = fmaf(c.z - acc2, dLp2, dL_dopa);                                            \
+            dL_dopa = fmaf(c.w - acc_d, dLd, dL_dopa);                                            \
+            dL_dopa = fmaf(1.f - acc_a, dLa, dL_dopa);                                            \
+            dL_dopa *= T;                                                                         \
+            if (has_bg) dL_dopa += (-T_final / one_m_a) * bg_dot;                                 \
+            lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
+            const float dL_dG = con##J.w * dL_dopa;                                               \
+            const float gdx = gm * DX, gdy = gm * DY;                                             \
+            const float dG_ddelx = fmaf(-gdy, con##J.y, -gdx * con##J.x);                         \
+            const float dG_ddely = fmaf(-gdx, con##J.y, -gdy * con##J.z);                         \
+            const float hq = -0.5f * dL_dG;                                                       \
+            V##0 = dL_dG * dG_ddelx * ddelx_dx;                                                   \
+            V##1 = dL_dG * dG_ddely * ddely_dy;                                                   \
+            V##2 = hq * gdx * DX;                                                                 \
+            V##3 = hq * gdx * DY;                                                                 \
+            V##4 = hq * gdy * DY;                                                                 \
+            V##5 = gm * dL_dopa;                                                                  \
+            V##6 = dchannel_dcolor * dLp0;                                                        \
+            V##7 = dchannel_dcolor * dLp1;                                                        \
+            V##8 = dchannel_dcolor * dLp2;                                                        \
+            V##9 = dchannel_dcolor * dLd;                                                         \
+        }
+#define GVD_BWD_STORE10(J, V)                                                                     \
+        wave_reduce10(V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9);                \
+        if ((lane & 31) == 31) {                                                                  \
+            float* o = &s_part[w][j + J][(lane >> 5) * 5];                                        \
+            o[0] = V##0; o[1] = V##1; o[2] = V##2; o[3] = V##3; o[4] = V##4;                      \
+        }
+        {
 #pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
-                const float4 c = s_cd[j];
-                T = T / (1.f - alpha);
-                const float dchannel_dcolor = alpha * T;
-                float dL_dopa = 0.0f;
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                lc0 = c.x;
-                dL_dopa += (c.x - acc0) * dLp0;
-                v6 = dchannel_dcolor * dLp0;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                lc1 = c.y;
-                dL_dopa += (c.y - acc1) * dLp1;
-                v7 = dchannel_dcolor * dLp1;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                lc2 = c.z;
-                dL_dopa += (c.z - acc2) * dLp2;
-                v8 = dchannel_dcolor * dLp2;
-                acc_d = last_alpha * last_depth + (1.f - last_alpha) * acc_d;
-                last_depth = c.w;
-                dL_dopa += (c.w - acc_d) * dLd;
-                v9 = dchannel_dcolor * dLd;
-                acc_a = last_alpha + (1.f - last_alpha) * acc_a;
-                dL_dopa += (1.f - acc_a) * dLa;
-                dL_dopa *= T;
-                last_alpha = alpha;
-                dL_dopa += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = con_o.w * dL_dopa;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * con_o.x - gdy * con_o.y;
-                const float dG_ddely = -gdy * con_o.z - gdx * con_o.y;
-                v0 = dL_dG * dG_ddelx * ddelx_dx;
-                v1 = dL_dG * dG_ddely * ddely_dy;
-                v2 = -0.5f * gdx * dx * dL_dG;
-                v3 = -0.5f * gdx * dy * dL_dG;
-                v4 = -0.5f * gdy * dy * dL_dG;
-                v5 = G * dL_dopa;
+            uint32_t j = 0;
+            for (; j + 2 <= n; j += 2) {
+                GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
+                GVD_BWD_GEOM(1, dx1, dy1, G1, alpha1, act1)
+                const bool any0 = __any(act0), any1 = __any(act1);
+                if (any0 && any1) {
+                    GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
+                    GVD_BWD_TERMS(1, dx1, dy1, G1, alpha1, act1, q)
+                    wave_reduce20(p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, q0, q1, q2, q3, q4, q5, q6, q7, q8, q9);
+                    if ((lane & 15) == 15) {  // row 0: A[0..4], row 1: B[0..4], row 2: A[5..9], row 3: B[5..9]
+                        float* o = &s_part[w][j + ((lane >> 4) & 1)][(lane >> 5) * 5];
+                        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3; o[4] = p4;
+                    }
+                } else if (any0) {
+                    GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
+                    GVD_BWD_STORE10(0, p)
+                } else if (any1) {
+                    GVD_BWD_TERMS(1, dx1, dy1, G1, alpha1, act1, q)
+                    GVD_BWD_STORE10(1, q)
+                }
             }
-            wave_reduce10(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
-            if ((lane & 31) == 31) {  // lane 31: totals of values 0..4, lane 63: totals of values 5..9
-                float* o = &s_part[w][j][(lane >> 5) * 5];
-                o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
+            if (j < n) {
+                GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
+                if (__any(act0)) {
+                    GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
+                    GVD_BWD_STORE10(0, p)
+                }
             }
         }
+#undef GVD_BWD_STORE10
+#undef GVD_BWD_GEOM
+#undef GVD_BWD_TERMS
         __syncthreads();
 
         // ---- one partial record per kept (Gaussian, tile) instance, at its Gaussian-order slot ----
