@@ -309,7 +309,7 @@ int gvd_raster_forward_capped(
     return forward_stage2(in, L, geom, bin, img, capacity, 2, stream);
 }
 
-int gvd_raster_backward(
+int gvd_raster_backward_conf(
     int P, int D, int M, int R, const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -319,13 +319,13 @@ int gvd_raster_backward(
     const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-    int debug, void* stream_)
+    const float* confidence, int debug, void* stream_)
 {
     using namespace gvd;
     hipStream_t stream = (hipStream_t)stream_;
     if (P == 0) return GVD_OK;
     if (P < 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(GVD_ERR_INVALID, "bad backward arguments");
-    if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas) return fail(GVD_ERR_INVALID, "null pixel gradient");
+    if (!dL_dpix || !alphas) return fail(GVD_ERR_INVALID, "null pixel gradient");
     if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
         (M > 0 && !dL_dsh))
         return fail(GVD_ERR_INVALID, "null gradient output");
@@ -358,6 +358,7 @@ int gvd_raster_backward(
     ga.viewmatrix = viewmatrix; ga.projmatrix = projmatrix; ga.campos = campos; ga.radii = radii;
     ga.clamped = (const uint32_t*)(geom + L.clamped); ga.point_offsets = (const uint32_t*)(geom + L.point_offsets);
     ga.partials = partials;
+    ga.confidence = confidence;
     ga.has_sh = (shs != nullptr && M > 0 && colors_precomp == nullptr) ? 1 : 0;
     ga.has_scales = (scales != nullptr && rotations != nullptr && cov3D_precomp == nullptr) ? 1 : 0;
     ga.dL_dmean2D = dL_dmean2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolor = dL_dcolor;
@@ -369,6 +370,25 @@ int gvd_raster_backward(
     }
     AFTER_LAUNCH("gather_bwd");
     return GVD_OK;
+}
+
+int gvd_raster_backward(
+    int P, int D, int M, int R, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    int debug, void* stream_)
+{
+    return gvd_raster_backward_conf(P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales,
+                                    scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx,
+                                    tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dpix_depth,
+                                    dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
+                                    dL_dcov3D, dL_dsh, dL_dscale, dL_drot, nullptr, debug, stream_);
 }
 
 int gvd_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

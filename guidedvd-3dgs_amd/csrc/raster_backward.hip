@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         dLp0 = a.dL_dpix[pid];
         dLp1 = a.dL_dpix[HW + pid];
         dLp2 = a.dL_dpix[2 * HW + pid];
-        dLd = a.dL_dpix_depth[pid];
-        dLa = a.dL_dalphas[pid];
+        if (a.dL_dpix_depth) dLd = a.dL_dpix_depth[pid];  // NULL == all-zero gradient
+        if (a.dL_dalphas) dLa = a.dL_dalphas[pid];
     }
     float bg_dot = 0.f;  // backward.cu:575-577 accumulation order
     bg_dot += a.bg[0] * dLp0;
@@ -255,14 +255,18 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
             s[8] += r2.x; s[9] += r2.y;
         }
     }
+    // Optional per-Gaussian confidence (the fork's Python-side scaling, ref __init__.py:147-157, folded
+    // in): every returned gradient except the screen-space one is multiplied by conf AFTER it has been
+    // formed exactly as without confidence (x * 1.0f == x, so conf == NULL and conf == 1 agree bitwise).
+    const float conf = a.confidence ? a.confidence[idx] : 1.0f;
     a.dL_dmean2D[3 * idx] = s[0];
     a.dL_dmean2D[3 * idx + 1] = s[1];
     a.dL_dmean2D[3 * idx + 2] = 0.f;
     reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(s[2], s[3], 0.f, s[4]);
-    a.dL_dopacity[idx] = s[5];
-    a.dL_dcolor[3 * idx] = s[6];
-    a.dL_dcolor[3 * idx + 1] = s[7];
-    a.dL_dcolor[3 * idx + 2] = s[8];
+    a.dL_dopacity[idx] = s[5] * conf;
+    a.dL_dcolor[3 * idx] = s[6] * conf;
+    a.dL_dcolor[3 * idx + 1] = s[7] * conf;
+    a.dL_dcolor[3 * idx + 2] = s[8] * conf;
     a.dL_ddepth[idx] = s[9];
 
     float* dm = a.dL_dmean3D + 3 * idx;
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
         float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
         const int D = a.D;
 #define SHV(k, ch) sh[3 * (k) + (ch)]
-#define DSH(k, wgt) { const float w_ = (wgt); dsh[3 * (k)] = w_ * dRGB[0]; dsh[3 * (k) + 1] = w_ * dRGB[1]; dsh[3 * (k) + 2] = w_ * dRGB[2]; }
+#define DSH(k, wgt) { const float w_ = (wgt); dsh[3 * (k)] = (w_ * dRGB[0]) * conf; dsh[3 * (k) + 1] = (w_ * dRGB[1]) * conf; dsh[3 * (k) + 2] = (w_ * dRGB[2]) * conf; }
         DSH(0, SH_C0);
         int written = 1;
         if (D > 0) {
@@ -451,7 +455,7 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
     } else {
         for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
     }
-    dm[0] = g0; dm[1] = g1; dm[2] = g2;
+    dm[0] = g0 * conf; dm[1] = g1 * conf; dm[2] = g2 * conf;
 
     // ---------------- cov3D backward (backward.cu:278-341) ----------------
     if (a.has_scales) {
@@ -488,10 +492,23 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
         dq[1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
         dq[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
         dq[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+        if (a.confidence) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) ds[k] *= conf;
+#pragma unroll
+            for (int k = 0; k < 4; k++) dq[k] *= conf;
+        }
     } else {
         ds[0] = ds[1] = ds[2] = 0.f;
         dq[0] = dq[1] = dq[2] = dq[3] = 0.f;
     }
+}
+
+// dL_dcov3D is an input of the scale/rotation backward above, so it is scaled last, in place.
+__global__ void __launch_bounds__(256) k_scale_cov(int n, float* __restrict__ dL_dcov3D, const float* __restrict__ conf)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dL_dcov3D[i] *= conf[i / 6];
 }
 
 void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
@@ -501,6 +518,9 @@ void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    // only needed when the caller consumes dL_dcov3D (precomputed-covariance path)
+    if (a.confidence && !a.has_scales)
+        hipLaunchKernelGGL(k_scale_cov, dim3((a.P * 6 + 255) / 256), dim3(256), 0, s, a.P * 6, a.dL_dcov3D, a.confidence);
 }
 
 }  // namespace gvd

@@ -158,18 +158,31 @@ __global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, u
     const int t = blockIdx.x * 64 + tl;
     const int per = (B + 15) / 16;
     const int b0 = seg * per, b1 = min(B, b0 + per);
+    constexpr int U = 8;  // loads in flight per lane (the loop is latency-, not bandwidth-bound)
     uint32_t sum = 0;
-    if (t < T)
-        for (int b = b0; b < b1; b++) sum += hist[(size_t)b * T + t];
+    if (t < T) {
+        for (int b = b0; b < b1; b += U) {
+            uint32_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = (b + u < b1) ? hist[(size_t)(b + u) * T + t] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; u++) sum += v[u];
+        }
+    }
     s_seg[seg][tl] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int s = 0; s < seg; s++) run += s_seg[s][tl];
     if (t < T) {
-        for (int b = b0; b < b1; b++) {
-            const uint32_t v = hist[(size_t)b * T + t];
-            hist[(size_t)b * T + t] = run;
-            run += v;
+        for (int b = b0; b < b1; b += U) {
+            uint32_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = (b + u < b1) ? hist[(size_t)(b + u) * T + t] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (b + u < b1) hist[(size_t)(b + u) * T + t] = run;
+                run += v[u];
+            }
         }
         if (seg == 15) tile_count[t] = run;  // per*16 >= B so the last segment ends at B
     }

@@ -69,6 +69,7 @@ struct GatherBwdArgs {
     const int* radii;
     const uint32_t *clamped, *point_offsets;
     const float* partials;
+    const float* confidence;  // [P] or NULL
     int has_sh, has_scales;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_ddepth;
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;

@@ -51,10 +51,13 @@ def lib():
         L.gvd_raster_forward_capped.argtypes = [_P, _P, _P, ctypes.c_uint32, _I, _I, _I, _P, _I, _I,
                                                 _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _F, _I,
                                                 _P, _P, _P, _P, _P, _I, _P]
+        _bw = [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P,
+               _F, _F, _P, _P, _P, _P, _P, _P, _P,
+               _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]
         L.gvd_raster_backward.restype = _I
-        L.gvd_raster_backward.argtypes = [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P,
-                                          _F, _F, _P, _P, _P, _P, _P, _P, _P,
-                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]
+        L.gvd_raster_backward.argtypes = _bw + [_I, _P]
+        L.gvd_raster_backward_conf.restype = _I
+        L.gvd_raster_backward_conf.argtypes = _bw + [_P, _I, _P]
         L.gvd_raster_mark_visible.restype = _I
         L.gvd_raster_mark_visible.argtypes = [_I, _P, _P, _P, _P, _P]
         L.gvd_raster_chunk_layout.argtypes = [_I, _I, _I, ctypes.c_uint32, ctypes.POINTER(_ChunkLayout)]
@@ -135,7 +138,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
-                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug):
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug,
+                                 confidence=None):
+    """Reference signature (rasterize_points.h:41-65) + optional `confidence` [P,1]: when given, the
+    returned gradients (all but dL_dmeans2D) are already multiplied by it inside the gather kernel.
+    dL_dout_depth / dL_dout_alpha may be None (zero gradient)."""
     dev = means3D.device
     if dev.type != "cuda":
         raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a ROCm device; got " + str(dev))
@@ -149,20 +156,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             f(rotations, "rotations"), f(cov3D_precomp, "cov3D_precomp"), f(viewmatrix, "viewmatrix"),
             f(projmatrix, "projmatrix"), f(sh, "sh"), f(campos, "campos"))
         gC, gD, gA, al = f(dL_dout_color, "dL_dout_color"), f(dL_dout_depth, "dL_dout_depth"), f(dL_dout_alpha, "dL_dout_alpha"), f(alphas, "alphas")
+        conf = f(confidence, "confidence")
+        if conf is not None and conf.numel() != P:
+            raise RuntimeError(f"confidence must have {P} elements, got {tuple(conf.shape)}")
         M = 0 if shs is None else shs.size(1)
         mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = mk(P, 3), mk(P, 3), mk(P, 3), mk(P, 1)
         dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh = mk(P, 2, 2), mk(P, 1), mk(P, 6), mk(P, M, 3)
         dL_dscales, dL_drotations = mk(P, 3), mk(P, 4)
         if P != 0:
-            rc = L.gvd_raster_backward(P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shs), _ptr(col), _ptr(al),
+            rc = L.gvd_raster_backward_conf(P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shs), _ptr(col), _ptr(al),
                                        _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cam),
                                        float(tan_fovx), float(tan_fovy), radii.contiguous().data_ptr(),
                                        geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
                                        _ptr(gC), _ptr(gD), _ptr(gA), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
                                        dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_ddepths.data_ptr(),
                                        dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M > 0 else None,
-                                       dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)), _stream())
+                                       dL_dscales.data_ptr(), dL_drotations.data_ptr(), _ptr(conf), int(bool(debug)), _stream())
             if rc < 0:
                 raise _err(rc)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations

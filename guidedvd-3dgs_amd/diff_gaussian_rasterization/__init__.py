@@ -19,6 +19,7 @@ Behaviour kept from the reference:
 The compute is the HIP library behind `_C` (ctypes -> libgvd_raster.so, C-ABI in include/gvd_raster.h).
 There is no CPU or eager fallback.
 """
+import functools
 from typing import NamedTuple
 
 import torch
@@ -75,6 +76,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom_buf, binning_buf, img_buf, alpha)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # untouched outputs arrive as None -> NULL at the C-ABI, no zero fills
         return color, radii, depth, alpha
 
     @staticmethod
@@ -82,22 +84,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geom_buf, binning_buf, img_buf, alpha) = ctx.saved_tensors
-        # outputs the loss did not touch arrive as None
+        # outputs the loss did not touch arrive as None (== zero gradient; the native side takes NULL)
         if grad_color is None:
             grad_color = torch.zeros_like(alpha).expand(3, -1, -1).contiguous()
-        if grad_depth is None:
-            grad_depth = torch.zeros_like(alpha)
-        if grad_alpha is None:
-            grad_alpha = torch.zeros_like(alpha)
         native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_color, grad_depth, grad_alpha,
                        sh, s.sh_degree, s.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, alpha, s.debug)
+        # The reference multiplies every gradient except the screen-space one by `confidence` [P,1] in
+        # Python (ref :147-157, seven elementwise launches); here the gather kernel applies it.
+        fused = functools.partial(_C.rasterize_gaussians_backward, confidence=s.confidence)
         (g_means2D, g_colors, g_opacity, g_means3D,
-         g_cov3D, g_sh, g_scales, g_rot) = _call_native(_C.rasterize_gaussians_backward, native_args, s.debug,
-                                                        "snapshot_bw.dump", "backward")
-        conf = s.confidence  # [P,1]; everything but the screen-space gradient is weighted by it
-        return (g_means3D * conf, g_means2D, g_sh * conf[..., None], g_colors * conf, g_opacity * conf,
-                g_scales * conf, g_rot * conf, g_cov3D * conf, None)
+         g_cov3D, g_sh, g_scales, g_rot) = _call_native(fused, native_args, s.debug, "snapshot_bw.dump", "backward")
+        return (g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rot, g_cov3D, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

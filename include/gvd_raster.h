@@ -154,6 +154,48 @@ int gvd_raster_backward(
     int debug,
     void* stream);
 
+/* Same as gvd_raster_backward plus the fork's per-Gaussian confidence[P] (may be NULL == all ones):
+ * folds the Python-side scaling of diff_gaussian_rasterization/__init__.py:147-157 into the gather
+ * kernel -- dL_dmean3D, dL_dopacity, dL_dcolor, dL_dsh, dL_dscale, dL_drot, dL_dcov3D are returned
+ * already multiplied by confidence; dL_dmean2D is not (ref :149).  dL_dpix_depth / dL_dalphas may be
+ * NULL (== zero gradient for that output), here and in gvd_raster_backward. */
+int gvd_raster_backward_conf(
+    int P, int D, int M, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* alphas,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* campos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    char* geom_buffer,
+    char* binning_buffer,
+    char* image_buffer,
+    const float* dL_dpix,
+    const float* dL_dpix_depth,
+    const float* dL_dalphas,
+    float* dL_dmean2D,
+    float* dL_dconic,
+    float* dL_dopacity,
+    float* dL_dcolor,
+    float* dL_ddepth,
+    float* dL_dmean3D,
+    float* dL_dcov3D,
+    float* dL_dsh,
+    float* dL_dscale,
+    float* dL_drot,
+    const float* confidence,
+    int debug,
+    void* stream);
+
 /* rasterizer.h:28-33  Rasterizer::markVisible.  present[P] is one byte (bool) per Gaussian. */
 int gvd_raster_mark_visible(int P, const float* means3D, const float* viewmatrix,
                             const float* projmatrix, uint8_t* present, void* stream);
