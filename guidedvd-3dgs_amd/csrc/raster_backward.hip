@@ -236,10 +236,10 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
+// Per-Gaussian part of the backward.  `dsh` is where this Gaussian's 3*M SH gradients go (global row,
+// or a row of the block's LDS staging tile).
+__device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int idx, float* dsh)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
     const bool visible = a.radii[idx] > 0;
     float s[kNV];
 #pragma unroll
@@ -271,7 +271,6 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
 
     float* dm = a.dL_dmean3D + 3 * idx;
     float* dcov = a.dL_dcov3D + 6 * idx;
-    float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
     float* ds = a.dL_dscale + 3 * idx;
     float* dq = a.dL_drot + 4 * idx;
     if (!visible) {
@@ -504,6 +503,33 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
     }
 }
 
+// dL_dsh is 48 floats (192 B) per Gaussian: written per thread it is a 192-byte-stride scatter (64 cache
+// lines per store instruction).  Instead each thread drops its row into an LDS tile (row stride 49
+// floats: conflict-free) and the block streams the tile out as contiguous float4 (1 KiB per wave store).
+constexpr int kShRow = 49;
+
+__global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
+{
+    extern __shared__ float s_sh[];  // [256][kShRow] when M == 16 (launch passes the size), else unused
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool stage_sh = (a.M == 16);
+    if (idx < a.P) gather_body(a, idx, stage_sh ? (s_sh + threadIdx.x * kShRow) : (a.dL_dsh + (size_t)idx * a.M * 3));
+    if (stage_sh) {
+        __syncthreads();
+        const size_t block_base = (size_t)blockIdx.x * 256 * 48;
+        const size_t total = (size_t)a.P * 48;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int i = (k * 256 + (int)threadIdx.x) * 4;  // float index inside the block's 256x48 tile
+            if (block_base + i < total) {
+                const int g = i / 48, c = i - g * 48;
+                const float* r = s_sh + g * kShRow + c;
+                *reinterpret_cast<float4*>(a.dL_dsh + block_base + i) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+    }
+}
+
 // dL_dcov3D is an input of the scale/rotation backward above, so it is scaled last, in place.
 __global__ void __launch_bounds__(256) k_scale_cov(int n, float* __restrict__ dL_dcov3D, const float* __restrict__ conf)
 {
@@ -517,7 +543,7 @@ void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 }
 void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + 255) / 256), dim3(256), a.M == 16 ? (size_t)256 * kShRow * 4 : 0, s, a);
     // only needed when the caller consumes dL_dcov3D (precomputed-covariance path)
     if (a.confidence && !a.has_scales)
         hipLaunchKernelGGL(k_scale_cov, dim3((a.P * 6 + 255) / 256), dim3(256), 0, s, a.P * 6, a.dL_dcov3D, a.confidence);
