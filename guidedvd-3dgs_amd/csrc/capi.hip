@@ -47,7 +47,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 // ---- per-kernel HIP-event timing (bench.py roofline leg) ----
 struct ProfRec { const char* name; hipEvent_t a, b; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+int g_prof_level = 0;  // 0 off, 1 blend kernels only (cheap: used inside bench's timed region), 2 every kernel
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
@@ -55,8 +55,9 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     const char* name;
     bool on;
-    ProfScope(const char* n, hipStream_t st) : s(st), name(n), on(g_prof_on)
+    ProfScope(const char* n, hipStream_t st) : s(st), name(n)
     {
+        on = g_prof_level >= 2 || (g_prof_level == 1 && n[0] == 'r');  // "render_fwd" / "render_bwd"
         if (on) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
@@ -404,7 +405,7 @@ int gvd_raster_mark_visible(int P, const float* means3D, const float* viewmatrix
     return GVD_OK;
 }
 
-void gvd_profile_enable(int enable) { g_prof_on = enable != 0; }
+void gvd_profile_enable(int level) { g_prof_level = level; }
 
 void gvd_profile_reset(void)
 {

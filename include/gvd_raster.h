@@ -231,10 +231,11 @@ typedef struct gvd_chunk_layout {
 void gvd_raster_chunk_layout(int P, int width, int height, uint32_t num_rendered, gvd_chunk_layout* out);
 
 /* Per-kernel timing with HIP events on the launch stream (for bench.py's roofline leg).
- * enable!=0 starts recording; gvd_profile_read sums the elapsed time (ms) and launch count of the
+ * level 1 records only the two blend kernels (2 events per launch: negligible perturbation, used inside
+ * the timed region), level 2 every kernel, 0 stops; gvd_profile_read sums the elapsed time (ms) and launch count of the
  * kernel `name` ("render_fwd", "render_bwd", "preprocess", ...) and clears nothing.  Reading
  * synchronises the recorded events. */
-void gvd_profile_enable(int enable);
+void gvd_profile_enable(int level);
 void gvd_profile_reset(void);
 int gvd_profile_read(const char* name, double* total_ms, int* launches);
 
