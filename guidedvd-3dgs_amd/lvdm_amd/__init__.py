@@ -1,0 +1,10 @@
+"""MI355X-native rebuild of the ViewCrafter DDIM denoise loop.
+
+    schedule   B4   beta / zero-terminal-SNR / DDIM tables, v-parameterisation helpers, timestep embedding
+    samplers   B2/B3 DDIMSampler, DDIMSamplerGuidance (same .sample() API as lvdm.models.samplers.*)
+    unet       B6-B11 UNetModel (state-dict compatible with the ViewCrafter checkpoint)
+    vae        B13  KL-VAE decoder (+ post_quant_conv) used inside the guided step
+    guidance   B12  LossGuidance
+    model      B1/B5 LatentDiffusion-shaped wrapper the samplers duck-type against (apply_model, decode)
+    ops        hot operators; HIP kernels (csrc/diffusion_*.hip) on ROCm devices, no silent CPU fallback
+"""

@@ -1,0 +1,81 @@
+"""The LatentDiffusion-shaped object the samplers duck-type against.
+
+Provides exactly what `DDIMSampler` / `DDIMSamplerGuidance` read from `model` in the reference
+(SURVEY 8b "Sampler API"): num_timesteps, betas, alphas_cumprod(_prev), device, use_dynamic_rescale, scale_arr,
+parameterization, apply_model, predict_*_from_z_and_v, q_sample, differentiable_decode_first_stage,
+decode_first_stage, .model (DiffusionWrapper with .diffusion_model), .first_stage_model.
+"""
+import torch
+import torch.nn as nn
+
+from .schedule import DiffusionSchedule
+from .unet import UNetModel
+from .vae import AutoencoderKLDecoder
+
+# configs/inference_pvd_1024.yaml:33-64 / :66-87
+VIEWCRAFTER_UNET = dict(in_channels=8, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+                        num_res_blocks=2, channel_mult=[1, 2, 4, 4], dropout=0.1, num_head_channels=64,
+                        transformer_depth=1, context_dim=1024, use_linear=True, use_checkpoint=False,
+                        temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
+                        use_relative_position=False, use_causal_attention=False, temporal_length=16,
+                        addition_attention=True, image_cross_attention=True, default_fs=10, fs_condition=True)
+VIEWCRAFTER_VAE = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                       ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+class DiffusionWrapper(nn.Module):
+    """ddpm3d.py:1420-1491, 'hybrid' conditioning: channel-concat c_concat, token-concat c_crossattn."""
+
+    def __init__(self, unet, conditioning_key="hybrid"):
+        super().__init__()
+        if conditioning_key != "hybrid":
+            raise NotImplementedError("ViewCrafter uses conditioning_key='hybrid'")
+        self.diffusion_model = unet
+        self.conditioning_key = conditioning_key
+
+    def forward(self, x, t, c_concat=None, c_crossattn=None, **kwargs):
+        xc = torch.cat([x] + list(c_concat), dim=1)
+        cc = torch.cat(list(c_crossattn), 1)
+        return self.diffusion_model(xc, t, context=cc, **kwargs)
+
+
+class LatentDiffusion(DiffusionSchedule):
+    def __init__(self, unet_config=None, first_stage_config=None, scale_factor=0.18215, perframe_ae=True, **schedule_kw):
+        super().__init__(**schedule_kw)
+        self.model = DiffusionWrapper(UNetModel(**(unet_config or VIEWCRAFTER_UNET)))
+        self.first_stage_model = AutoencoderKLDecoder(first_stage_config or VIEWCRAFTER_VAE)
+        self.scale_factor = scale_factor
+        self.perframe_ae = perframe_ae
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def apply_model(self, x_noisy, t, cond, **kwargs):  # ddpm3d.py:723-738
+        if not isinstance(cond, dict):
+            cond = {"c_crossattn": cond if isinstance(cond, list) else [cond]}
+        # sampler-only kwargs the reference's UNet swallows in **kwargs (openaimodel3d.py:548)
+        fwd_kw = {k: v for k, v in kwargs.items() if k in ("fs", "features_adapter")}
+        out = self.model(x_noisy, t, **cond, **fwd_kw)
+        return out[0] if isinstance(out, tuple) else out
+
+    def decode_core(self, z, **kwargs):  # ddpm3d.py:646-667
+        reshape_back = z.dim() == 5
+        if reshape_back:
+            b, _, t, _, _ = z.shape
+            z = z.transpose(1, 2).reshape(b * t, z.shape[1], z.shape[3], z.shape[4])
+        if not self.perframe_ae:
+            res = self.first_stage_model.decode(1. / self.scale_factor * z, **kwargs)
+        else:
+            res = torch.cat([self.first_stage_model.decode(1. / self.scale_factor * z[i:i + 1], **kwargs)
+                             for i in range(z.shape[0])], dim=0)
+        if reshape_back:
+            res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
+        return res
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, **kwargs):
+        return self.decode_core(z, **kwargs)
+
+    def differentiable_decode_first_stage(self, z, **kwargs):
+        return self.decode_core(z, **kwargs)

@@ -1,0 +1,175 @@
+"""Hot operators of the diffusion path.
+
+On a ROCm device the fp16/bf16 (autocast) path runs the hand-written HIP kernels of
+csrc/diffusion_kernels.hip through the C-ABI library lib/libgvd_diffusion.so; there is no silent CPU
+fallback: CPU tensors raise unless a test has explicitly enabled the reference math with
+`use_reference_math(True)` (the `-m "not gpu"` tests of the host logic / module structure do that).
+
+    attention(q, k, v, heads)          softmax(q k^T / sqrt(d)) v per head, q [B,Nq,h*d], k/v [B,Nk,h*d]
+    group_norm(x, groups, w, b, eps, silu)   fp32 statistics (lvdm/basics.py:76-78), optional fused SiLU
+    ddim_step(...)                     the whole no-grad DDIM update of ddim.py:208-280 in one kernel
+"""
+import ctypes
+import math
+import os
+
+import torch
+import torch.nn.functional as F
+
+_REFERENCE_MATH = False
+_LIB = None
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_diffusion.so")
+
+
+def use_reference_math(flag):
+    """TESTS ONLY: allow CPU tensors through plain torch math (never enabled by the product)."""
+    global _REFERENCE_MATH
+    _REFERENCE_MATH = bool(flag)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: build the HIP extensions first "
+                               f"(python -c 'import __graft_entry__ as g; g.build()')")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.gvd_diff_last_error.restype = ctypes.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _require_device(t, what):
+    if t.is_cuda:
+        return True
+    if _REFERENCE_MATH:
+        return False
+    raise RuntimeError(f"lvdm_amd.ops.{what}: tensor on {t.device}; this build has no CPU path "
+                       f"(tests may call ops.use_reference_math(True))")
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"gvd_diffusion error {rc}: {lib().gvd_diff_last_error().decode()}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------------------------------
+def attention_math(q, k, v, heads):
+    """Explicit form (the reference's einsum path, attention.py:101-135), fp32 softmax."""
+    B, Nq, C = q.shape
+    d = C // heads
+    qh = q.reshape(B, Nq, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, k.shape[1], heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B, v.shape[1], heads, d).permute(0, 2, 1, 3)
+    sim = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
+    p = sim.float().softmax(dim=-1).to(vh.dtype)
+    return torch.matmul(p, vh).permute(0, 2, 1, 3).reshape(B, Nq, C)
+
+
+class _FlashAttention(torch.autograd.Function):
+    """fp16/bf16 MFMA flash attention (csrc/diffusion_kernels.hip).  Forward is the hand-written
+    kernel; backward (guided sampler only) recomputes through the explicit math in fp32-softmax form."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        out = _hip_attention_fwd(q, k, v, heads)
+        ctx.save_for_backward(q, k, v)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v = ctx.saved_tensors
+        with torch.enable_grad():
+            q_, k_, v_ = (t.detach().requires_grad_(True) for t in (q, k, v))
+            o = attention_math(q_, k_, v_, ctx.heads)
+            gq, gk, gv = torch.autograd.grad(o, (q_, k_, v_), g)
+        return gq, gk, gv, None
+
+
+def _hip_attention_fwd(q, k, v, heads):
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    d = C // heads
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    out = torch.empty_like(q)
+    is_bf16 = 1 if q.dtype == torch.bfloat16 else 0
+    with torch.cuda.device(q.device):
+        rc = lib().gvd_attention_fwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
+                                     ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                     B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), is_bf16,
+                                     ctypes.c_void_p(_stream()))
+    _check(rc)
+    return out
+
+
+def attention(q, k, v, heads):
+    on_dev = _require_device(q, "attention")
+    d = q.shape[-1] // heads
+    if on_dev and q.dtype in (torch.float16, torch.bfloat16) and d == 64 and k.dtype == q.dtype and v.dtype == q.dtype:
+        if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+            return _FlashAttention.apply(q, k, v, heads)
+        return _hip_attention_fwd(q, k, v, heads)
+    # fp32 tensors (parity tests) and head sizes the MFMA kernel does not cover (VAE mid-attention, d=512)
+    return attention_math(q, k, v, heads)
+
+
+# --------------------------------------------------------------------------------------------------
+def group_norm(x, groups, weight, bias, eps=1e-5, silu=False):
+    """GroupNorm with fp32 statistics (GroupNormSpecific, lvdm/basics.py:76-78) + optional SiLU."""
+    _require_device(x, "group_norm")
+    y = F.group_norm(x.float(), groups, weight.float() if weight is not None else None,
+                     bias.float() if bias is not None else None, eps)
+    if silu:
+        y = F.silu(y)
+    return y.to(x.dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+def ddim_step(x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac_t, sqrt_1mac_t, sqrt_a_prev, dir_coef,
+              sigma_t, x0_rescale, temperature=1.0):
+    """One no-grad DDIM update for the v-parameterisation (ddim.py:208-280):
+        v      = e_uncond + s (e_cond - e_uncond);  v <- rescale_noise_cfg(v, e_cond, phi)  (if phi > 0)
+        eps    = sqrt_ac_t v + sqrt_1mac_t x ;  x0 = (sqrt_ac_t x - sqrt_1mac_t v) * x0_rescale
+        x_prev = sqrt_a_prev x0 + dir_coef eps + sigma * temperature * noise   (dir_coef = sqrt(1 - a_prev - sigma^2), fp32)
+    Returns (x_prev, x0).  All per-batch statistics (std over non-batch dims) are fp32."""
+    on_dev = _require_device(x, "ddim_step")
+    if on_dev and x.dtype == torch.float32 and x.shape[0] == 1 and e_uncond is not None:
+        x, e_cond, e_uncond, noise = (t.contiguous() for t in (x, e_cond, e_uncond, noise))
+        x_prev, x0 = torch.empty_like(x), torch.empty_like(x)
+        ws = torch.empty(8, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib().gvd_ddim_step(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(e_cond.data_ptr()),
+                                     ctypes.c_void_p(e_uncond.data_ptr()), ctypes.c_void_p(noise.data_ptr()),
+                                     ctypes.c_void_p(x_prev.data_ptr()), ctypes.c_void_p(x0.data_ptr()),
+                                     ctypes.c_void_p(ws.data_ptr()), ctypes.c_longlong(x.numel()),
+                                     ctypes.c_float(cfg_scale), ctypes.c_float(guidance_rescale),
+                                     ctypes.c_float(sqrt_ac_t), ctypes.c_float(sqrt_1mac_t), ctypes.c_float(sqrt_a_prev),
+                                     ctypes.c_float(dir_coef), ctypes.c_float(sigma_t), ctypes.c_float(x0_rescale),
+                                     ctypes.c_float(temperature),
+                                     ctypes.c_void_p(_stream()))
+        _check(rc)
+        return x_prev, x0
+    return ddim_step_math(x, e_cond, e_uncond, noise, cfg_scale=cfg_scale, guidance_rescale=guidance_rescale,
+                          sqrt_ac_t=sqrt_ac_t, sqrt_1mac_t=sqrt_1mac_t, sqrt_a_prev=sqrt_a_prev, dir_coef=dir_coef,
+                          sigma_t=sigma_t, x0_rescale=x0_rescale, temperature=temperature)
+
+
+def ddim_step_math(x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_ac_t, sqrt_1mac_t, sqrt_a_prev, dir_coef,
+                   sigma_t, x0_rescale, temperature=1.0):
+    from .schedule import rescale_noise_cfg
+    if e_uncond is None:
+        v = e_cond
+    else:
+        v = e_uncond + cfg_scale * (e_cond - e_uncond)
+        if guidance_rescale > 0.0:
+            v = rescale_noise_cfg(v, e_cond, guidance_rescale)
+    eps = sqrt_ac_t * v + sqrt_1mac_t * x
+    x0 = (sqrt_ac_t * x - sqrt_1mac_t * v) * x0_rescale
+    x_prev = sqrt_a_prev * x0 + dir_coef * eps + sigma_t * temperature * noise
+    return x_prev, x0

@@ -1,0 +1,211 @@
+"""DDIM samplers with the reference's API.
+
+    DDIMSampler(model).sample(S, batch_size, shape, conditioning, ..., eta, x_T, unconditional_guidance_scale,
+                              unconditional_conditioning, fs, timestep_spacing, guidance_rescale, **kwargs)
+        -> (samples, {'x_inter': [...], 'pred_x0': [...]})                    lvdm/models/samplers/ddim.py:61-134
+    DDIMSamplerGuidance: same, with the scene-grounding guidance of ddim_guidance.py:205-363 when
+        `loss_guidance_fn` is passed in kwargs.
+
+Differences from the reference, none of which change results:
+  * tables live on `model.device` (the reference hard-codes "cuda", ddim.py:18-22);
+  * the whole no-grad update of one step (CFG combine, guidance rescale incl. its two std reductions,
+    v->eps / v->x0, dynamic rescale, x_{t-1}) is ONE fused kernel (`ops.ddim_step`);
+  * the guided step drops the per-step host stalls listed in SURVEY 8f N1 (mp4 dump moved behind
+    `loss_guidance_fn.save_dir is not None`, no empty_cache(), one host sync for rho instead of two).
+Random draws: x_T, then per plain step ONE latent-shaped draw (ddim.py:274); per guided step TWO
+(sigma noise :287 and the re-noise :360, drawn even when recur_steps == 1) -- same generator order as
+the reference, so seeding reproduces its trajectories given the same model.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .schedule import make_ddim_sampling_parameters, make_ddim_timesteps, rescale_noise_cfg
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.counter = 0
+
+    # ---- tables -------------------------------------------------------------------------------
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        m = self.model
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+        ac = m.alphas_cumprod
+        assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        ac_np = ac.detach().cpu().to(torch.float32)
+        if m.use_dynamic_rescale:
+            self.ddim_scale_arr = m.scale_arr[self.ddim_timesteps.copy()]
+            self.ddim_scale_arr_prev = torch.cat([m.scale_arr[0:1], self.ddim_scale_arr[:-1]])
+        sig, a, a_prev = make_ddim_sampling_parameters(ac_np, self.ddim_timesteps, ddim_eta)
+        # kept as in the reference: torch tensors of the model's cumulative tables, numpy for the DDIM subset
+        self.ddim_sigmas = sig
+        self.ddim_alphas = a
+        self.ddim_alphas_prev = a_prev
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - a)
+        self.betas, self.alphas_cumprod, self.alphas_cumprod_prev = m.betas, m.alphas_cumprod, m.alphas_cumprod_prev
+
+    def _step_constants(self, index):
+        """fp32 scalars of step `index`, rounded exactly as `torch.full(size, table[index])` rounds them."""
+        f = lambda v: float(np.float32(v))
+        t = int(self.ddim_timesteps[index])
+        c = dict(a_t=f(self.ddim_alphas[index]), a_prev=f(self.ddim_alphas_prev[index]),
+                 sigma_t=f(self.ddim_sigmas[index]), sqrt_one_minus_at=f(self.ddim_sqrt_one_minus_alphas[index]),
+                 sqrt_ac_t=float(self.model.sqrt_alphas_cumprod[t]),
+                 sqrt_1mac_t=float(self.model.sqrt_one_minus_alphas_cumprod[t]), x0_rescale=1.0)
+        if self.model.use_dynamic_rescale:
+            st, sp = np.float32(float(self.ddim_scale_arr[index])), np.float32(float(self.ddim_scale_arr_prev[index]))
+            c["x0_rescale"] = float(sp / st)
+        # (1 - a_prev - sigma^2).sqrt() and a_prev.sqrt() are fp32 TENSOR ops in the reference (ddim.py:268,274):
+        # with zero terminal SNR the first step has 1 - a_prev - sigma^2 ~ 1e-8 in fp32, whose sqrt (~1e-4) is
+        # visible in x_prev -- so the difference must be formed in fp32, not in double.
+        a32, s32 = np.float32(c["a_prev"]), np.float32(c["sigma_t"])
+        d32 = np.float32(1.) - a32 - s32 * s32
+        c["dir_coef"] = float(np.sqrt(np.maximum(d32, np.float32(0.))))  # the reference would NaN on d32 < 0
+        c["sqrt_a_prev"] = float(np.sqrt(a32))
+        return c
+
+    # ---- API ----------------------------------------------------------------------------------
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, schedule_verbose=False, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, precision=None, fs=None,
+               timestep_spacing="uniform", guidance_rescale=0.0, **kwargs):
+        if conditioning is not None:
+            first = conditioning[list(conditioning.keys())[0]] if isinstance(conditioning, dict) else conditioning
+            cbs = (first[0] if isinstance(first, (list, tuple)) else first).shape[0]
+            if cbs != batch_size:
+                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        if quantize_x0 or score_corrector is not None or noise_dropout > 0.:
+            raise NotImplementedError("quantize_x0 / score_corrector / noise_dropout are unused by ViewCrafter")
+        self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
+        size = (batch_size, *shape)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, mask=mask, x0=x0,
+                                  temperature=temperature, x_T=x_T, log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, precision=precision, fs=fs,
+                                  guidance_rescale=guidance_rescale, **kwargs)
+
+    def _grad_ctx(self):
+        return torch.no_grad()
+
+    def ddim_sampling(self, cond, shape, x_T=None, callback=None, mask=None, x0=None, img_callback=None, log_every_t=100,
+                      temperature=1., unconditional_guidance_scale=1., unconditional_conditioning=None, precision=None,
+                      fs=None, guidance_rescale=0.0, **kwargs):
+        device = self.model.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T
+        if precision == 16:
+            img = img.to(dtype=torch.float16)
+        timesteps = self.ddim_timesteps
+        total = timesteps.shape[0]
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        clean_cond = kwargs.pop("clean_cond", False)
+        with self._grad_ctx():
+            for i, step in enumerate(np.flip(timesteps)):
+                index = total - i - 1
+                ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+                if mask is not None:
+                    assert x0 is not None
+                    img_orig = x0 if clean_cond else self.model.q_sample(x0, ts)
+                    img = img_orig * mask + (1. - mask) * img
+                img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
+                                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                                  unconditional_conditioning=unconditional_conditioning, fs=fs,
+                                                  guidance_rescale=guidance_rescale, **kwargs)
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(pred_x0, i)
+                if index % log_every_t == 0 or index == total - 1:
+                    intermediates["x_inter"].append(img)
+                    intermediates["pred_x0"].append(pred_x0)
+        return img, intermediates
+
+    def p_sample_ddim(self, x, c, t, index, temperature=1., unconditional_guidance_scale=1.,
+                      unconditional_conditioning=None, guidance_rescale=0.0, noise=None, **kwargs):
+        """Plain step (ddim.py:208-280) for the v-parameterisation.  `noise` lets tests inject the draw."""
+        if self.model.parameterization != "v":
+            raise NotImplementedError("ViewCrafter is v-parameterised")
+        m = self.model
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+            e_cond, e_uncond = m.apply_model(x, t, c, **kwargs), None
+        else:
+            e_cond = m.apply_model(x, t, c, **kwargs)
+            e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
+        k = self._step_constants(index)
+        if noise is None:
+            noise = torch.randn(x.shape, device=x.device)
+        return ops.ddim_step(x.float(), e_cond.float(), None if e_uncond is None else e_uncond.float(), noise,
+                             cfg_scale=float(unconditional_guidance_scale), guidance_rescale=float(guidance_rescale),
+                             sqrt_ac_t=k["sqrt_ac_t"], sqrt_1mac_t=k["sqrt_1mac_t"], sqrt_a_prev=k["sqrt_a_prev"],
+                             dir_coef=k["dir_coef"], sigma_t=k["sigma_t"], x0_rescale=k["x0_rescale"],
+                             temperature=float(temperature))
+
+
+class DDIMSamplerGuidance(DDIMSampler):
+    """ddim_guidance.py: the guided step differentiates pred_x0 w.r.t. x_t through BOTH U-Net evaluations
+    and back-propagates the per-frame decoder-space loss gradient (Algorithm 1, L11-L13 of the paper)."""
+
+    def _grad_ctx(self):
+        return torch.enable_grad()
+
+    def p_sample_ddim(self, x, c, t, index, temperature=1., unconditional_guidance_scale=1.,
+                      unconditional_conditioning=None, guidance_rescale=0.0, noise=None, renoise=None, **kwargs):
+        loss_guidance_fn = kwargs.get("loss_guidance_fn")
+        if loss_guidance_fn is None:  # the reference returns the un-updated input in this case; we do the plain step
+            with torch.no_grad():
+                return super().p_sample_ddim(x, c, t, index, temperature, unconditional_guidance_scale,
+                                             unconditional_conditioning, guidance_rescale, noise=noise, **kwargs)
+        m = self.model
+        k = self._step_constants(index)
+        repeat = loss_guidance_fn.recur_steps
+        assert repeat in (1, 2), "only support 2 recur steps"
+        w = 1.0
+        if getattr(loss_guidance_fn, "scale_guidance_weight", False):
+            w = loss_guidance_fn.guidance_weight_fn(loss_guidance_fn.current_train_iter)
+        # The reference flips requires_grad on all U-Net / VAE weights here (ddim_guidance.py:259-260) although
+        # only d/dx is ever requested (inputs=x prunes weight gradients); leaving the weights frozen gives the
+        # same x-gradient without retaining weight-gradient state.
+        beta_t = k["a_t"] / k["a_prev"]
+        s = float(unconditional_guidance_scale)
+        for _ in range(repeat):
+            x = x.detach().requires_grad_(True)
+            e_cond = m.apply_model(x, t, c, **kwargs)
+            e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
+            v = e_uncond + s * (e_cond - e_uncond)
+            correction = (e_cond - e_uncond).detach()
+            v = rescale_noise_cfg(v, e_cond, guidance_rescale)  # unconditional in the guided sampler (:272)
+            e_t = k["sqrt_ac_t"] * v + k["sqrt_1mac_t"] * x
+            pred_x0 = (k["sqrt_ac_t"] * x - k["sqrt_1mac_t"] * v) * k["x0_rescale"]
+            with torch.no_grad():
+                dir_xt = k["dir_coef"] * e_t
+                nz = torch.randn(x.shape, device=x.device) if noise is None else noise
+                x_prev = k["sqrt_a_prev"] * pred_x0 + dir_xt + k["sigma_t"] * temperature * nz
+            # per-frame decode + loss gradient w.r.t. the (detached) x0 latent of that frame
+            n_frames = pred_x0.shape[2]
+            grads, decoded = [], []
+            for f in range(n_frames):
+                z = pred_x0[:, :, f:f + 1].clone().detach().requires_grad_(True)
+                D = m.differentiable_decode_first_stage(z)
+                loss_dict, numel = loss_guidance_fn(D[0], index, f, f + 1)
+                g = torch.autograd.grad(outputs=loss_dict["recon"], inputs=z)[0]
+                if not loss_guidance_fn.mean_loss:
+                    g = g / numel
+                grads.append(g)
+                if getattr(loss_guidance_fn, "save_dir", None) is not None:
+                    decoded.append(D.detach())
+            if decoded:
+                loss_guidance_fn.save_pred_x0(torch.cat(decoded, dim=2), index)
+            G = torch.cat(grads, dim=2)
+            (gx,) = torch.autograd.grad(pred_x0, x, grad_outputs=G)
+            with torch.no_grad():
+                rms = torch.stack([(gx * gx).mean().sqrt(), (correction ** 2).mean().sqrt()]).tolist()  # one host sync
+                rho = 0.0 if rms[0] == 0 else rms[1] * s / rms[0] * (0.2 * w)
+                x_prev = x_prev - rho * gx
+                rz = torch.randn(x.shape, device=x.device) if renoise is None else renoise
+                x = float(np.sqrt(np.float32(beta_t))) * x_prev + float(np.sqrt(np.float32(1 - beta_t))) * rz
+        return x_prev.detach(), pred_x0.detach()

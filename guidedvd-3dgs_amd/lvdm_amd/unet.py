@@ -1,0 +1,401 @@
+"""3D (2D + temporal) denoising U-Net of ViewCrafter, rebuilt.
+
+Operator boundary kept: `UNetModel(**yaml_params).forward(x[b,8,T,h,w], timesteps[b], context[b,L,1024], fs[b])
+-> [b,4,T,h,w]` (lvdm/modules/networks/openaimodel3d.py:548-603), and the parameter tree carries the
+reference's state-dict key names (`input_blocks.4.0.in_layers.2.weight`, `...temopral_conv.conv3.3.weight`,
+`...transformer_blocks.0.attn2.to_k_ip.weight`, ...) so the ViewCrafter checkpoint loads with strict=True.
+
+What is different: the compute is organised around the hot operators of `ops` (flash attention on
+MFMA, fp32-statistics GroupNorm(+SiLU)), tokens stay in one [B, N, C] layout through a transformer
+block, the 256 image tokens + 77 text tokens are projected ONCE per layer for all T frames when the
+context is frame-invariant (the reference re-projects 25 identical copies), and activation
+checkpointing is off by default (288 GB of HBM; it can be switched on per model).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint as _ckpt
+
+from . import ops
+from .schedule import timestep_embedding
+
+
+def zero_module(m):
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+class GroupNorm32(nn.GroupNorm):
+    """fp32-statistics GroupNorm (lvdm/basics.py:76-86); `silu=True` fuses the activation."""
+
+    def forward(self, x, silu=False):
+        return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, silu)
+
+
+def _run(fn, use_checkpoint, *args):
+    return _ckpt(fn, *args, use_reentrant=False) if (use_checkpoint and torch.is_grad_enabled()) else fn(*args)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention side (lvdm/modules/attention.py)
+# ------------------------------------------------------------------------------------------------
+class CrossAttention(nn.Module):
+    """attention.py:42-144.  Self-attention when context is None; with `image_cross_attention` the
+    context is [text 77 | image tokens] and the two softmaxes are separate and summed."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0., image_cross_attention=False,
+                 image_cross_attention_scale=1.0, image_cross_attention_scale_learnable=False, text_context_len=77):
+        super().__init__()
+        inner = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.heads, self.dim_head = heads, dim_head
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+        self.image_cross_attention = image_cross_attention
+        self.image_cross_attention_scale = image_cross_attention_scale
+        self.image_cross_attention_scale_learnable = image_cross_attention_scale_learnable
+        self.text_context_len = text_context_len
+        if image_cross_attention:
+            self.to_k_ip = nn.Linear(context_dim, inner, bias=False)
+            self.to_v_ip = nn.Linear(context_dim, inner, bias=False)
+            if image_cross_attention_scale_learnable:
+                self.register_parameter("alpha", nn.Parameter(torch.tensor(0.)))
+
+    def _kv(self, context, frames):
+        """Project K/V (and image-prompt K/V).  `frames` > 1 means `context` holds ONE copy of a context
+        shared by `frames` consecutive batch rows: project once, expand as a view."""
+        ctx_t = context[:, :self.text_context_len]
+        k, v = self.to_k(ctx_t), self.to_v(ctx_t)
+        k_ip = v_ip = None
+        if self.image_cross_attention:
+            ctx_i = context[:, self.text_context_len:]
+            k_ip, v_ip = self.to_k_ip(ctx_i), self.to_v_ip(ctx_i)
+        if frames > 1:
+            rep = lambda t: None if t is None else t.repeat_interleave(frames, dim=0)
+            k, v, k_ip, v_ip = rep(k), rep(v), rep(k_ip), rep(v_ip)
+        return k, v, k_ip, v_ip
+
+    def forward(self, x, context=None, shared_frames=1):
+        q = self.to_q(x)
+        if context is None:
+            out = ops.attention(q, self.to_k(x), self.to_v(x), self.heads)
+        else:
+            k, v, k_ip, v_ip = self._kv(context, shared_frames)
+            out = ops.attention(q, k, v, self.heads)
+            if k_ip is not None:
+                out_ip = ops.attention(q, k_ip, v_ip, self.heads)
+                s = self.image_cross_attention_scale
+                if self.image_cross_attention_scale_learnable:
+                    out = out + s * out_ip * (torch.tanh(self.alpha) + 1)
+                else:
+                    out = out + s * out_ip
+        return self.to_out(out)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        a, gate = self.proj(x).chunk(2, dim=-1)
+        return a * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(dropout), nn.Linear(dim * mult, dim))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention.py:212-246: x += attn1(LN x); x += attn2(LN x, context); x += FF(LN x)."""
+
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, use_checkpoint=False, **attn2_kw):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, n_heads, d_head, dropout)
+        self.ff = FeedForward(dim, dropout=dropout)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, dropout, **attn2_kw)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.use_checkpoint = use_checkpoint
+
+    def _fwd(self, x, context, shared_frames):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), context, shared_frames) + x
+        return self.ff(self.norm3(x)) + x
+
+    def forward(self, x, context=None, shared_frames=1):
+        return _run(lambda a, c: self._fwd(a, c, shared_frames), self.use_checkpoint, x, context)
+
+
+class SpatialTransformer(nn.Module):
+    """attention.py:249-310 (use_linear=True layout: GN -> tokens -> Linear in -> blocks -> Linear out)."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, use_checkpoint=False,
+                 use_linear=True, image_cross_attention=False, image_cross_attention_scale_learnable=False):
+        super().__init__()
+        inner = n_heads * d_head
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.use_linear = use_linear
+        self.proj_in = nn.Linear(in_channels, inner) if use_linear else nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, n_heads, d_head, dropout, context_dim, use_checkpoint,
+                                  image_cross_attention=image_cross_attention,
+                                  image_cross_attention_scale_learnable=image_cross_attention_scale_learnable)
+            for _ in range(depth)])
+        self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv2d(inner, in_channels, 1))
+
+    def forward(self, x, context=None, shared_frames=1):
+        b, c, h, w = x.shape
+        x_in = x
+        x = ops.group_norm(x, 32, self.norm.weight, self.norm.bias, self.norm.eps)
+        if not self.use_linear:
+            x = self.proj_in(x)
+        x = x.flatten(2).transpose(1, 2)  # [b, hw, c]
+        if self.use_linear:
+            x = self.proj_in(x)
+        for blk in self.transformer_blocks:
+            x = blk(x, context, shared_frames)
+        if self.use_linear:
+            x = self.proj_out(x)
+        x = x.transpose(1, 2).reshape(b, -1, h, w)
+        if not self.use_linear:
+            x = self.proj_out(x)
+        return x + x_in
+
+
+class TemporalTransformer(nn.Module):
+    """attention.py:313-412, only_self_att=True, no relative position, no causal mask (ViewCrafter yaml).
+    Tokens: one sequence of T frames per pixel -> [(b h w), T, C]; both attn1 and attn2 are self-attention."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., use_checkpoint=False, use_linear=False):
+        super().__init__()
+        inner = n_heads * d_head
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.use_linear = use_linear
+        self.proj_in = nn.Linear(in_channels, inner) if use_linear else nn.Conv1d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, n_heads, d_head, dropout, None, use_checkpoint) for _ in range(depth)])
+        self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv1d(inner, in_channels, 1))
+
+    def forward(self, x):  # x [b, c, t, h, w]
+        b, c, t, h, w = x.shape
+        x_in = x
+        x = ops.group_norm(x, 32, self.norm.weight, self.norm.bias, self.norm.eps)
+        x = x.permute(0, 3, 4, 2, 1).reshape(b * h * w, t, c)  # [(b h w), t, c]
+        if self.use_linear:
+            x = self.proj_in(x)
+        else:  # Conv1d(k=1) == per-token linear with weight [inner, c, 1]
+            x = F.linear(x, self.proj_in.weight.squeeze(-1), self.proj_in.bias)
+        for blk in self.transformer_blocks:
+            x = blk(x)
+        if self.use_linear:
+            x = self.proj_out(x)
+        else:
+            x = F.linear(x, self.proj_out.weight.squeeze(-1), self.proj_out.bias)
+        x = x.reshape(b, h, w, t, c).permute(0, 4, 3, 1, 2)
+        return x + x_in
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutional side (openaimodel3d.py)
+# ------------------------------------------------------------------------------------------------
+class TemporalConvBlock(nn.Module):
+    """openaimodel3d.py:239-279: 4 x [GN32 -> SiLU -> (Dropout) -> Conv3d k=(3,1,1)] + identity."""
+
+    def __init__(self, channels, dropout=0.0):
+        super().__init__()
+        conv = lambda: nn.Conv3d(channels, channels, (3, 1, 1), padding=(1, 0, 0))
+        self.conv1 = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), conv())
+        self.conv2 = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Dropout(dropout), conv())
+        self.conv3 = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Dropout(dropout), conv())
+        self.conv4 = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Dropout(dropout), conv())
+        nn.init.zeros_(self.conv4[-1].weight)
+        nn.init.zeros_(self.conv4[-1].bias)
+
+    def forward(self, x):  # [b, c, t, h, w]
+        h = x
+        for seq in (self.conv1, self.conv2, self.conv3, self.conv4):
+            gn, conv = seq[0], seq[-1]
+            # plain nn.GroupNorm here in the reference (autocast runs it in fp32 as well)
+            h = conv(ops.group_norm(h, 32, gn.weight, gn.bias, gn.eps, silu=True))
+        return x + h
+
+
+class ResBlock(nn.Module):
+    """openaimodel3d.py:109-236 (no scale-shift norm, no up/down variants: the yaml uses neither)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_checkpoint=False, use_temporal_conv=False):
+        super().__init__()
+        out_channels = out_channels or channels
+        self.use_checkpoint = use_checkpoint
+        self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(), nn.Conv2d(channels, out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, out_channels))
+        self.out_layers = nn.Sequential(GroupNorm32(32, out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(nn.Conv2d(out_channels, out_channels, 3, padding=1)))
+        self.skip_connection = nn.Identity() if out_channels == channels else nn.Conv2d(channels, out_channels, 1)
+        self.use_temporal_conv = use_temporal_conv
+        if use_temporal_conv:
+            self.temopral_conv = TemporalConvBlock(out_channels, dropout=0.1)  # (sic) reference attribute name
+
+    def _fwd(self, x, emb, batch_size):
+        h = self.in_layers[2](self.in_layers[0](x, silu=True))
+        h = h + self.emb_layers[1](F.silu(emb)).to(h.dtype)[:, :, None, None]
+        h = self.out_layers[3](self.out_layers[2](self.out_layers[0](h, silu=True)))
+        h = self.skip_connection(x) + h
+        if self.use_temporal_conv and batch_size:
+            bt, c, hh, ww = h.shape
+            h5 = h.reshape(batch_size, bt // batch_size, c, hh, ww).transpose(1, 2)
+            h = self.temopral_conv(h5).transpose(1, 2).reshape(bt, c, hh, ww)
+        return h
+
+    def forward(self, x, emb, batch_size=None):
+        return _run(lambda a, e: self._fwd(a, e, batch_size), self.use_checkpoint, x, emb)
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.op = nn.Conv2d(channels, out_channels or channels, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, out_channels or channels, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"))
+
+
+class TimestepEmbedSequential(nn.Sequential):
+    """openaimodel3d.py:30-48: routes (emb | context | batch size) to the children that take them."""
+
+    def forward(self, x, emb, context=None, batch_size=None, shared_frames=1):
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                x = layer(x, emb, batch_size=batch_size)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context, shared_frames)
+            elif isinstance(layer, TemporalTransformer):
+                bt, c, h, w = x.shape
+                x5 = x.reshape(batch_size, bt // batch_size, c, h, w).transpose(1, 2)
+                x = layer(x5).transpose(1, 2).reshape(bt, c, h, w)
+            else:
+                x = layer(x)
+        return x
+
+
+class UNetModel(nn.Module):
+    """openaimodel3d.py:281-603.  Accepts the reference's constructor keywords (yaml `unet_config.params`);
+    options the shipped ViewCrafter config does not use raise instead of being silently ignored."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None, use_scale_shift_norm=False,
+                 resblock_updown=False, num_heads=-1, num_head_channels=-1, transformer_depth=1, use_linear=False,
+                 use_checkpoint=False, temporal_conv=False, tempspatial_aware=False, temporal_attention=True,
+                 use_relative_position=True, use_causal_attention=False, temporal_length=None, use_fp16=False,
+                 addition_attention=False, temporal_selfatt_only=True, image_cross_attention=False,
+                 image_cross_attention_scale_learnable=False, default_fs=4, fs_condition=False):
+        super().__init__()
+        if (dims != 2 or use_scale_shift_norm or resblock_updown or tempspatial_aware or use_relative_position
+                or use_causal_attention or not temporal_selfatt_only or not conv_resample or num_head_channels == -1):
+            raise NotImplementedError("UNetModel (MI355X build) covers the ViewCrafter configuration "
+                                      "(configs/inference_pvd_1024.yaml:33-64) only")
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.temporal_attention, self.addition_attention = temporal_attention, addition_attention
+        self.default_fs, self.fs_condition = default_fs, fs_condition
+        self.dtype = torch.float16 if use_fp16 else torch.float32
+        ted = model_channels * 4
+        mlp = lambda: nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        self.time_embed = mlp()
+        if fs_condition:
+            self.fps_embedding = mlp()
+            nn.init.zeros_(self.fps_embedding[-1].weight)
+            nn.init.zeros_(self.fps_embedding[-1].bias)
+
+        def res(cin, cout):
+            return ResBlock(cin, ted, dropout, cout, use_checkpoint, temporal_conv)
+
+        def attn_layers(ch):
+            heads = ch // num_head_channels
+            out = [SpatialTransformer(ch, heads, num_head_channels, transformer_depth, 0., context_dim, use_checkpoint,
+                                      use_linear, image_cross_attention, image_cross_attention_scale_learnable)]
+            if temporal_attention:
+                out.append(TemporalTransformer(ch, heads, num_head_channels, transformer_depth, 0., use_checkpoint, use_linear))
+            return out
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        if addition_attention:
+            self.init_attn = TimestepEmbedSequential(
+                TemporalTransformer(model_channels, 8, num_head_channels, transformer_depth, 0., use_checkpoint, use_linear=False))
+        chans, ch, ds = [model_channels], model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers += attn_layers(ch)
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, ch)))
+                chans.append(ch)
+                ds *= 2
+        mid = [res(ch, ch)] + attn_layers(ch) + [res(ch, ch)]
+        self.middle_block = TimestepEmbedSequential(*mid)
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [res(ch + chans.pop(), mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers += attn_layers(ch)
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(),
+                                 zero_module(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
+
+    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
+        b, _, t, hh, ww = x.shape
+        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
+        # Context routing (openaimodel3d.py:555-562): per-frame image tokens only when L == 77 + 16 T,
+        # otherwise the SAME context for every frame -> keep ONE copy per batch row and let the
+        # cross-attention project it once (shared_frames = T) instead of T identical copies.
+        shared = 1
+        if context.shape[1] == 77 + t * 16:
+            ctx_text = context[:, :77].repeat_interleave(t, dim=0)
+            ctx_img = context[:, 77:].reshape(b * t, 16, context.shape[-1])
+            context = torch.cat([ctx_text, ctx_img], dim=1)
+        else:
+            shared = t
+        emb = emb.repeat_interleave(t, dim=0)
+        if self.fs_condition:
+            if fs is None:
+                fs = torch.full((b,), self.default_fs, dtype=torch.long, device=x.device)
+            fs_emb = self.fps_embedding(timestep_embedding(fs, self.model_channels).type(x.dtype))
+            emb = emb + fs_emb.repeat_interleave(t, dim=0)
+        h = x.transpose(1, 2).reshape(b * t, -1, hh, ww).type(self.dtype)
+        hs = []
+        for i, module in enumerate(self.input_blocks):
+            h = module(h, emb, context, b, shared)
+            if i == 0 and self.addition_attention:
+                h = self.init_attn(h, emb, context, b, shared)
+            hs.append(h)
+        h = self.middle_block(h, emb, context, b, shared)
+        for module in self.output_blocks:
+            h = module(torch.cat([h, hs.pop()], dim=1), emb, context, b, shared)
+        h = h.type(x.dtype)
+        y = self.out[2](self.out[0](h, silu=True))
+        return y.reshape(b, t, -1, hh, ww).transpose(1, 2)

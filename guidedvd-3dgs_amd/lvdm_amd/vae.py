@@ -1,0 +1,113 @@
+"""KL-VAE decoder used inside the guided DDIM step.
+
+Rebuild of `AutoencoderKL.decode` = post_quant_conv (1x1) -> Decoder (lvdm/models/autoencoder.py:104-107,
+lvdm/modules/networks/ae_modules.py:466-578, AttnBlock :26-78, ResnetBlock :151-210) with the reference's
+parameter names (`decoder.mid.attn_1.q.weight`, `decoder.up.3.block.0.nin_shortcut.weight`, ...) so the
+`first_stage_model.*` part of the ViewCrafter checkpoint loads strict.  eps of every GroupNorm is 1e-6.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _norm(c):
+    return nn.GroupNorm(32, c, eps=1e-6, affine=True)
+
+
+def _gn_swish(gn, x):
+    return ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, silu=True)  # x*sigmoid(x) == SiLU
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.norm1 = _norm(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.norm2 = _norm(out_channels)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1)
+
+    def forward(self, x):
+        h = self.conv1(_gn_swish(self.norm1, x))
+        h = self.conv2(_gn_swish(self.norm2, h))
+        return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
+
+
+class AttnBlock(nn.Module):
+    """Single-head attention over h*w tokens with c channels (ae_modules.py:26-78); q/k/v/proj are 1x1 convs."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.norm = _norm(c)
+        self.q, self.k, self.v, self.proj_out = (nn.Conv2d(c, c, 1) for _ in range(4))
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        hn = ops.group_norm(x, 32, self.norm.weight, self.norm.bias, self.norm.eps)
+        tok = lambda t: t.flatten(2).transpose(1, 2)  # [b, hw, c]
+        o = ops.attention(tok(self.q(hn)), tok(self.k(hn)), tok(self.v(hn)), heads=1)
+        return x + self.proj_out(o.transpose(1, 2).reshape(b, c, h, w))
+
+
+class Upsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions=(), dropout=0.0,
+                 in_channels=3, resolution=256, z_channels=4, **ignored):
+        super().__init__()
+        if len(attn_resolutions) != 0:
+            raise NotImplementedError("per-level attention is not used by the ViewCrafter VAE (yaml: attn_resolutions: [])")
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        block_in = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block_out = ch * ch_mult[i_level]
+            up = nn.Module()
+            up.block = nn.ModuleList()
+            up.attn = nn.ModuleList()
+            for _ in range(num_res_blocks + 1):
+                up.block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            if i_level != 0:
+                up.upsample = Upsample(block_in)
+            self.up.insert(0, up)
+        self.norm_out = _norm(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, padding=1)
+
+    def forward(self, z):
+        h = self.conv_in(z)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        for i_level in reversed(range(self.num_resolutions)):
+            for blk in self.up[i_level].block:
+                h = blk(h)
+            if i_level != 0:
+                h = self.up[i_level].upsample(h)
+        return self.conv_out(_gn_swish(self.norm_out, h))
+
+
+class AutoencoderKLDecoder(nn.Module):
+    """`first_stage_model` as far as the DDIM loop needs it: decode() only (encode is a 'next' row, N2)."""
+
+    def __init__(self, ddconfig, embed_dim=4):
+        super().__init__()
+        self.decoder = Decoder(**ddconfig)
+        self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+
+    def decode(self, z, **kwargs):
+        return self.decoder(self.post_quant_conv(z))

@@ -1,0 +1,220 @@
+"""CPU-only parity of the rebuilt diffusion path against golden vectors produced by the REFERENCE'S OWN
+Python (tests/golden/make_golden_diffusion.py): schedule tables, timestep embedding, the whole U-Net
+(fwd + input-gradient, both context-routing branches), the VAE decoder (fwd + dgrad), a plain DDIM step
+and a guided DDIM step.  Weights are derived from parameter names (tests/fill_by_name.py), so a passing
+strict load_state_dict-style key comparison + output match proves checkpoint compatibility.
+
+These tests exercise host logic and module structure; they run the hot operators through plain torch math
+(`ops.use_reference_math(True)`) -- the product itself refuses CPU tensors (see test_no_cpu_path)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fill_by_name import fill_by_name
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "diffusion_ref.npz"), allow_pickle=False)
+
+
+@pytest.fixture(autouse=True)
+def _refmath():
+    from lvdm_amd import ops
+    ops.use_reference_math(True)
+    yield
+    ops.use_reference_math(False)
+
+
+def test_schedule_tables_match_reference():
+    from lvdm_amd import schedule as S
+    betas = S.rescale_zero_terminal_snr(S.make_beta_schedule("linear", 1000, 0.00085, 0.012))
+    assert np.array_equal(betas, G["g1_betas"])
+    ac = np.cumprod(1. - betas, axis=0)
+    assert np.array_equal(ac, G["g1_alphas_cumprod"]) and ac[-1] == 0.0  # zero terminal SNR, exactly
+    for name, method in (("trailing", "uniform_trailing"), ("uniform", "uniform")):
+        ts = S.make_ddim_timesteps(method, 50, 1000)
+        assert np.array_equal(ts, G[f"g1_ts_{name}"])
+        sig, a, ap = S.make_ddim_sampling_parameters(torch.tensor(ac, dtype=torch.float32).numpy(), ts, 1.0)
+        for mine, ref in ((sig, "sig"), (a, "a"), (ap, "aprev")):
+            assert np.array_equal(mine, G[f"g1_{ref}_{name}"], equal_nan=True), (name, ref)
+    assert list(G["g1_ts_trailing"][[0, 1, -1]]) == [19, 39, 999]
+    sched = S.DiffusionSchedule()
+    assert np.array_equal(sched.alphas_cumprod.numpy(), ac.astype(np.float32))
+    assert float(sched.scale_arr[0]) == 1.0 and abs(float(sched.scale_arr[400]) - 0.3) < 1e-7 and sched.scale_arr.numel() == 1400
+
+
+def test_timestep_embedding_matches_reference():
+    from lvdm_amd.schedule import timestep_embedding
+    assert np.array_equal(timestep_embedding(torch.tensor(G["g2_t"]), 320).numpy(), G["g2_emb"])
+
+
+UNET_CFG = dict(in_channels=8, out_channels=4, model_channels=64, attention_resolutions=[2, 1], num_res_blocks=1,
+                channel_mult=[1, 2], dropout=0.1, num_head_channels=32, transformer_depth=1, context_dim=48,
+                use_linear=True, use_checkpoint=False, temporal_conv=True, temporal_attention=True,
+                temporal_selfatt_only=True, use_relative_position=False, use_causal_attention=False, temporal_length=16,
+                addition_attention=True, image_cross_attention=True, default_fs=10, fs_condition=True)
+
+
+@pytest.mark.parametrize("tag", ["shared", "perframe"])
+def test_unet_forward_and_input_gradient_match_reference(tag):
+    from lvdm_amd.unet import UNetModel
+    unet = UNetModel(**UNET_CFG)
+    assert sorted(unet.state_dict().keys()) == list(G["unet_keys"])  # strict checkpoint compatibility
+    fill_by_name(unet).eval()
+    x = torch.tensor(G[f"unet_{tag}_x"], requires_grad=True)
+    y = unet(x, torch.tensor([400]), context=torch.tensor(G[f"unet_{tag}_ctx"]), fs=torch.tensor([10]))
+    ref = G[f"unet_{tag}_y"]
+    assert np.abs(ref).max() > 1e-3  # non-degenerate (zero-init modules were re-randomised)
+    np.testing.assert_allclose(y.detach().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    (gx,) = torch.autograd.grad(y, x, torch.tensor(G[f"unet_{tag}_gy"]))
+    gref = G[f"unet_{tag}_gx"]
+    np.testing.assert_allclose(gx.numpy(), gref, rtol=1e-4, atol=1e-4 * np.abs(gref).max())
+
+
+def test_unet_activation_checkpointing_is_equivalent():
+    from lvdm_amd.unet import UNetModel
+    a = fill_by_name(UNetModel(**UNET_CFG)).eval()
+    b = fill_by_name(UNetModel(**{**UNET_CFG, "use_checkpoint": True})).eval()
+    x = torch.tensor(G["unet_shared_x"], requires_grad=True)
+    ctx = torch.tensor(G["unet_shared_ctx"])
+    ga = torch.autograd.grad(a(x, torch.tensor([400]), context=ctx).square().sum(), x)[0]
+    gb = torch.autograd.grad(b(x, torch.tensor([400]), context=ctx).square().sum(), x)[0]
+    assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-7)
+
+
+def test_vae_decoder_forward_and_input_gradient_match_reference():
+    from lvdm_amd.vae import Decoder
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2],
+              num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    dec = Decoder(**dd)
+    assert sorted(dec.state_dict().keys()) == list(G["dec_keys"])
+    fill_by_name(dec).eval()
+    z = torch.tensor(G["dec_z"], requires_grad=True)
+    img = dec(z)
+    np.testing.assert_allclose(img.detach().numpy(), G["dec_img"], rtol=1e-4, atol=1e-4 * np.abs(G["dec_img"]).max())
+    (gz,) = torch.autograd.grad(img, z, torch.tensor(G["dec_gi"]))
+    np.testing.assert_allclose(gz.numpy(), G["dec_gz"], rtol=1e-4, atol=1e-4 * np.abs(G["dec_gz"]).max())
+
+
+class _Duck(torch.nn.Module):
+    """Same stand-in as the golden script, but built on OUR schedule object."""
+
+    def __init__(self):
+        super().__init__()
+        from lvdm_amd.schedule import DiffusionSchedule
+        self.sched = DiffusionSchedule()
+        for k in ("num_timesteps", "parameterization", "use_dynamic_rescale"):
+            setattr(self, k, getattr(self.sched, k))
+        self.model = torch.nn.Conv3d(4, 4, 1)
+        self.first_stage_model = torch.nn.Conv2d(4, 3, 1)
+        fill_by_name(self.model_and_vae(), std=0.5)
+
+    def model_and_vae(self):
+        m = torch.nn.Module()
+        m.model, m.first_stage_model = self.model, self.first_stage_model
+        return m
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("sched"), name)
+
+    def apply_model(self, x, t, c, **kw):
+        return self.model(x) * (1 + c["c_crossattn"][0].mean())
+
+    def differentiable_decode_first_stage(self, z):
+        return torch.tanh(self.first_stage_model(z[:, :, 0]))[:, :, None]
+
+
+def _duck_inputs():
+    x = torch.tensor(G["step_x"])
+    cond = {"c_crossattn": [torch.tensor(G["step_c"])]}
+    uc = {"c_crossattn": [torch.tensor(G["step_uc"])]}
+    return x, cond, uc
+
+
+@pytest.mark.parametrize("index", [49, 30, 0])
+def test_plain_ddim_step_matches_reference(index):
+    from lvdm_amd.samplers import DDIMSampler
+    duck = _Duck()
+    s = DDIMSampler(duck)
+    s.make_schedule(50, "uniform_trailing", 1.0)
+    x, cond, uc = _duck_inputs()
+    t = torch.full((1,), int(s.ddim_timesteps[index]), dtype=torch.long)
+    with torch.no_grad():
+        xp, p0 = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                                 guidance_rescale=0.7, noise=torch.tensor(G["step_noise0"]))
+    ref_xp, ref_p0 = G[f"plain{index}_xprev"], G[f"plain{index}_x0"]
+    assert np.isfinite(ref_xp).all(), "reference produced non-finite x_prev"
+    np.testing.assert_allclose(p0.numpy(), ref_p0, rtol=2e-5, atol=2e-6 * np.abs(ref_p0).max())
+    np.testing.assert_allclose(xp.numpy(), ref_xp, rtol=2e-5, atol=2e-6 * np.abs(ref_xp).max())
+
+
+@pytest.mark.parametrize("index", [40, 3])
+def test_guided_ddim_step_matches_reference(index):
+    from lvdm_amd.guidance import LossGuidance
+    from lvdm_amd.samplers import DDIMSamplerGuidance
+    duck = _Duck()
+    s = DDIMSamplerGuidance(duck)
+    s.make_schedule(50, "uniform_trailing", 1.0)
+    x, cond, uc = _duck_inputs()
+    lg = LossGuidance(ddim_steps=50, recur_steps=1)
+    lg.set_hw(6, 7)
+    lg.set_guidance_images(torch.tensor(G["guide_imgs"]))
+    lg.set_guidance_masks(torch.tensor(G["guide_masks"]))
+    t = torch.full((1,), int(s.ddim_timesteps[index]), dtype=torch.long)
+    xp, p0 = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                             guidance_rescale=0.7, loss_guidance_fn=lg, noise=torch.tensor(G["step_noise0"]),
+                             renoise=torch.tensor(G["step_noise1"]))
+    ref_xp, ref_p0 = G[f"guided{index}_xprev"], G[f"guided{index}_x0"]
+    np.testing.assert_allclose(p0.numpy(), ref_p0, rtol=2e-5, atol=2e-6 * np.abs(ref_p0).max())
+    np.testing.assert_allclose(xp.numpy(), ref_xp, rtol=1e-4, atol=1e-5 * np.abs(ref_xp).max())
+
+
+def test_sampler_api_end_to_end_and_rng_order():
+    """sample() signature/returns (ddim.py:61-134) and the generator draw order (x_T, then one draw per step)."""
+    from lvdm_amd.samplers import DDIMSampler
+    duck = _Duck()
+    x, cond, uc = _duck_inputs()
+    torch.manual_seed(123)
+    samples, inter = DDIMSampler(duck).sample(S=5, batch_size=1, shape=[4, 5, 6, 7], conditioning=cond, eta=1.0,
+                                              unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                                              timestep_spacing="uniform_trailing", guidance_rescale=0.7, fs=torch.tensor([10]),
+                                              verbose=False)
+    assert samples.shape == (1, 4, 5, 6, 7) and set(inter) == {"x_inter", "pred_x0"} and torch.isfinite(samples).all()
+    torch.manual_seed(123)
+    x_T = torch.randn(1, 4, 5, 6, 7)
+    noises = [torch.randn(1, 4, 5, 6, 7) for _ in range(5)]
+    s = DDIMSampler(duck)
+    s.make_schedule(5, "uniform_trailing", 1.0)
+    img = x_T
+    with torch.no_grad():
+        for i, step in enumerate(np.flip(s.ddim_timesteps)):
+            t = torch.full((1,), int(step), dtype=torch.long)
+            img, _ = s.p_sample_ddim(img, cond, t, index=4 - i, unconditional_guidance_scale=7.5,
+                                     unconditional_conditioning=uc, guidance_rescale=0.7, noise=noises[i])
+    assert torch.equal(img, samples)
+
+
+def test_latent_diffusion_wrapper_shapes_and_hybrid_conditioning():
+    from lvdm_amd.model import LatentDiffusion
+    vae = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2],
+               num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    ld = fill_by_name(LatentDiffusion(unet_config=UNET_CFG, first_stage_config=vae)).eval()
+    x = torch.randn(1, 4, 2, 8, 8)
+    cond = {"c_crossattn": [torch.randn(1, 77, 48), torch.randn(1, 20, 48)], "c_concat": [torch.randn(1, 4, 2, 8, 8)]}
+    with torch.no_grad():
+        v = ld.apply_model(x, torch.tensor([999]), cond, fs=torch.tensor([10]), loss_guidance_fn=None)
+        img = ld.decode_first_stage(x)
+    assert v.shape == (1, 4, 2, 8, 8) and img.shape == (1, 3, 2, 16, 16)
+
+
+def test_no_cpu_path_in_the_product():
+    from lvdm_amd import ops
+    ops.use_reference_math(False)
+    q = torch.randn(1, 4, 64)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.attention(q, q, q, 1)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.group_norm(torch.randn(1, 32, 2, 2), 32, None, None)
