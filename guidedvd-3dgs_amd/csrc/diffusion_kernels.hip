@@ -1,0 +1,300 @@
+// diffusion_kernels.hip -- hand-written gfx950 kernels on the ViewCrafter DDIM hot path
+// (C-ABI: include/gvd_diffusion.h).
+//
+//  k_attn_fwd     flash attention forward on MFMA 32x32x16 (f16 / bf16 operands, fp32 accumulate, fp32 online
+//                 softmax).  Replaces xformers.memory_efficient_attention (lvdm/modules/attention.py:175,187).
+//  k_ddim_stats / k_ddim_apply   the whole no-grad DDIM update (lvdm/models/samplers/ddim.py:208-280).
+//
+// Attention design (wave64, one wave = 32 query rows):
+//   * operands are read straight from the [B, N, H*64] token-major layout the Linear layers produce
+//     (row stride H*64) -- no head-split permute/contiguous copies (the reference makes 3 per call);
+//   * "swapped" product S^T = K Q^T: MFMA C/D layout puts one QUERY per lane column, so every softmax
+//     reduction is over a lane's own 32 registers plus ONE cross-half exchange (lane ^ 32);
+//   * P^T goes back into an MFMA B operand without touching LDS: pack to 16 bit, v_permlane32_swap
+//     between the wave halves (keys 8s..8s+3 / 8s+4..8s+7 interleave of the 32x32 C layout);
+//   * V is written TRANSPOSED into LDS when the tile is staged, so the P V product reads its A operand
+//     (V^T) with plain 16-byte ds_read_b128; K and V^T rows are padded to 72 elements (144 B) so the
+//     32 lanes of a half-wave hit different bank groups;
+//   * O^T = V^T P^T accumulates in 32 fp32 registers, rescaled by the per-lane alpha of the online softmax.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/gvd_diffusion.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[384];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Tr;
+template <> struct Tr<_Float16> {
+    typedef h8 vec8;
+    static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi)
+    {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 p = { (_Float16)lo, (_Float16)hi };
+        return __builtin_bit_cast(unsigned, p);
+    }
+};
+template <> struct Tr<__bf16> {
+    typedef b8 vec8;
+    static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi)
+    {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        b2 p = { (__bf16)lo, (__bf16)hi };
+        return __builtin_bit_cast(unsigned, p);
+    }
+};
+
+constexpr int KV_TILE = 64;   // keys per iteration
+constexpr int LDS_ROW = 72;   // padded row length (elements): 144 B, 16-byte aligned, spreads bank groups
+
+template <typename T, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                         T* __restrict__ out, int H, int Nq, int Nk, float scale_log2e)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    constexpr int NT = WAVES * 64;
+    __shared__ __attribute__((aligned(16))) T sK[KV_TILE][LDS_ROW];
+    __shared__ __attribute__((aligned(16))) T sVt[64][LDS_ROW];
+
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+    const size_t rs = (size_t)H * 64;  // row stride in elements
+    const T* qb = q + ((size_t)b * Nq) * rs + (size_t)h * 64;
+    const T* kb = k + ((size_t)b * Nk) * rs + (size_t)h * 64;
+    const T* vb = v + ((size_t)b * Nk) * rs + (size_t)h * 64;
+    T* ob = out + ((size_t)b * Nq) * rs + (size_t)h * 64;
+
+    const int query = blockIdx.y * (32 * WAVES) + wave * 32 + col;
+    const bool valid_q = query < Nq;
+
+    vec8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        if (valid_q) qf[ks] = *reinterpret_cast<const vec8*>(qb + (size_t)query * rs + 16 * ks + 8 * hi);
+        else qf[ks] = vec8{};
+    }
+
+    f16v o0 = {}, o1 = {};
+    float m = -1.0e30f, l = 0.f;
+
+    for (int kt = 0; kt < Nk; kt += KV_TILE) {
+        __syncthreads();
+        // ---- stage K (row-major) and V (transposed) tiles ----
+        for (int c = tid; c < KV_TILE * 8; c += NT) {
+            const int row = c >> 3, c8 = (c & 7) * 8;
+            const int key = kt + row;
+            vec8 kv = vec8{}, vv = vec8{};
+            if (key < Nk) {
+                kv = *reinterpret_cast<const vec8*>(kb + (size_t)key * rs + c8);
+                vv = *reinterpret_cast<const vec8*>(vb + (size_t)key * rs + c8);
+            }
+            *reinterpret_cast<vec8*>(&sK[row][c8]) = kv;
+#pragma unroll
+            for (int i = 0; i < 8; i++) sVt[c8 + i][row] = vv[i];
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T : two 32-key blocks ----
+        f16v s0 = {}, s1 = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const vec8 a0 = *reinterpret_cast<const vec8*>(&sK[col][16 * ks + 8 * hi]);
+            const vec8 a1 = *reinterpret_cast<const vec8*>(&sK[32 + col][16 * ks + 8 * hi]);
+            s0 = Tr<T>::mfma(a0, qf[ks], s0);
+            s1 = Tr<T>::mfma(a1, qf[ks], s1);
+        }
+        // ---- online softmax over this lane's 32 scores (+ the other half's 32) ----
+        const bool ragged = kt + KV_TILE > Nk;
+        float mt = -1.0e30f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float x0 = s0[r] * scale_log2e, x1 = s1[r] * scale_log2e;
+            if (ragged) {
+                if (kt + krow >= Nk) x0 = -1.0e30f;
+                if (kt + 32 + krow >= Nk) x1 = -1.0e30f;
+            }
+            s0[r] = x0;
+            s1[r] = x1;
+            mt = fmaxf(mt, fmaxf(x0, x1));
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        float rowsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float p0 = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            const float p1 = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            s0[r] = p0;
+            s1[r] = p1;
+            rowsum += p0 + p1;
+        }
+        rowsum += __shfl_xor(rowsum, 32, 64);
+        l = l * alpha + rowsum;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T += V^T P^T : P^T fragments via pack + permlane32_swap ----
+#pragma unroll
+        for (int kbk = 0; kbk < 2; kbk++) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const int r0 = 8 * k2;
+                unsigned u01, u23, u45, u67;
+                if (kbk == 0) {
+                    u01 = Tr<T>::pack2(s0[r0 + 0], s0[r0 + 1]); u23 = Tr<T>::pack2(s0[r0 + 2], s0[r0 + 3]);
+                    u45 = Tr<T>::pack2(s0[r0 + 4], s0[r0 + 5]); u67 = Tr<T>::pack2(s0[r0 + 6], s0[r0 + 7]);
+                } else {
+                    u01 = Tr<T>::pack2(s1[r0 + 0], s1[r0 + 1]); u23 = Tr<T>::pack2(s1[r0 + 2], s1[r0 + 3]);
+                    u45 = Tr<T>::pack2(s1[r0 + 4], s1[r0 + 5]); u67 = Tr<T>::pack2(s1[r0 + 6], s1[r0 + 7]);
+                }
+                // upper half of (u01,u23) <-> lower half of (u45,u67): lower lanes end with keys base+0..7,
+                // upper lanes with keys base+8..15 -- exactly the B-operand k mapping (k = 8*hi + j)
+                auto sa = __builtin_amdgcn_permlane32_swap(u01, u45, false, false);
+                auto sb = __builtin_amdgcn_permlane32_swap(u23, u67, false, false);
+                const u4 packed = { sa[0], sb[0], sa[1], sb[1] };
+                const vec8 pf = __builtin_bit_cast(vec8, packed);
+                const int kcol = 32 * kbk + 16 * k2 + 8 * hi;
+                const vec8 va0 = *reinterpret_cast<const vec8*>(&sVt[col][kcol]);
+                const vec8 va1 = *reinterpret_cast<const vec8*>(&sVt[32 + col][kcol]);
+                o0 = Tr<T>::mfma(va0, pf, o0);
+                o1 = Tr<T>::mfma(va1, pf, o1);
+            }
+        }
+    }
+    // ---- epilogue: O[query][d] = O^T / l ----
+    if (valid_q) {
+        const float inv = 1.0f / l;
+        T* orow = ob + (size_t)query * rs;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int d0 = 8 * rg + 4 * hi;
+            uint2 w0, w1;
+            w0.x = Tr<T>::pack2(o0[4 * rg] * inv, o0[4 * rg + 1] * inv);
+            w0.y = Tr<T>::pack2(o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
+            w1.x = Tr<T>::pack2(o1[4 * rg] * inv, o1[4 * rg + 1] * inv);
+            w1.y = Tr<T>::pack2(o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + d0) = w0;
+            *reinterpret_cast<uint2*>(orow + 32 + d0) = w1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_ddim_stats(const float* __restrict__ ec, const float* __restrict__ eu, long long n,
+                                                    float cfg, double* __restrict__ ws)
+{
+    double se = 0, se2 = 0, sv = 0, sv2 = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float e = ec[i], u = eu[i];
+        const float vv = u + cfg * (e - u);
+        se += e; se2 += (double)e * e; sv += vv; sv2 += (double)vv * vv;
+    }
+    se = wave_sum_d(se); se2 = wave_sum_d(se2); sv = wave_sum_d(sv); sv2 = wave_sum_d(sv2);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&ws[0], se); atomicAdd(&ws[1], se2); atomicAdd(&ws[2], sv); atomicAdd(&ws[3], sv2);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ddim_apply(const float* __restrict__ x, const float* __restrict__ ec,
+                                                    const float* __restrict__ eu, const float* __restrict__ noise,
+                                                    float* __restrict__ x_prev, float* __restrict__ x0, const double* __restrict__ ws,
+                                                    long long n, float cfg, float phi, float sa, float s1a, float sap, float dirc,
+                                                    float sig_temp, float x0r)
+{
+    float mix = 1.0f;  // v <- v * (phi * std_e / std_v + 1 - phi)
+    if (phi > 0.f) {
+        const double dn = (double)n;
+        const double var_e = (ws[1] - ws[0] * ws[0] / dn) / (dn - 1.0);
+        const double var_v = (ws[3] - ws[2] * ws[2] / dn) / (dn - 1.0);
+        const float ratio = (float)(sqrt(var_e) / sqrt(var_v));
+        mix = phi * ratio + (1.f - phi);
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float xi = x[i], e = ec[i], u = eu[i];
+        const float vv = (u + cfg * (e - u)) * mix;
+        const float eps = sa * vv + s1a * xi;
+        const float p0 = (sa * xi - s1a * vv) * x0r;
+        x0[i] = p0;
+        x_prev[i] = sap * p0 + dirc * eps + sig_temp * noise[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gvd_diff_last_error(void) { return g_err.c_str(); }
+
+int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                      float scale, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return fail(-1, "gvd_attention_fwd: bad arguments");
+    if (D != 64) return fail(-1, "gvd_attention_fwd: head dim must be 64");
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(-1, "gvd_attention_fwd: pointers must be 16-byte aligned");
+    const float sl2 = scale * 1.4426950408889634f;
+    const bool big = Nq > 64;
+    const int rows = big ? 128 : 32;
+    dim3 grid((unsigned)(B * H), (unsigned)((Nq + rows - 1) / rows));
+    if (is_bf16) {
+        if (big) hipLaunchKernelGGL((k_attn_fwd<__bf16, 4>), grid, dim3(256), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2);
+        else hipLaunchKernelGGL((k_attn_fwd<__bf16, 1>), grid, dim3(64), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2);
+    } else {
+        if (big) hipLaunchKernelGGL((k_attn_fwd<_Float16, 4>), grid, dim3(256), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2);
+        else hipLaunchKernelGGL((k_attn_fwd<_Float16, 1>), grid, dim3(64), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_attn_fwd", e);
+    return 0;
+}
+
+int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, const float* noise, float* x_prev, float* x0,
+                  double* ws, long long n, float cfg_scale, float guidance_rescale, float sqrt_ac_t, float sqrt_1mac_t,
+                  float sqrt_a_prev, float dir_coef, float sigma_t, float x0_rescale, float temperature, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !e_cond || !e_uncond || !noise || !x_prev || !x0 || !ws || n <= 1) return fail(-1, "gvd_ddim_step: bad arguments");
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (guidance_rescale > 0.f) {
+        hipError_t e = hipMemsetAsync(ws, 0, 4 * sizeof(double), stream);
+        if (e != hipSuccess) return fail(-2, "hipMemsetAsync(ws)", e);
+        hipLaunchKernelGGL(k_ddim_stats, dim3(blocks), dim3(256), 0, stream, e_cond, e_uncond, n, cfg_scale, ws);
+    }
+    hipLaunchKernelGGL(k_ddim_apply, dim3(blocks), dim3(256), 0, stream, x, e_cond, e_uncond, noise, x_prev, x0, ws, n,
+                       cfg_scale, guidance_rescale, sqrt_ac_t, sqrt_1mac_t, sqrt_a_prev, dir_coef, sigma_t * temperature, x0_rescale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_ddim_*", e);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+/*
+ * gvd_diffusion.h -- C-ABI of the hand-written HIP kernels on the ViewCrafter DDIM hot path.
+ *
+ * Plain C: raw DEVICE pointers, sizes, hipStream_t as void*.  Every function returns 0 on success
+ * or a negative code (gvd_diff_last_error() has the message).
+ */
+#ifndef GVD_DIFFUSION_H_INCLUDED
+#define GVD_DIFFUSION_H_INCLUDED
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Multi-head attention forward, softmax(Q K^T * scale) V, flash style (no N x N matrix in HBM), MFMA
+ * 32x32x16 f16/bf16 with fp32 accumulation and fp32 online softmax.
+ * Replaces xformers.ops.memory_efficient_attention(q, k, v) at
+ *   third_party/ViewCrafter/lvdm/modules/attention.py:175,187 (un-vendored pip dependency `xformers`,
+ *   unpinned in requirements.txt:26); its semantics are pinned by the in-tree explicit path :101-135.
+ * Layout (no head-split copies): q, out [B, Nq, H*D], k, v [B, Nk, H*D], 16-bit elements, contiguous;
+ * head h owns channels [h*D, (h+1)*D).  D must be 64 (every U-Net head).  Any Nq, Nk >= 1. */
+int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out,
+                      int B, int H, int Nq, int Nk, int D, float scale, int is_bf16, void* stream);
+
+/* One complete no-grad DDIM update for the v-parameterisation, batch 1, fp32 latents of n elements:
+ *   v      = e_uncond + cfg_scale (e_cond - e_uncond)
+ *   v      = phi v std(e_cond)/std(v) + (1 - phi) v              (phi = guidance_rescale; skipped if 0)
+ *   eps    = sqrt_ac_t v + sqrt_1mac_t x ;   x0 = (sqrt_ac_t x - sqrt_1mac_t v) * x0_rescale
+ *   x_prev = sqrt_a_prev x0 + dir_coef eps + sigma_t * temperature * noise
+ * Replaces the ~20 elementwise/reduction launches of DDIMSampler.p_sample_ddim
+ *   (lvdm/models/samplers/ddim.py:208-280, rescale_noise_cfg utils_diffusion.py:147-158).
+ * ws: 4 doubles of device scratch (sum / sum of squares of e_cond and of v), any content on entry. */
+int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, const float* noise,
+                  float* x_prev, float* x0, double* ws, long long n,
+                  float cfg_scale, float guidance_rescale, float sqrt_ac_t, float sqrt_1mac_t,
+                  float sqrt_a_prev, float dir_coef, float sigma_t, float x0_rescale, float temperature,
+                  void* stream);
+
+const char* gvd_diff_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
