@@ -37,6 +37,11 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--workload", choices=["raster", "ddim"], default="raster",
+                    help="raster = BASELINE configs[1] (default, the driver's line); ddim = configs[2], ViewCrafter 25-frame DDIM")
+    ap.add_argument("--ddim-height", type=int, default=576)
+    ap.add_argument("--ddim-width", type=int, default=1024)
+    ap.add_argument("--frames", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -44,6 +49,9 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    if args.workload == "ddim":
+        return ddim_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,6 +206,112 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ddim_main(args):
+    """BASELINE configs[2]: ViewCrafter 25-frame DDIM (unguided: 2 U-Net forwards + fused update per step),
+    random-init U-Net with the zero-init modules re-randomised (SURVEY 7 'random-init U-Net is degenerate'),
+    fp16 weights/activations with fp32 GroupNorm statistics and fp32 sampler math, synthetic conditioning.
+    One step = one DDIM step.  Single GPU in this round (frame/CFG sharding is a later round)."""
+    import numpy as np
+    import torch
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from lvdm_amd import ops
+    from lvdm_amd.model import VIEWCRAFTER_UNET, DiffusionWrapper
+    from lvdm_amd.samplers import DDIMSampler
+    from lvdm_amd.schedule import DiffusionSchedule
+    from lvdm_amd.unet import UNetModel
+
+    T, h, w = args.frames, args.ddim_height // 8, args.ddim_width // 8
+    torch.manual_seed(0)
+    with torch.device(dev):
+        unet = UNetModel(**VIEWCRAFTER_UNET)
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for p_ in unet.parameters():  # re-randomise zero-init modules, std 0.02
+            if float(p_.abs().max()) == 0.0:
+                p_.copy_(torch.randn(p_.shape, device=dev, generator=g) * 0.02)
+    unet = unet.half().eval()
+
+    class LD(DiffusionSchedule):
+        def __init__(self):
+            super().__init__()
+            self.model = DiffusionWrapper(unet)
+
+        @property
+        def device(self):
+            return self.betas.device
+
+        def apply_model(self, x, t, cond, **kw):
+            return self.model(x.half(), t, **cond, fs=kw.get("fs"))
+
+    ld = LD().to(dev)
+    cond = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g).half()],
+            "c_concat": [(torch.randn(1, 4, T, h, w, device=dev, generator=g) * 0.18).half()]}
+    uc = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g).half()], "c_concat": cond["c_concat"]}
+    sampler = DDIMSampler(ld)
+    sampler.make_schedule(50, "uniform_trailing", 1.0)
+    x = torch.randn(1, 4, T, h, w, device=dev, generator=g)
+    fs = torch.tensor([10], device=dev)
+    steps, warm = min(args.steps, 50), min(args.warmup, 5)
+    idx = list(range(49, -1, -1))
+
+    def one(i, x):
+        index = idx[i % 50]
+        t = torch.full((1,), int(sampler.ddim_timesteps[index]), device=dev, dtype=torch.long)
+        with torch.no_grad():
+            xp, _ = sampler.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5,
+                                          unconditional_conditioning=uc, guidance_rescale=0.7, fs=fs)
+        return xp
+
+    for i in range(warm):
+        x = one(i, x)
+    torch.cuda.synchronize()
+    # attention kernel time inside the timed region (HIP events on torch's current stream = the launch stream)
+    ev = []
+    orig = ops._hip_attention_fwd
+
+    def timed_attn(q, k, v, heads):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        o = orig(q, k, v, heads)
+        b.record()
+        ev.append((a, b, q.shape[0] * heads, q.shape[1], k.shape[1]))
+        return o
+
+    ops._hip_attention_fwd = timed_attn
+    t0 = time.perf_counter()
+    for i in range(steps):
+        x = one(warm + i, x)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops._hip_attention_fwd = orig
+    assert torch.isfinite(x).all()
+    att_ms = sum(a.elapsed_time(b) for a, b, *_ in ev)
+    att_flops = sum(4.0 * bh * nq * nk * 64 for _, _, bh, nq, nk in ev)
+    MFMA_PEAK = 2500.0  # TFLOP/s dense f16/bf16 (MI355X_MICROARCH.md)
+    unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
+    line = {
+        "metric": "viewcrafter_ddim_steps_per_s", "value": round(steps / elapsed, 4), "unit": "steps/s", "n_gpus": 1,
+        "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / steps, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": (round((steps / elapsed) / 0.42, 3) if (args.ddim_height, args.ddim_width, T) == (576, 1024, 25) else None),
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: ViewCrafter {T}-frame {args.ddim_height}x{args.ddim_width} DDIM, unguided, CFG 7.5, "
+                               "rescale 0.7, eta 1 (2 U-Net fwd / step), random-init U-Net 1.44 B params",
+                   "latent": [1, 4, T, h, w], "context_tokens": 333, "unet_tflop_per_fwd": unet_tflop,
+                   "baseline_note": "vs_baseline = steps/s over the ViewCrafter README A100 figure 0.42 steps/s (120 s / 50 steps, "
+                                    "whole pipeline incl. VAE/CLIP; third_party/ViewCrafter/README.md:116-118)"},
+        "roofline": {"bound": "mfma", "kernel": "k_attn_fwd (all spatial/cross/temporal attention launches)",
+                     "achieved": round(att_flops / (att_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                     "frac": round(att_flops / (att_ms * 1e-3) / 1e12 / MFMA_PEAK, 4), "traffic": None,
+                     "launches": len(ev), "attention_ms_per_step": round(att_ms / steps, 2)},
+        "unet_achieved_tflops": (round(2 * unet_tflop * steps / elapsed, 1) if unet_tflop else None),
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
 
 
 def cpu_leg(sc, args, np):

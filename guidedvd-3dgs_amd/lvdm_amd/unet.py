@@ -369,6 +369,9 @@ class UNetModel(nn.Module):
 
     def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         b, _, t, hh, ww = x.shape
+        wdtype = self.input_blocks[0][0].weight.dtype  # fp32 weights (+autocast) or a model converted with .half()
+        x = x.to(wdtype)
+        context = context.to(wdtype)
         emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
         # Context routing (openaimodel3d.py:555-562): per-frame image tokens only when L == 77 + 16 T,
         # otherwise the SAME context for every frame -> keep ONE copy per batch row and let the
@@ -386,7 +389,7 @@ class UNetModel(nn.Module):
                 fs = torch.full((b,), self.default_fs, dtype=torch.long, device=x.device)
             fs_emb = self.fps_embedding(timestep_embedding(fs, self.model_channels).type(x.dtype))
             emb = emb + fs_emb.repeat_interleave(t, dim=0)
-        h = x.transpose(1, 2).reshape(b * t, -1, hh, ww).type(self.dtype)
+        h = x.transpose(1, 2).reshape(b * t, -1, hh, ww)
         hs = []
         for i, module in enumerate(self.input_blocks):
             h = module(h, emb, context, b, shared)
