@@ -249,6 +249,147 @@ __global__ void __launch_bounds__(256) k_ddim_apply(const float* __restrict__ x,
     }
 }
 
+
+// number of channel octets a 256-thread block walks in parallel in the NSC statistics kernel
+__device__ __host__ __forceinline__ int oct_stride(int oct) { return oct < 256 ? (oct < 32 ? 32 : (oct <= 64 ? 64 : (oct <= 128 ? 128 : 256))) : 256; }
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (+ optional SiLU), 16-bit activations, fp32 statistics (lvdm/basics.py:76-86 semantics).
+// Two layouts:  NCS  x[N][C][S] (channel-first, what the 2-D convolutions produce)
+//               NSC  x[N][S][C] (token-major, what the Linear / temporal-GEMM path uses)
+// Pass 1 accumulates sum / sum-of-squares per (n, group) into doubles (2 atomics per block), pass 2
+// normalises: 2 reads + 1 write of the 16-bit tensor in total, versus ~5 fp32-sized passes through the
+// cast -> group_norm -> silu -> cast sequence of the eager path.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_stats_ncs(const T* __restrict__ x, double* __restrict__ stats, long long L, int chunks)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const long long grp = blockIdx.x;            // n * G + g ; its L = cpg * S elements are contiguous
+    const T* p = x + grp * L;
+    const long long per = ((L + chunks - 1) / chunks + 7) & ~7LL;
+    const long long beg = (long long)blockIdx.y * per, end = (beg + per < L) ? beg + per : L;
+    float s = 0.f, q = 0.f;
+    if ((L & 7) == 0) {
+        for (long long i = beg + (long long)threadIdx.x * 8; i < end; i += 256 * 8) {
+            const vec8 v = *reinterpret_cast<const vec8*>(p + i);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float f = to_f(v[k]); s += f; q = fmaf(f, f, q); }
+        }
+    } else {
+        for (long long i = beg + threadIdx.x; i < end; i += 256) { const float f = to_f(p[i]); s += f; q = fmaf(f, f, q); }
+    }
+    double ds = wave_sum_d((double)s), dq = wave_sum_d((double)q);
+    __shared__ double sh[8];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[2 * w] = ds; sh[2 * w + 1] = dq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * grp], sh[0] + sh[2] + sh[4] + sh[6]);
+        atomicAdd(&stats[2 * grp + 1], sh[1] + sh[3] + sh[5] + sh[7]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_apply_ncs(const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int C, int G, long long S, float eps, int silu, long long total)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int cpg = C / G;
+    const double cnt = (double)cpg * (double)S;
+    const bool vec = (S & 7) == 0;
+    const long long step = (long long)gridDim.x * 256 * (vec ? 8 : 1);
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * (vec ? 8 : 1); i < total; i += step) {
+        const long long nc = i / S;              // n * C + c   (8 consecutive elements share it when S % 8 == 0)
+        const int c = (int)(nc % C);
+        const long long grp = (nc / C) * G + c / cpg;
+        const double mean = stats[2 * grp] / cnt;
+        const double var = stats[2 * grp + 1] / cnt - mean * mean;
+        const float rstd = rsqrtf((float)(var > 0 ? var : 0) + eps);
+        const float a = rstd * gamma[c], b = beta[c] - (float)mean * a;
+        if (vec) {
+            vec8 v = *reinterpret_cast<const vec8*>(x + i);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float f = fmaf(to_f(v[k]), a, b);
+                if (silu) f = f / (1.f + __expf(-f));
+                v[k] = (T)f;
+            }
+            *reinterpret_cast<vec8*>(y + i) = v;
+        } else {
+            float f = fmaf(to_f(x[i]), a, b);
+            if (silu) f = f / (1.f + __expf(-f));
+            y[i] = (T)f;
+        }
+    }
+}
+
+// NSC: thread -> one octet of 8 consecutive channels, walking down the rows of its block's strip.
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_stats_nsc(const T* __restrict__ x, double* __restrict__ stats, int C, int G, long long S,
+                                                      int rows_per_block)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    extern __shared__ float sh_g[];  // [G][2]
+    const int n = blockIdx.y, cpg = C / G, oct = C / 8;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.f;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
+    const T* base = x + (long long)n * S * C;
+    for (int o = threadIdx.x % oct_stride(oct), lane_row = threadIdx.x / oct_stride(oct); o < oct; o += oct_stride(oct)) {
+        float s[8], q[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s[k] = 0.f; q[k] = 0.f; }
+        const int rstep = 256 / oct_stride(oct);
+        for (long long r = r0 + lane_row; r < r1; r += rstep) {
+            const vec8 v = *reinterpret_cast<const vec8*>(base + r * C + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float f = to_f(v[k]); s[k] += f; q[k] = fmaf(f, f, q[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int g = (o * 8 + k) / cpg;
+            atomicAdd(&sh_g[2 * g], s[k]);
+            atomicAdd(&sh_g[2 * g + 1], q[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[(long long)n * 2 * G + i], (double)sh_g[i]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_apply_nsc(const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int C, int G, long long S, float eps, int silu, long long total)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int cpg = C / G;
+    const double cnt = (double)cpg * (double)S;
+    const long long step = (long long)gridDim.x * 256 * 8;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < total; i += step) {
+        const int c0 = (int)(i % C);
+        const long long n = i / ((long long)S * C);
+        vec8 v = *reinterpret_cast<const vec8*>(x + i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = c0 + k;
+            const long long grp = n * G + c / cpg;
+            const double mean = stats[2 * grp] / cnt;
+            const double var = stats[2 * grp + 1] / cnt - mean * mean;
+            const float rstd = rsqrtf((float)(var > 0 ? var : 0) + eps);
+            const float a = rstd * gamma[c];
+            float f = fmaf(to_f(v[k]), a, beta[c] - (float)mean * a);
+            if (silu) f = f / (1.f + __expf(-f));
+            v[k] = (T)f;
+        }
+        *reinterpret_cast<vec8*>(y + i) = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -294,6 +435,47 @@ int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, co
                        cfg_scale, guidance_rescale, sqrt_ac_t, sqrt_1mac_t, sqrt_a_prev, dir_coef, sigma_t * temperature, x0_rescale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_ddim_*", e);
+    return 0;
+}
+
+
+int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta, double* stats, int N, int C, long long S,
+                   int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !gamma || !beta || !stats || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return fail(-1, "gvd_group_norm: bad arguments");
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(-1, "gvd_group_norm: x / y must be 16-byte aligned");
+    if (channels_last && (C % 8)) return fail(-1, "gvd_group_norm: channels-last needs C % 8 == 0");
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(double), stream);
+    if (e != hipSuccess) return fail(-2, "hipMemsetAsync(stats)", e);
+    const long long total = (long long)N * C * S;
+    const long long vecs = channels_last || (S % 8 == 0) ? total / 8 : total;
+    const int ablocks = (int)((vecs + 255) / 256 < 8192 ? (vecs + 255) / 256 : 8192);
+    if (!channels_last) {
+        const long long L = (long long)(C / G) * S;
+        int chunks = (int)((L + 32767) / 32768);
+        chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+        dim3 grid((unsigned)(N * G), (unsigned)chunks);
+        if (is_bf16) {
+            hipLaunchKernelGGL(k_gn_stats_ncs<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, stats, L, chunks);
+            hipLaunchKernelGGL(k_gn_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+        } else {
+            hipLaunchKernelGGL(k_gn_stats_ncs<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, stats, L, chunks);
+            hipLaunchKernelGGL(k_gn_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+        }
+    } else {
+        const int rows = 128;
+        dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
+        if (is_bf16) {
+            hipLaunchKernelGGL(k_gn_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, stats, C, G, S, rows);
+            hipLaunchKernelGGL(k_gn_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+        } else {
+            hipLaunchKernelGGL(k_gn_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, stats, C, G, S, rows);
+            hipLaunchKernelGGL(k_gn_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+        }
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_gn_*", e);
     return 0;
 }
 

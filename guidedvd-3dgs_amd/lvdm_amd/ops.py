@@ -120,14 +120,68 @@ def attention(q, k, v, heads):
 
 
 # --------------------------------------------------------------------------------------------------
-def group_norm(x, groups, weight, bias, eps=1e-5, silu=False):
-    """GroupNorm with fp32 statistics (GroupNormSpecific, lvdm/basics.py:76-78) + optional SiLU."""
-    _require_device(x, "group_norm")
-    y = F.group_norm(x.float(), groups, weight.float() if weight is not None else None,
-                     bias.float() if bias is not None else None, eps)
+def group_norm_math(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False):
+    """Eager form: statistics and affine in fp32 (GroupNormSpecific, lvdm/basics.py:76-86), result cast back."""
+    if channels_last:  # [N, ..., C] -> [N, C, ...]
+        xc = x.movedim(-1, 1)
+    else:
+        xc = x
+    y = F.group_norm(xc.float(), groups, None if weight is None else weight.float(),
+                     None if bias is None else bias.float(), eps)
     if silu:
         y = F.silu(y)
-    return y.to(x.dtype)
+    y = y.to(x.dtype)
+    return y.movedim(1, -1).contiguous() if channels_last else y
+
+
+def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last):
+    x = x.contiguous()
+    N = x.shape[0]
+    C = x.shape[-1] if channels_last else x.shape[1]
+    S = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    stats = torch.empty(2 * N * groups, dtype=torch.float64, device=x.device)
+    g = weight.float().contiguous()
+    b = bias.float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = lib().gvd_group_norm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(g.data_ptr()),
+                                  ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(stats.data_ptr()), N, C, ctypes.c_longlong(S),
+                                  groups, ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)),
+                                  1 if x.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
+    _check(rc)
+    return y
+
+
+class _GroupNormFn(torch.autograd.Function):
+    """Forward: the fused HIP kernel.  Backward (guided sampler only): autograd through the eager form."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu, channels_last):
+        ctx.save_for_backward(x, weight, bias)
+        ctx.cfg = (groups, eps, silu, channels_last)
+        return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias = ctx.saved_tensors
+        groups, eps, silu, cl = ctx.cfg
+        with torch.enable_grad():
+            x_ = x.detach().requires_grad_(True)
+            y = group_norm_math(x_, groups, weight.detach(), bias.detach(), eps, silu, cl)
+            (gx,) = torch.autograd.grad(y, x_, gy)
+        return gx, None, None, None, None, None, None
+
+
+def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False):
+    """GroupNorm with fp32 statistics + optional fused SiLU.  channels_last: x is [N, ..., C]."""
+    on_dev = _require_device(x, "group_norm")
+    C = x.shape[-1] if channels_last else x.shape[1]
+    if (on_dev and x.dtype in (torch.float16, torch.bfloat16) and weight is not None and bias is not None
+            and (not channels_last or C % 8 == 0)):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last)
+        return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last)
+    return group_norm_math(x, groups, weight, bias, eps, silu, channels_last)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -35,6 +35,15 @@ int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, co
                   float sqrt_a_prev, float dir_coef, float sigma_t, float x0_rescale, float temperature,
                   void* stream);
 
+/* GroupNorm with fp32 statistics and optional fused SiLU on 16-bit activations, forward.
+ *   channels_last == 0 : x, y [N][C][S]   (S = product of the spatial/temporal dims)
+ *   channels_last == 1 : x, y [N][S][C]   (token-major; C % 8 == 0)
+ * gamma, beta: fp32 [C].  stats: 2*N*G doubles of device scratch.  Semantics: GroupNormSpecific
+ * (lvdm/basics.py:76-86: statistics in fp32, result cast back) followed by nn.SiLU where the reference has
+ * `normalization -> SiLU` (openaimodel3d.py:152-156,177-182,259-268,542-546; ae_modules.py nonlinearity). */
+int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta, double* stats,
+                   int N, int C, long long S, int G, float eps, int silu, int channels_last, int is_bf16, void* stream);
+
 const char* gvd_diff_last_error(void);
 
 #ifdef __cplusplus

@@ -153,3 +153,37 @@ def test_plain_sampler_on_device_uses_fused_step():
                                      guidance_rescale=0.7, noise=torch.tensor(G["step_noise0"], device=DEV))
         ref = G[f"plain{index}_xprev"]
         np.testing.assert_allclose(xp.cpu().numpy(), ref, rtol=5e-5, atol=5e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,cl", [((3, 320, 40, 56), False), ((2, 640, 5, 7), False), ((1, 320, 25, 12, 16), False),
+                                      ((1, 25, 192, 320), True), ((2, 7, 35, 1280), True), ((1, 4, 600, 64), True)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_fused_group_norm_kernel_matches_fp32_group_norm(dtype, shape, cl, silu):
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = (torch.randn(shape, device=DEV, generator=g) * 1.7 + 0.4).to(dtype)
+    C = shape[-1] if cl else shape[1]
+    w = (torch.randn(C, device=DEV, generator=g) * 0.3 + 1).to(dtype)
+    b = (torch.randn(C, device=DEV, generator=g) * 0.2).to(dtype)
+    y = ops.group_norm(x, 32, w, b, 1e-5, silu=silu, channels_last=cl)
+    ref = ops.group_norm_math(x.float(), 32, w, b, 1e-5, silu=silu, channels_last=cl)
+    assert y.dtype == dtype and y.shape == x.shape
+    tol = 6e-3 if dtype == torch.float16 else 4e-2  # output rounding of the 16-bit type dominates
+    assert float((y.float() - ref).abs().max()) < tol
+
+
+def test_temporal_conv_gemm_form_on_device_matches_conv3d():
+    from lvdm_amd.unet import TemporalConvBlock
+    blk = fill_by_name(TemporalConvBlock(64)).eval().to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(2, 64, 7, 6, 5, device=DEV, generator=g)
+    with torch.no_grad():
+        y = blk(x)
+        h = x
+        for seq in (blk.conv1, blk.conv2, blk.conv3, blk.conv4):
+            h = seq[-1](torch.nn.functional.silu(torch.nn.functional.group_norm(h, 32, seq[0].weight, seq[0].bias, seq[0].eps)))
+        ref = x + h
+        assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5)
+        y16 = blk.half()(x.half())
+    assert float((y16.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
