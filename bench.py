@@ -218,6 +218,7 @@ def ddim_main(args):
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = os.environ.get("GVD_CONV_FIND", "1") == "1"  # let MIOpen time its NHWC solvers once per shape
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from lvdm_amd import ops
     from lvdm_amd.model import VIEWCRAFTER_UNET, DiffusionWrapper
@@ -234,7 +235,7 @@ def ddim_main(args):
         for p_ in unet.parameters():  # re-randomise zero-init modules, std 0.02
             if float(p_.abs().max()) == 0.0:
                 p_.copy_(torch.randn(p_.shape, device=dev, generator=g) * 0.02)
-    unet = unet.half().eval()
+    unet = unet.half().eval().to_token_major()
 
     class LD(DiffusionSchedule):
         def __init__(self):
@@ -274,12 +275,13 @@ def ddim_main(args):
     ev = []
     orig = ops._hip_attention_fwd
 
-    def timed_attn(q, k, v, heads):
+    def timed_attn(q, k, v, heads, frame_major=False):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        o = orig(q, k, v, heads)
+        o = orig(q, k, v, heads, frame_major)
         b.record()
-        ev.append((a, b, q.shape[0] * heads, q.shape[1], k.shape[1]))
+        nb, nq, nk = (q.shape[1], q.shape[0], k.shape[0]) if frame_major else (q.shape[0], q.shape[1], k.shape[1])
+        ev.append((a, b, nb * heads, nq, nk))
         return o
 
     ops._hip_attention_fwd = timed_attn

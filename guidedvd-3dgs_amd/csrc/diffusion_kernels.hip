@@ -68,7 +68,8 @@ constexpr int LDS_ROW = 72;   // padded row length (elements): 144 B, 16-byte al
 
 template <typename T, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                         T* __restrict__ out, int H, int Nq, int Nk, float scale_log2e)
+                                                         T* __restrict__ out, int H, int Nq, int Nk, float scale_log2e,
+                                                         long long q_bs, long long q_rs, long long kv_bs, long long kv_rs)
 {
     typedef typename Tr<T>::vec8 vec8;
     constexpr int NT = WAVES * 64;
@@ -78,11 +79,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
-    const size_t rs = (size_t)H * 64;  // row stride in elements
-    const T* qb = q + ((size_t)b * Nq) * rs + (size_t)h * 64;
-    const T* kb = k + ((size_t)b * Nk) * rs + (size_t)h * 64;
-    const T* vb = v + ((size_t)b * Nk) * rs + (size_t)h * 64;
-    T* ob = out + ((size_t)b * Nq) * rs + (size_t)h * 64;
+    // element (batch b, row n, head h, d) lives at b*bs + n*rs + h*64 + d: covers the plain [B, N, H*64] layout
+    // (bs = N*H*64, rs = H*64) and the frame-strided temporal layout [T, pixels, H*64] (bs = H*64, rs = pixels*H*64)
+    const size_t rs = (size_t)q_rs, krs = (size_t)kv_rs;
+    const T* qb = q + (size_t)b * q_bs + (size_t)h * 64;
+    const T* kb = k + (size_t)b * kv_bs + (size_t)h * 64;
+    const T* vb = v + (size_t)b * kv_bs + (size_t)h * 64;
+    T* ob = out + (size_t)b * q_bs + (size_t)h * 64;
 
     const int query = blockIdx.y * (32 * WAVES) + wave * 32 + col;
     const bool valid_q = query < Nq;
@@ -105,8 +108,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
             const int key = kt + row;
             vec8 kv = vec8{}, vv = vec8{};
             if (key < Nk) {
-                kv = *reinterpret_cast<const vec8*>(kb + (size_t)key * rs + c8);
-                vv = *reinterpret_cast<const vec8*>(vb + (size_t)key * rs + c8);
+                kv = *reinterpret_cast<const vec8*>(kb + (size_t)key * krs + c8);
+                vv = *reinterpret_cast<const vec8*>(vb + (size_t)key * krs + c8);
             }
             *reinterpret_cast<vec8*>(&sK[row][c8]) = kv;
 #pragma unroll
@@ -399,7 +402,16 @@ const char* gvd_diff_last_error(void) { return g_err.c_str(); }
 int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
                       float scale, int is_bf16, void* stream_)
 {
+    return gvd_attention_fwd_strided(q, k, v, out, B, H, Nq, Nk, D, scale, (long long)Nq * H * D, (long long)H * D,
+                                     (long long)Nk * H * D, (long long)H * D, is_bf16, stream_);
+}
+
+int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                              float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs, int is_bf16,
+                              void* stream_)
+{
     hipStream_t stream = (hipStream_t)stream_;
+    if ((q_bs | q_rs | kv_bs | kv_rs) & 7) return fail(-1, "gvd_attention_fwd: strides must be multiples of 8 elements");
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return fail(-1, "gvd_attention_fwd: bad arguments");
     if (D != 64) return fail(-1, "gvd_attention_fwd: head dim must be 64");
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(-1, "gvd_attention_fwd: pointers must be 16-byte aligned");
@@ -408,11 +420,11 @@ int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out, in
     const int rows = big ? 128 : 32;
     dim3 grid((unsigned)(B * H), (unsigned)((Nq + rows - 1) / rows));
     if (is_bf16) {
-        if (big) hipLaunchKernelGGL((k_attn_fwd<__bf16, 4>), grid, dim3(256), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2);
-        else hipLaunchKernelGGL((k_attn_fwd<__bf16, 1>), grid, dim3(64), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2);
+        if (big) hipLaunchKernelGGL((k_attn_fwd<__bf16, 4>), grid, dim3(256), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        else hipLaunchKernelGGL((k_attn_fwd<__bf16, 1>), grid, dim3(64), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
     } else {
-        if (big) hipLaunchKernelGGL((k_attn_fwd<_Float16, 4>), grid, dim3(256), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2);
-        else hipLaunchKernelGGL((k_attn_fwd<_Float16, 1>), grid, dim3(64), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2);
+        if (big) hipLaunchKernelGGL((k_attn_fwd<_Float16, 4>), grid, dim3(256), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        else hipLaunchKernelGGL((k_attn_fwd<_Float16, 1>), grid, dim3(64), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_attn_fwd", e);

@@ -8,3 +8,9 @@
     model      B1/B5 LatentDiffusion-shaped wrapper the samplers duck-type against (apply_model, decode)
     ops        hot operators; HIP kernels (csrc/diffusion_*.hip) on ROCm devices, no silent CPU fallback
 """
+
+import os as _os
+
+# The U-Net keeps every feature map token-major (channels_last); PyTorch-ROCm only hands NHWC tensors to MIOpen's
+# NHWC kernels when this is set (otherwise it transposes to NCHW and back around every convolution).
+_os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")

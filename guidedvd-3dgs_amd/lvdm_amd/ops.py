@@ -59,8 +59,10 @@ def _stream():
 
 
 # --------------------------------------------------------------------------------------------------
-def attention_math(q, k, v, heads):
+def attention_math(q, k, v, heads, frame_major=False):
     """Explicit form (the reference's einsum path, attention.py:101-135), fp32 softmax."""
+    if frame_major:  # [N, B, C] -> [B, N, C] and back
+        return attention_math(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), heads).transpose(0, 1).contiguous()
     B, Nq, C = q.shape
     d = C // heads
     qh = q.reshape(B, Nq, heads, d).permute(0, 2, 1, 3)
@@ -76,10 +78,10 @@ class _FlashAttention(torch.autograd.Function):
     kernel; backward (guided sampler only) recomputes through the explicit math in fp32-softmax form."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads):
-        out = _hip_attention_fwd(q, k, v, heads)
+    def forward(ctx, q, k, v, heads, frame_major):
+        out = _hip_attention_fwd(q, k, v, heads, frame_major)
         ctx.save_for_backward(q, k, v)
-        ctx.heads = heads
+        ctx.heads, ctx.frame_major = heads, frame_major
         return out
 
     @staticmethod
@@ -87,36 +89,47 @@ class _FlashAttention(torch.autograd.Function):
         q, k, v = ctx.saved_tensors
         with torch.enable_grad():
             q_, k_, v_ = (t.detach().requires_grad_(True) for t in (q, k, v))
-            o = attention_math(q_, k_, v_, ctx.heads)
+            o = attention_math(q_, k_, v_, ctx.heads, ctx.frame_major)
             gq, gk, gv = torch.autograd.grad(o, (q_, k_, v_), g)
-        return gq, gk, gv, None
+        return gq, gk, gv, None, None
 
 
-def _hip_attention_fwd(q, k, v, heads):
-    B, Nq, C = q.shape
-    Nk = k.shape[1]
-    d = C // heads
+def _hip_attention_fwd(q, k, v, heads, frame_major=False):
+    """q [B,Nq,C], k/v [B,Nk,C]; with frame_major=True the tensors are [N, B, C] (sequence outermost: the T
+    frames of B pixels) and are read in place through the kernel's strided addressing."""
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    C = q.shape[-1]
+    d = C // heads
+    if frame_major:
+        Nq, B = q.shape[0], q.shape[1]
+        Nk = k.shape[0]
+        q_bs, q_rs, kv_bs, kv_rs = C, B * C, C, B * C
+    else:
+        B, Nq = q.shape[0], q.shape[1]
+        Nk = k.shape[1]
+        q_bs, q_rs, kv_bs, kv_rs = Nq * C, C, Nk * C, C
     out = torch.empty_like(q)
     is_bf16 = 1 if q.dtype == torch.bfloat16 else 0
+    LL = ctypes.c_longlong
     with torch.cuda.device(q.device):
-        rc = lib().gvd_attention_fwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
-                                     ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                     B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), is_bf16,
-                                     ctypes.c_void_p(_stream()))
+        rc = lib().gvd_attention_fwd_strided(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
+                                             ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                             B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), LL(q_bs), LL(q_rs), LL(kv_bs),
+                                             LL(kv_rs), is_bf16, ctypes.c_void_p(_stream()))
     _check(rc)
     return out
 
 
-def attention(q, k, v, heads):
+def attention(q, k, v, heads, frame_major=False):
+    """softmax(q k^T / sqrt(d)) v per head.  q [B,Nq,h*d], k/v [B,Nk,h*d]; frame_major: [N,B,h*d] (see above)."""
     on_dev = _require_device(q, "attention")
     d = q.shape[-1] // heads
     if on_dev and q.dtype in (torch.float16, torch.bfloat16) and d == 64 and k.dtype == q.dtype and v.dtype == q.dtype:
         if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
-            return _FlashAttention.apply(q, k, v, heads)
-        return _hip_attention_fwd(q, k, v, heads)
+            return _FlashAttention.apply(q, k, v, heads, frame_major)
+        return _hip_attention_fwd(q, k, v, heads, frame_major)
     # fp32 tensors (parity tests) and head sizes the MFMA kernel does not cover (VAE mid-attention, d=512)
-    return attention_math(q, k, v, heads)
+    return attention_math(q, k, v, heads, frame_major)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -5,11 +5,22 @@ Operator boundary kept: `UNetModel(**yaml_params).forward(x[b,8,T,h,w], timestep
 reference's state-dict key names (`input_blocks.4.0.in_layers.2.weight`, `...temopral_conv.conv3.3.weight`,
 `...transformer_blocks.0.attn2.to_k_ip.weight`, ...) so the ViewCrafter checkpoint loads with strict=True.
 
-What is different: the compute is organised around the hot operators of `ops` (flash attention on
-MFMA, fp32-statistics GroupNorm(+SiLU)), tokens stay in one [B, N, C] layout through a transformer
-block, the 256 image tokens + 77 text tokens are projected ONCE per layer for all T frames when the
-context is frame-invariant (the reference re-projects 25 identical copies), and activation
-checkpointing is off by default (288 GB of HBM; it can be switched on per model).
+Layout (the MI355X-first part).  Every feature map lives in ONE memory layout for the whole network:
+token-major  [frame, y, x, channel]  (= torch channels_last for the 4-D [(b t), C, H, W] view):
+
+  * 2-D convolutions consume / produce it directly (NHWC implicit-GEMM kernels, no NCHW<->NHWC transposes);
+  * a spatial transformer's tokens [(b t), h*w, C] are the same bytes -- no 'b c h w -> b (h w) c' copies;
+  * the temporal (3,1,1) convolution is three [T*h*w, C] x [C, C] GEMMs on frame-shifted slices of the same
+    bytes (see TemporalConvBlock);
+  * temporal self-attention (sequence = the T frames of one pixel) reads its q/k/v in place with the strided
+    MFMA attention kernel (`frame_major=True`) instead of materialising '(b h w) t c' tensors;
+  * GroupNorm runs the channels-last kernel on whatever token range the statistics span
+    (one frame for 2-D norms, all T frames for the temporal ones).
+The reference performs 4-6 full-tensor rearrange copies per transformer / temporal block.
+
+Also: the 77 text + 256 image context tokens are projected ONCE per layer for all T frames when the context
+is frame-invariant (the reference projects 25 identical copies), and activation checkpointing is
+off by default (288 GB of HBM; `use_checkpoint=True` restores it).
 """
 import torch
 import torch.nn as nn
@@ -26,11 +37,34 @@ def zero_module(m):
     return m
 
 
+def _cl(x):
+    """4-D [(b t), C, H, W] tensor in token-major (channels_last) memory."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _tok(x):
+    """[(b t), C, H, W] channels_last  ->  [(b t), H, W, C] contiguous VIEW (a copy only if x was not channels_last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _img(tok):
+    """[(b t), H, W, C] contiguous -> [(b t), C, H, W] channels_last view."""
+    return tok.permute(0, 3, 1, 2)
+
+
+def _gn_tokens(gn, tok, n_stat, silu=False):
+    """GroupNorm over token-major data; statistics span tok.numel() / (n_stat * C) tokens per group."""
+    C = tok.shape[-1]
+    y = ops.group_norm(tok.reshape(n_stat, -1, C), gn.num_groups, gn.weight, gn.bias, gn.eps, silu=silu, channels_last=True)
+    return y.reshape(tok.shape)
+
+
 class GroupNorm32(nn.GroupNorm):
-    """fp32-statistics GroupNorm (lvdm/basics.py:76-86); `silu=True` fuses the activation."""
+    """fp32-statistics GroupNorm of a 4-D feature map (lvdm/basics.py:76-86); `silu=True` fuses the activation."""
 
     def forward(self, x, silu=False):
-        return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, silu)
+        tok = _tok(x)
+        return _img(_gn_tokens(self, tok, tok.shape[0], silu))
 
 
 def _run(fn, use_checkpoint, *args):
@@ -66,7 +100,7 @@ class CrossAttention(nn.Module):
 
     def _kv(self, context, frames):
         """Project K/V (and image-prompt K/V).  `frames` > 1 means `context` holds ONE copy of a context
-        shared by `frames` consecutive batch rows: project once, expand as a view."""
+        shared by `frames` consecutive batch rows: project once, then expand."""
         ctx_t = context[:, :self.text_context_len]
         k, v = self.to_k(ctx_t), self.to_v(ctx_t)
         k_ip = v_ip = None
@@ -78,10 +112,14 @@ class CrossAttention(nn.Module):
             k, v, k_ip, v_ip = rep(k), rep(v), rep(k_ip), rep(v_ip)
         return k, v, k_ip, v_ip
 
-    def forward(self, x, context=None, shared_frames=1):
+    def forward(self, x, context=None, shared_frames=1, frame_major=False):
         q = self.to_q(x)
         if context is None:
-            out = ops.attention(q, self.to_k(x), self.to_v(x), self.heads)
+            k, v = self.to_k(x), self.to_v(x)
+            if frame_major:  # x [b, T, pixels, C]: one T-long sequence per pixel, read in place
+                out = torch.stack([ops.attention(q[i], k[i], v[i], self.heads, frame_major=True) for i in range(x.shape[0])], 0)
+            else:
+                out = ops.attention(q, k, v, self.heads)
         else:
             k, v, k_ip, v_ip = self._kv(context, shared_frames)
             out = ops.attention(q, k, v, self.heads)
@@ -125,17 +163,17 @@ class BasicTransformerBlock(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
         self.use_checkpoint = use_checkpoint
 
-    def _fwd(self, x, context, shared_frames):
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), context, shared_frames) + x
+    def _fwd(self, x, context, shared_frames, frame_major):
+        x = self.attn1(self.norm1(x), frame_major=frame_major) + x
+        x = self.attn2(self.norm2(x), context, shared_frames, frame_major=frame_major) + x
         return self.ff(self.norm3(x)) + x
 
-    def forward(self, x, context=None, shared_frames=1):
-        return _run(lambda a, c: self._fwd(a, c, shared_frames), self.use_checkpoint, x, context)
+    def forward(self, x, context=None, shared_frames=1, frame_major=False):
+        return _run(lambda a, c: self._fwd(a, c, shared_frames, frame_major), self.use_checkpoint, x, context)
 
 
 class SpatialTransformer(nn.Module):
-    """attention.py:249-310 (use_linear=True layout: GN -> tokens -> Linear in -> blocks -> Linear out)."""
+    """attention.py:249-310 (use_linear=True: GN -> tokens -> Linear in -> blocks -> Linear out -> + x)."""
 
     def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, use_checkpoint=False,
                  use_linear=True, image_cross_attention=False, image_cross_attention_scale_learnable=False):
@@ -151,28 +189,28 @@ class SpatialTransformer(nn.Module):
             for _ in range(depth)])
         self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv2d(inner, in_channels, 1))
 
+    @staticmethod
+    def _proj(layer, t):  # per-token projection; a 1x1 Conv2d is a Linear with weight [out, in, 1, 1]
+        if isinstance(layer, nn.Linear):
+            return layer(t)
+        return F.linear(t, layer.weight.flatten(1), layer.bias)
+
     def forward(self, x, context=None, shared_frames=1):
-        b, c, h, w = x.shape
-        x_in = x
-        x = ops.group_norm(x, 32, self.norm.weight, self.norm.bias, self.norm.eps)
-        if not self.use_linear:
-            x = self.proj_in(x)
-        x = x.flatten(2).transpose(1, 2)  # [b, hw, c]
-        if self.use_linear:
-            x = self.proj_in(x)
+        n, c, h, w = x.shape
+        tok = _tok(x)
+        t = _gn_tokens(self.norm, tok, n).reshape(n, h * w, c)
+        t = self._proj(self.proj_in, t)
         for blk in self.transformer_blocks:
-            x = blk(x, context, shared_frames)
-        if self.use_linear:
-            x = self.proj_out(x)
-        x = x.transpose(1, 2).reshape(b, -1, h, w)
-        if not self.use_linear:
-            x = self.proj_out(x)
-        return x + x_in
+            t = blk(t, context, shared_frames)
+        t = self._proj(self.proj_out, t)
+        return _img(t.reshape(n, h, w, c) + tok)
 
 
 class TemporalTransformer(nn.Module):
     """attention.py:313-412, only_self_att=True, no relative position, no causal mask (ViewCrafter yaml).
-    Tokens: one sequence of T frames per pixel -> [(b h w), T, C]; both attn1 and attn2 are self-attention."""
+    One sequence of T frames per pixel; both attn1 and attn2 are self-attention.  Works on the token-major
+    [b, T, h*w, C] view: per-token ops (GN affine, LayerNorm, Linear, FF) are order-agnostic, and the attention
+    kernel reads the frames of a pixel with stride h*w*C."""
 
     def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., use_checkpoint=False, use_linear=False):
         super().__init__()
@@ -184,23 +222,22 @@ class TemporalTransformer(nn.Module):
             BasicTransformerBlock(inner, n_heads, d_head, dropout, None, use_checkpoint) for _ in range(depth)])
         self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv1d(inner, in_channels, 1))
 
-    def forward(self, x):  # x [b, c, t, h, w]
-        b, c, t, h, w = x.shape
-        x_in = x
-        x = ops.group_norm(x, 32, self.norm.weight, self.norm.bias, self.norm.eps)
-        x = x.permute(0, 3, 4, 2, 1).reshape(b * h * w, t, c)  # [(b h w), t, c]
-        if self.use_linear:
-            x = self.proj_in(x)
-        else:  # Conv1d(k=1) == per-token linear with weight [inner, c, 1]
-            x = F.linear(x, self.proj_in.weight.squeeze(-1), self.proj_in.bias)
+    @staticmethod
+    def _proj(layer, t):  # Conv1d(k=1) == per-token Linear with weight [out, in, 1]
+        if isinstance(layer, nn.Linear):
+            return layer(t)
+        return F.linear(t, layer.weight.squeeze(-1), layer.bias)
+
+    def forward(self, x, batch_size):  # x [(b T), C, H, W]
+        bt, c, h, w = x.shape
+        b, T = batch_size, bt // batch_size
+        tok = _tok(x)
+        t = _gn_tokens(self.norm, tok, b).reshape(b, T, h * w, c)  # statistics over (C/32, T, h, w) per sample
+        t = self._proj(self.proj_in, t)
         for blk in self.transformer_blocks:
-            x = blk(x)
-        if self.use_linear:
-            x = self.proj_out(x)
-        else:
-            x = F.linear(x, self.proj_out.weight.squeeze(-1), self.proj_out.bias)
-        x = x.reshape(b, h, w, t, c).permute(0, 4, 3, 1, 2)
-        return x + x_in
+            t = blk(t, frame_major=True)
+        t = self._proj(self.proj_out, t)
+        return _img(t.reshape(bt, h, w, c) + tok)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -210,11 +247,9 @@ class TemporalConvBlock(nn.Module):
     """openaimodel3d.py:239-279: 4 x [GN32 -> SiLU -> (Dropout) -> Conv3d k=(3,1,1) pad (1,0,0)] + identity.
 
     The (3,1,1) convolution mixes channels over three neighbouring FRAMES of one pixel; on MI355X it is run
-    as what it is -- three [T*h*w, C] x [C, C] GEMMs on a token-major [b, T, h*w, C] view, the t-1 / t+1 taps
+    as what it is -- three [T*h*w, C] x [C, C] GEMMs on the token-major [b, T, h*w, C] view, the t-1 / t+1 taps
     accumulated in the GEMM epilogue (addmm_, beta = 1) on frame-shifted slices.  No im2col, no 3-D
-    convolution library call (MIOpen's grouped-conv kernel ran these at ~47 TFLOP/s: 40 % of a U-Net forward).
-    The four GroupNorms run on the same token-major tensor (channels-last kernel), so the block costs one
-    layout change in and one out."""
+    convolution library call (MIOpen's grouped-conv kernel ran these at ~47 TFLOP/s: 40 % of a U-Net forward)."""
 
     def __init__(self, channels, dropout=0.0):
         super().__init__()
@@ -230,13 +265,11 @@ class TemporalConvBlock(nn.Module):
     def _tap_weights(self, conv):
         """[3, Cout, Cin] contiguous per-frame-tap matrices, cached until the parameter changes."""
         w = conv.weight
-        key = id(conv)
-        hit = self._taps.get(key)
-        if hit is None or hit[0] != w._version or hit[1].dtype != w.dtype or hit[1].device != w.device or w.requires_grad:
-            taps = w[:, :, :, 0, 0].permute(2, 0, 1).contiguous()
-            if w.requires_grad:
-                return taps
-            self._taps[key] = hit = (w._version, taps)
+        if w.requires_grad:
+            return w[:, :, :, 0, 0].permute(2, 0, 1).contiguous()
+        hit = self._taps.get(id(conv))
+        if hit is None or hit[0] != w._version or hit[1].dtype != w.dtype or hit[1].device != w.device:
+            self._taps[id(conv)] = hit = (w._version, w[:, :, :, 0, 0].permute(2, 0, 1).contiguous())
         return hit[1]
 
     @staticmethod
@@ -253,14 +286,19 @@ class TemporalConvBlock(nn.Module):
                 out[bi, :-1].reshape(-1, co).addmm_(hs[bi, 1:].reshape(-1, c), w2)
         return out
 
-    def forward(self, x):  # [b, c, t, h, w] (any strides)
-        b, c, t, hh, ww = x.shape
-        h = x.permute(0, 2, 3, 4, 1).reshape(b, t, hh * ww, c)  # token-major copy
+    def forward_tokens(self, tok, b):  # tok [(b t), H, W, C] contiguous
+        bt, hh, ww, c = tok.shape
+        h = tok.reshape(b, bt // b, hh * ww, c)
         for seq in (self.conv1, self.conv2, self.conv3, self.conv4):
             gn, conv = seq[0], seq[-1]
-            h = ops.group_norm(h, 32, gn.weight, gn.bias, gn.eps, silu=True, channels_last=True)
+            h = _gn_tokens(gn, h, b, silu=True)
             h = self._temporal_gemm(h, self._tap_weights(conv), conv.bias)
-        return x + h.reshape(b, t, hh, ww, c).permute(0, 4, 1, 2, 3)
+        return tok + h.reshape(bt, hh, ww, c)
+
+    def forward(self, x):  # reference signature: [b, c, t, h, w]
+        b, c, t, hh, ww = x.shape
+        tok = x.permute(0, 2, 3, 4, 1).reshape(b * t, hh, ww, c)
+        return self.forward_tokens(tok, b).reshape(b, t, hh, ww, c).permute(0, 4, 1, 2, 3)
 
 
 class ResBlock(nn.Module):
@@ -285,9 +323,7 @@ class ResBlock(nn.Module):
         h = self.out_layers[3](self.out_layers[2](self.out_layers[0](h, silu=True)))
         h = self.skip_connection(x) + h
         if self.use_temporal_conv and batch_size:
-            bt, c, hh, ww = h.shape
-            h5 = h.reshape(batch_size, bt // batch_size, c, hh, ww).transpose(1, 2)
-            h = self.temopral_conv(h5).transpose(1, 2).reshape(bt, c, hh, ww)
+            h = _img(self.temopral_conv.forward_tokens(_tok(h), batch_size))
         return h
 
     def forward(self, x, emb, batch_size=None):
@@ -322,9 +358,7 @@ class TimestepEmbedSequential(nn.Sequential):
             elif isinstance(layer, SpatialTransformer):
                 x = layer(x, context, shared_frames)
             elif isinstance(layer, TemporalTransformer):
-                bt, c, h, w = x.shape
-                x5 = x.reshape(batch_size, bt // batch_size, c, h, w).transpose(1, 2)
-                x = layer(x5).transpose(1, 2).reshape(bt, c, h, w)
+                x = layer(x, batch_size)
             else:
                 x = layer(x)
         return x
@@ -402,9 +436,18 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(),
                                  zero_module(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
 
+    def to_token_major(self):
+        """Store every Conv2d weight channels_last so the NHWC convolution kernels get their native filter layout
+        (values unchanged; state_dict round-trips)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        return self
+
     def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         b, _, t, hh, ww = x.shape
         wdtype = self.input_blocks[0][0].weight.dtype  # fp32 weights (+autocast) or a model converted with .half()
+        xin_dtype = x.dtype
         x = x.to(wdtype)
         context = context.to(wdtype)
         emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
@@ -424,7 +467,7 @@ class UNetModel(nn.Module):
                 fs = torch.full((b,), self.default_fs, dtype=torch.long, device=x.device)
             fs_emb = self.fps_embedding(timestep_embedding(fs, self.model_channels).type(x.dtype))
             emb = emb + fs_emb.repeat_interleave(t, dim=0)
-        h = x.transpose(1, 2).reshape(b * t, -1, hh, ww)
+        h = _cl(x.transpose(1, 2).reshape(b * t, -1, hh, ww))  # -> token-major for the whole network
         hs = []
         for i, module in enumerate(self.input_blocks):
             h = module(h, emb, context, b, shared)
@@ -434,6 +477,5 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb, context, b, shared)
         for module in self.output_blocks:
             h = module(torch.cat([h, hs.pop()], dim=1), emb, context, b, shared)
-        h = h.type(x.dtype)
-        y = self.out[2](self.out[0](h, silu=True))
+        y = self.out[2](self.out[0](h, silu=True)).to(xin_dtype)
         return y.reshape(b, t, -1, hh, ww).transpose(1, 2)

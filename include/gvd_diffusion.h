@@ -21,6 +21,16 @@ extern "C" {
 int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out,
                       int B, int H, int Nq, int Nk, int D, float scale, int is_bf16, void* stream);
 
+/* Same kernel with explicit addressing: element (batch b, row n, head h, channel d) of q/out lives at
+ * b*q_bs + n*q_rs + h*D + d, of k/v at b*kv_bs + n*kv_rs + h*D + d (strides in elements, multiples of 8).
+ * Lets temporal attention (sequence = the T frames of one pixel) read a token-major [T, pixels, H*D] tensor in
+ * place (bs = H*D, rs = pixels*H*D) instead of materialising the '(b h w) t c' transposes of
+ * lvdm/modules/attention.py:370-407. */
+int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void* out,
+                              int B, int H, int Nq, int Nk, int D, float scale,
+                              long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
+                              int is_bf16, void* stream);
+
 /* One complete no-grad DDIM update for the v-parameterisation, batch 1, fp32 latents of n elements:
  *   v      = e_uncond + cfg_scale (e_cond - e_uncond)
  *   v      = phi v std(e_cond)/std(v) + (1 - phi) v              (phi = guidance_rescale; skipped if 0)

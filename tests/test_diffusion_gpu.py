@@ -187,3 +187,14 @@ def test_temporal_conv_gemm_form_on_device_matches_conv3d():
         assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5)
         y16 = blk.half()(x.half())
     assert float((y16.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("T,P,H", [(25, 300, 5), (16, 64, 8), (3, 1000, 10)])
+def test_frame_major_strided_attention_matches_transposed_math(T, P, H):
+    """Temporal attention reads [T, pixels, H*64] in place (kernel batch stride = H*64, row stride = pixels*H*64)."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(T * P)
+    q, k, v = (torch.randn(T, P, H * 64, device=DEV, generator=g).half() for _ in range(3))
+    out = ops.attention(q, k, v, H, frame_major=True)
+    ref = ops.attention_math(q.float().transpose(0, 1), k.float().transpose(0, 1), v.float().transpose(0, 1), H).transpose(0, 1)
+    assert out.shape == q.shape and float((out.float() - ref).abs().max()) < 4e-3
