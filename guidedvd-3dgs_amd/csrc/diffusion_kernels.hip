@@ -100,22 +100,50 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
     f16v o0 = {}, o1 = {};
     float m = -1.0e30f, l = 0.f;
 
-    for (int kt = 0; kt < Nk; kt += KV_TILE) {
-        __syncthreads();
-        // ---- stage K (row-major) and V (transposed) tiles ----
-        for (int c = tid; c < KV_TILE * 8; c += NT) {
-            const int row = c >> 3, c8 = (c & 7) * 8;
-            const int key = kt + row;
-            vec8 kv = vec8{}, vv = vec8{};
-            if (key < Nk) {
-                kv = *reinterpret_cast<const vec8*>(kb + (size_t)key * krs + c8);
-                vv = *reinterpret_cast<const vec8*>(vb + (size_t)key * krs + c8);
-            }
-            *reinterpret_cast<vec8*>(&sK[row][c8]) = kv;
+    // Staging maps (per pass of NT threads over the 512 16-byte chunks of a 64-key x 64-channel tile):
+    //   K : chunk c -> key row c>>3, channels (c&7)*8..+7 : 8 lanes cover one 128-byte row (coalesced), ds_write_b128.
+    //   V : chunk c -> key PAIR kp = c&31 (keys 2kp, 2kp+1), channels (c>>5)*8..+7 : the two keys of each channel are
+    //       packed into one dword and written to V^T[channel][2kp] with ds_write_b32 -- 32 consecutive dwords per
+    //       half-wave, conflict-free (the per-element b16 scatter of the first version was a 16-way bank conflict).
+    constexpr int PASSES = (KV_TILE * 8) / NT;  // 2 for 256 threads, 8 for 64
+    vec8 rk[PASSES], rv0[PASSES / 2 > 0 ? PASSES / 2 : 1], rv1[PASSES / 2 > 0 ? PASSES / 2 : 1];
+    auto prefetch = [&](int kt) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) sVt[c8 + i][row] = vv[i];
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int c = tid + ps * NT, row = c >> 3, c8 = (c & 7) * 8, key = kt + row;
+            rk[ps] = (key < Nk) ? *reinterpret_cast<const vec8*>(kb + (size_t)key * krs + c8) : vec8{};
         }
+#pragma unroll
+        for (int ps = 0; ps < PASSES / 2; ps++) {
+            const int c = tid + ps * NT, kp = c & 31, c8 = (c >> 5) * 8, key = kt + 2 * kp;
+            rv0[ps] = (key < Nk) ? *reinterpret_cast<const vec8*>(vb + (size_t)key * krs + c8) : vec8{};
+            rv1[ps] = (key + 1 < Nk) ? *reinterpret_cast<const vec8*>(vb + (size_t)(key + 1) * krs + c8) : vec8{};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int c = tid + ps * NT, row = c >> 3, c8 = (c & 7) * 8;
+            *reinterpret_cast<vec8*>(&sK[row][c8]) = rk[ps];
+        }
+#pragma unroll
+        for (int ps = 0; ps < PASSES / 2; ps++) {
+            const int c = tid + ps * NT, kp = c & 31, c8 = (c >> 5) * 8;
+            typedef T T2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const T2 pr = { rv0[ps][i], rv1[ps][i] };
+                *reinterpret_cast<T2*>(&sVt[c8 + i][2 * kp]) = pr;
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int kt = 0; kt < Nk; kt += KV_TILE) {
+        __syncthreads();  // every wave is done reading the previous tile
+        commit();
         __syncthreads();
+        if (kt + KV_TILE < Nk) prefetch(kt + KV_TILE);  // global loads of the next tile fly under this tile's math
 
         // ---- S^T = K Q^T : two 32-key blocks ----
         f16v s0 = {}, s1 = {};
@@ -126,29 +154,27 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
             s0 = Tr<T>::mfma(a0, qf[ks], s0);
             s1 = Tr<T>::mfma(a1, qf[ks], s1);
         }
-        // ---- online softmax over this lane's 32 scores (+ the other half's 32) ----
-        const bool ragged = kt + KV_TILE > Nk;
-        float mt = -1.0e30f;
+        // ---- online softmax over this lane's 32 scores (+ the other half's 32); the 1/sqrt(d)*log2(e) scale is
+        //      folded into the exp2 argument (one fma per score) ----
+        if (kt + KV_TILE > Nk) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float x0 = s0[r] * scale_log2e, x1 = s1[r] * scale_log2e;
-            if (ragged) {
-                if (kt + krow >= Nk) x0 = -1.0e30f;
-                if (kt + 32 + krow >= Nk) x1 = -1.0e30f;
+            for (int r = 0; r < 16; r++) {
+                const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (kt + krow >= Nk) s0[r] = -3.0e38f;
+                if (kt + 32 + krow >= Nk) s1[r] = -3.0e38f;
             }
-            s0[r] = x0;
-            s1[r] = x1;
-            mt = fmaxf(mt, fmaxf(x0, x1));
         }
+        float mt = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; r++) mt = fmaxf(mt, fmaxf(s0[r], s1[r]));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m, mt);
+        const float m_new = fmaxf(m, mt * scale_log2e);
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         float rowsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float p0 = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            const float p1 = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, -m_new));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, -m_new));
             s0[r] = p0;
             s1[r] = p1;
             rowsum += p0 + p1;
@@ -156,8 +182,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
         rowsum += __shfl_xor(rowsum, 32, 64);
         l = l * alpha + rowsum;
         m = m_new;
+        if (__any(alpha != 1.0f)) {  // wave-uniform: after the first tiles the running max rarely moves
 #pragma unroll
-        for (int r = 0; r < 16; r++) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; r++) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
 
         // ---- O^T += V^T P^T : P^T fragments via pack + permlane32_swap ----
 #pragma unroll
