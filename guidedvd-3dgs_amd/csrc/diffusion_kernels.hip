@@ -323,36 +323,50 @@ __global__ void __launch_bounds__(256) k_gn_stats_ncs(const T* __restrict__ x, d
     }
 }
 
+// Per-(sample, channel) affine of the normalisation, y = a x + b, formed once (N*C threads) so the streaming apply
+// kernels do one fma (+ SiLU) per element instead of fp64 divisions.
+__global__ void __launch_bounds__(256) k_gn_coef(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float2* __restrict__ coef,
+                                                 int N, int C, int G, long long S, float eps)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C, cpg = C / G;
+    const double cnt = (double)cpg * (double)S;
+    const long long grp = (long long)n * G + c / cpg;
+    const double mean = stats[2 * grp] / cnt;
+    const double var = stats[2 * grp + 1] / cnt - mean * mean;
+    const float rstd = rsqrtf((float)(var > 0 ? var : 0) + eps);
+    const float a = rstd * gamma[c];
+    coef[i] = make_float2(a, beta[c] - (float)mean * a);
+}
+
+__device__ __forceinline__ float silu_f(float f)
+{
+    return f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * f));
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) k_gn_apply_ncs(const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ stats,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      int C, int G, long long S, float eps, int silu, long long total)
+__global__ void __launch_bounds__(256) k_gn_apply_ncs(const T* __restrict__ x, T* __restrict__ y, const float2* __restrict__ coef,
+                                                      long long S, int silu, long long total)
 {
     typedef typename Tr<T>::vec8 vec8;
-    const int cpg = C / G;
-    const double cnt = (double)cpg * (double)S;
     const bool vec = (S & 7) == 0;
     const long long step = (long long)gridDim.x * 256 * (vec ? 8 : 1);
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * (vec ? 8 : 1); i < total; i += step) {
-        const long long nc = i / S;              // n * C + c   (8 consecutive elements share it when S % 8 == 0)
-        const int c = (int)(nc % C);
-        const long long grp = (nc / C) * G + c / cpg;
-        const double mean = stats[2 * grp] / cnt;
-        const double var = stats[2 * grp + 1] / cnt - mean * mean;
-        const float rstd = rsqrtf((float)(var > 0 ? var : 0) + eps);
-        const float a = rstd * gamma[c], b = beta[c] - (float)mean * a;
+        const float2 ab = coef[i / S];           // n * C + c   (8 consecutive elements share it when S % 8 == 0)
         if (vec) {
             vec8 v = *reinterpret_cast<const vec8*>(x + i);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                float f = fmaf(to_f(v[k]), a, b);
-                if (silu) f = f / (1.f + __expf(-f));
+                float f = fmaf(to_f(v[k]), ab.x, ab.y);
+                if (silu) f = silu_f(f);
                 v[k] = (T)f;
             }
             *reinterpret_cast<vec8*>(y + i) = v;
         } else {
-            float f = fmaf(to_f(x[i]), a, b);
-            if (silu) f = f / (1.f + __expf(-f));
+            float f = fmaf(to_f(x[i]), ab.x, ab.y);
+            if (silu) f = silu_f(f);
             y[i] = (T)f;
         }
     }
@@ -393,31 +407,101 @@ __global__ void __launch_bounds__(256) k_gn_stats_nsc(const T* __restrict__ x, d
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_gn_apply_nsc(const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ stats,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      int C, int G, long long S, float eps, int silu, long long total)
+__global__ void __launch_bounds__(256) k_gn_apply_nsc(const T* __restrict__ x, T* __restrict__ y, const float2* __restrict__ coef,
+                                                      int C, long long S, int silu, long long total)
 {
     typedef typename Tr<T>::vec8 vec8;
-    const int cpg = C / G;
-    const double cnt = (double)cpg * (double)S;
     const long long step = (long long)gridDim.x * 256 * 8;
+    const long long SC = S * C;
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < total; i += step) {
-        const int c0 = (int)(i % C);
-        const long long n = i / ((long long)S * C);
+        const long long n = i / SC;
+        const int c0 = (int)((i - n * SC) % C);
+        const float4* cf = reinterpret_cast<const float4*>(coef + n * C + c0);   // 8 (a, b) pairs, 64 B, L1/L2 resident
         vec8 v = *reinterpret_cast<const vec8*>(x + i);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int c = c0 + k;
-            const long long grp = n * G + c / cpg;
-            const double mean = stats[2 * grp] / cnt;
-            const double var = stats[2 * grp + 1] / cnt - mean * mean;
-            const float rstd = rsqrtf((float)(var > 0 ? var : 0) + eps);
-            const float a = rstd * gamma[c];
-            float f = fmaf(to_f(v[k]), a, beta[c] - (float)mean * a);
-            if (silu) f = f / (1.f + __expf(-f));
-            v[k] = (T)f;
+        for (int k = 0; k < 4; k++) {
+            const float4 ab = cf[k];
+            float f0 = fmaf(to_f(v[2 * k]), ab.x, ab.y), f1 = fmaf(to_f(v[2 * k + 1]), ab.z, ab.w);
+            if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
+            v[2 * k] = (T)f0;
+            v[2 * k + 1] = (T)f1;
         }
         *reinterpret_cast<vec8*>(y + i) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim of [M, C] 16-bit rows (nn.LayerNorm in BasicTransformerBlock, attention.py:283-285).
+// One wave per row, the row lives in registers (<= 4 octets per lane), fp32 two-pass statistics.
+template <typename T>
+__global__ void __launch_bounds__(256) k_layer_norm(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ gamma,
+                                                    const T* __restrict__ beta, long long M, int C, float eps)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int lane = threadIdx.x & 63, oct = C >> 3;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * C;
+    vec8 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int o = lane + 64 * j;
+        if (o < oct) {
+            v[j] = *reinterpret_cast<const vec8*>(xr + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += to_f(v[j][k]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (lane + 64 * j < oct) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float d = to_f(v[j][k]) - mean; q = fmaf(d, d, q); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    T* yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int o = lane + 64 * j;
+        if (o < oct) {
+            const vec8 g = *reinterpret_cast<const vec8*>(gamma + o * 8), b = *reinterpret_cast<const vec8*>(beta + o * 8);
+            vec8 r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = (T)fmaf((to_f(v[j][k]) - mean) * rstd, to_f(g[k]), to_f(b[k]));
+            *reinterpret_cast<vec8*>(yr + o * 8) = r;
+        }
+    }
+}
+
+// GEGLU gate (attention.py:415-423): y[m, c] = h[m, c] * gelu(h[m, C + c]) for h = proj(x) of width 2C; exact (erf) GELU.
+template <typename T>
+__global__ void __launch_bounds__(256) k_geglu(const T* __restrict__ h, T* __restrict__ y, long long M, int C)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int oct = C >> 3;
+    const long long total = M * oct, step = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) {
+        const long long m = i / oct;
+        const int o = (int)(i - m * oct);
+        const T* hr = h + m * 2 * C + o * 8;
+        const vec8 a = *reinterpret_cast<const vec8*>(hr), g = *reinterpret_cast<const vec8*>(hr + C);
+        vec8 r;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float gf = to_f(g[k]);
+            // torch evaluates gelu in fp32 and rounds to the 16-bit type before the product (two separate ops)
+            const T ge = (T)(0.5f * gf * (1.f + erff(gf * 0.70710678118654752f)));
+            r[k] = (T)(to_f(a[k]) * to_f(ge));
+        }
+        *reinterpret_cast<vec8*>(y + m * C + o * 8) = r;
     }
 }
 
@@ -488,9 +572,11 @@ int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta
     if (channels_last && (C % 8)) return fail(-1, "gvd_group_norm: channels-last needs C % 8 == 0");
     hipError_t e = hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(double), stream);
     if (e != hipSuccess) return fail(-2, "hipMemsetAsync(stats)", e);
+    float2* coef = reinterpret_cast<float2*>(stats + (size_t)N * G * 2);
+    const int cblocks = (N * C + 255) / 256;
     const long long total = (long long)N * C * S;
     const long long vecs = channels_last || (S % 8 == 0) ? total / 8 : total;
-    const int ablocks = (int)((vecs + 255) / 256 < 8192 ? (vecs + 255) / 256 : 8192);
+    const int ablocks = (int)((vecs + 255) / 256 < 16384 ? (vecs + 255) / 256 : 16384);
     if (!channels_last) {
         const long long L = (long long)(C / G) * S;
         int chunks = (int)((L + 32767) / 32768);
@@ -498,24 +584,56 @@ int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta
         dim3 grid((unsigned)(N * G), (unsigned)chunks);
         if (is_bf16) {
             hipLaunchKernelGGL(k_gn_stats_ncs<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, stats, L, chunks);
-            hipLaunchKernelGGL(k_gn_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
+            hipLaunchKernelGGL(k_gn_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, S, silu, total);
         } else {
             hipLaunchKernelGGL(k_gn_stats_ncs<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, stats, L, chunks);
-            hipLaunchKernelGGL(k_gn_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
+            hipLaunchKernelGGL(k_gn_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, S, silu, total);
         }
     } else {
         const int rows = 128;
         dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
         if (is_bf16) {
             hipLaunchKernelGGL(k_gn_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, stats, C, G, S, rows);
-            hipLaunchKernelGGL(k_gn_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
+            hipLaunchKernelGGL(k_gn_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, C, S, silu, total);
         } else {
             hipLaunchKernelGGL(k_gn_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, stats, C, G, S, rows);
-            hipLaunchKernelGGL(k_gn_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, stats, gamma, beta, C, G, S, eps, silu, total);
+            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
+            hipLaunchKernelGGL(k_gn_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, C, S, silu, total);
         }
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_*", e);
+    return 0;
+}
+
+int gvd_layer_norm(const void* x, void* y, const void* gamma, const void* beta, long long M, int C, float eps, int is_bf16,
+                   void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || (C % 8) || C > 2048) return fail(-1, "gvd_layer_norm: bad arguments (C % 8 == 0, C <= 2048)");
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return fail(-1, "gvd_layer_norm: pointers must be 16-byte aligned");
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (is_bf16) hipLaunchKernelGGL(k_layer_norm<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, (const __bf16*)gamma, (const __bf16*)beta, M, C, eps);
+    else hipLaunchKernelGGL(k_layer_norm<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, (const _Float16*)gamma, (const _Float16*)beta, M, C, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_layer_norm", e);
+    return 0;
+}
+
+int gvd_geglu(const void* h, void* y, long long M, int C, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h || !y || M <= 0 || C <= 0 || (C % 8)) return fail(-1, "gvd_geglu: bad arguments (C % 8 == 0)");
+    if (((uintptr_t)h | (uintptr_t)y) & 15) return fail(-1, "gvd_geglu: pointers must be 16-byte aligned");
+    const long long vecs = M * (C / 8);
+    const int blocks = (int)((vecs + 255) / 256 < 32768 ? (vecs + 255) / 256 : 32768);
+    if (is_bf16) hipLaunchKernelGGL(k_geglu<__bf16>, dim3(blocks), dim3(256), 0, stream, (const __bf16*)h, (__bf16*)y, M, C);
+    else hipLaunchKernelGGL(k_geglu<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)h, (_Float16*)y, M, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_geglu", e);
     return 0;
 }
 

@@ -14,3 +14,10 @@ import os as _os
 # The U-Net keeps every feature map token-major (channels_last); PyTorch-ROCm only hands NHWC tensors to MIOpen's
 # NHWC kernels when this is set (otherwise it transposes to NCHW and back around every convolution).
 _os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+
+# MIOpen's default (fast-find) heuristic picks a slow generic kernel for several of the U-Net's NHWC shapes; the
+# measured per-shape choices for gfx950 / 256 CUs (recorded by an exhaustive find on an MI355X, `GVD_CONV_FIND=1`) ship
+# with the package so that a fresh process starts with them instead of re-running a multi-minute find.
+_db = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+if _os.path.isdir(_db) and _os.access(_db, _os.W_OK):
+    _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)

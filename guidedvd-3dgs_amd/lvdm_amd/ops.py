@@ -153,7 +153,7 @@ def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last):
     C = x.shape[-1] if channels_last else x.shape[1]
     S = x.numel() // (N * C)
     y = torch.empty_like(x)
-    stats = torch.empty(2 * N * groups, dtype=torch.float64, device=x.device)
+    stats = torch.empty(2 * N * groups + N * C, dtype=torch.float64, device=x.device)  # group sums + (a, b) per (n, c)
     g = weight.float().contiguous()
     b = bias.float().contiguous()
     with torch.cuda.device(x.device):
@@ -195,6 +195,58 @@ def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=Fals
             return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last)
         return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last)
     return group_norm_math(x, groups, weight, bias, eps, silu, channels_last)
+
+
+# --------------------------------------------------------------------------------------------------
+def _half_pair(x, *params):
+    return x.dtype in (torch.float16, torch.bfloat16) and all(p is not None and p.dtype == x.dtype for p in params)
+
+
+def _hip_layer_norm(x, weight, bias, eps):
+    x = x.contiguous()
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib().gvd_layer_norm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                  ctypes.c_void_p(weight.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+                                  ctypes.c_longlong(x.numel() // C), C, ctypes.c_float(eps),
+                                  1 if x.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
+    _check(rc)
+    return y
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm over the last dim (attention.py:283-285).  HIP kernel for no-grad 16-bit activations with 16-bit
+    affine; everything else (fp32 parity runs, autocast with fp32 weights, the guided sampler's autograd pass) takes
+    F.layer_norm, which is what the reference calls."""
+    on_dev = _require_device(x, "layer_norm")
+    C = x.shape[-1]
+    if (on_dev and _half_pair(x, weight, bias) and C % 8 == 0 and C <= 2048
+            and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))):
+        return _hip_layer_norm(x, weight, bias, eps)
+    return F.layer_norm(x, (C,), weight, bias, eps)
+
+
+def geglu_math(h):
+    a, gate = h.chunk(2, dim=-1)
+    return a * F.gelu(gate)
+
+
+def geglu(h):
+    """x * gelu(gate) on the two halves of the GEGLU projection (attention.py:420-423)."""
+    on_dev = _require_device(h, "geglu")
+    C = h.shape[-1] // 2
+    if (on_dev and h.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0
+            and not (torch.is_grad_enabled() and h.requires_grad)):
+        h = h.contiguous()
+        y = torch.empty(h.shape[:-1] + (C,), dtype=h.dtype, device=h.device)
+        with torch.cuda.device(h.device):
+            rc = lib().gvd_geglu(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                 ctypes.c_longlong(h.numel() // (2 * C)), C,
+                                 1 if h.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
+        _check(rc)
+        return y
+    return geglu_math(h)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -133,14 +133,20 @@ class CrossAttention(nn.Module):
         return self.to_out(out)
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state-dict keys) routed through the HIP row kernel on 16-bit activations."""
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        a, gate = self.proj(x).chunk(2, dim=-1)
-        return a * F.gelu(gate)
+        return ops.geglu(self.proj(x))
 
 
 class FeedForward(nn.Module):
@@ -160,7 +166,7 @@ class BasicTransformerBlock(nn.Module):
         self.attn1 = CrossAttention(dim, None, n_heads, d_head, dropout)
         self.ff = FeedForward(dim, dropout=dropout)
         self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, dropout, **attn2_kw)
-        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.norm1, self.norm2, self.norm3 = LayerNorm(dim), LayerNorm(dim), LayerNorm(dim)
         self.use_checkpoint = use_checkpoint
 
     def _fwd(self, x, context, shared_frames, frame_major):

@@ -48,11 +48,20 @@ int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, co
 /* GroupNorm with fp32 statistics and optional fused SiLU on 16-bit activations, forward.
  *   channels_last == 0 : x, y [N][C][S]   (S = product of the spatial/temporal dims)
  *   channels_last == 1 : x, y [N][S][C]   (token-major; C % 8 == 0)
- * gamma, beta: fp32 [C].  stats: 2*N*G doubles of device scratch.  Semantics: GroupNormSpecific
+ * gamma, beta: fp32 [C].  stats: device scratch of 16*N*G + 8*N*C bytes (fp64 group sums, then the per-(n,c) fp32 affine).  Semantics: GroupNormSpecific
  * (lvdm/basics.py:76-86: statistics in fp32, result cast back) followed by nn.SiLU where the reference has
  * `normalization -> SiLU` (openaimodel3d.py:152-156,177-182,259-268,542-546; ae_modules.py nonlinearity). */
 int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta, double* stats,
                    int N, int C, long long S, int G, float eps, int silu, int channels_last, int is_bf16, void* stream);
+
+/* LayerNorm over the last dim of [M, C] 16-bit rows, fp32 statistics, gamma/beta in the same 16-bit type as x.
+ * Replaces nn.LayerNorm in BasicTransformerBlock (lvdm/modules/attention.py:283-285).  C % 8 == 0, C <= 2048. */
+int gvd_layer_norm(const void* x, void* y, const void* gamma, const void* beta, long long M, int C, float eps,
+                   int is_bf16, void* stream);
+
+/* GEGLU gate: y[m, c] = h[m, c] * gelu(h[m, C + c]) (exact erf GELU) for h [M, 2C] -> y [M, C], 16-bit.
+ * Replaces `x, gate = self.proj(x).chunk(2, dim=-1); return x * F.gelu(gate)` (lvdm/modules/attention.py:420-423). */
+int gvd_geglu(const void* h, void* y, long long M, int C, int is_bf16, void* stream);
 
 const char* gvd_diff_last_error(void);
 

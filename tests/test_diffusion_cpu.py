@@ -218,3 +218,19 @@ def test_no_cpu_path_in_the_product():
         ops.attention(q, q, q, 1)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.group_norm(torch.randn(1, 32, 2, 2), 32, None, None)
+
+
+def test_diffusion_library_exports_every_declared_symbol():
+    """include/gvd_diffusion.h is the C-ABI of the DDIM-path kernels; the gfx950 library must export all of it."""
+    import re
+    import __graft_entry__ as g
+    g.build_diffusion()
+    from lvdm_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "gvd_diffusion.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b(gvd_[a-z_0-9]+)\s*\(", hdr))
+    assert {"gvd_attention_fwd", "gvd_attention_fwd_strided", "gvd_ddim_step", "gvd_group_norm", "gvd_layer_norm",
+            "gvd_geglu", "gvd_diff_last_error"} <= names
+    L = ops.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), f"libgvd_diffusion.so does not export {n}"

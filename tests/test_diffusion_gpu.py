@@ -198,3 +198,39 @@ def test_frame_major_strided_attention_matches_transposed_math(T, P, H):
     out = ops.attention(q, k, v, H, frame_major=True)
     ref = ops.attention_math(q.float().transpose(0, 1), k.float().transpose(0, 1), v.float().transpose(0, 1), H).transpose(0, 1)
     assert out.shape == q.shape and float((out.float() - ref).abs().max()) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (33, 1280), (5, 2048), (1, 8)])
+def test_layer_norm_row_kernel_matches_fp32_layer_norm(dtype, M, C):
+    """Tolerance: one rounding of the 16-bit output type (2^-11 rel for f16, 2^-8 for bf16) on |y| <~ 6."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + C)
+    x = (torch.randn(M, C, device=DEV, generator=g) * 2.3 - 0.7).to(dtype)
+    w = (torch.randn(C, device=DEV, generator=g) * 0.3 + 1).to(dtype)
+    b = (torch.randn(C, device=DEV, generator=g) * 0.2).to(dtype)
+    y = ops.layer_norm(x, w, b, 1e-5)
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), w.float(), b.float(), 1e-5)
+    assert y.dtype == dtype and y.shape == x.shape
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert float((y.float() - ref).abs().max()) < tol
+    # 3-D input, same rows
+    y3 = ops.layer_norm(x.view(1, M, C), w, b, 1e-5)
+    assert torch.equal(y3.view(M, C), y)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(999, 1280), (64, 2560), (3, 8)])
+def test_geglu_kernel_matches_torch_two_op_form_bitwise(dtype, M, C):
+    """The kernel reproduces torch's two roundings (gelu -> 16 bit, product -> 16 bit); erf implementations may
+    differ in the last fp32 ulp, so allow one 16-bit ulp on a handful of elements and exactness elsewhere."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M * C)
+    h = (torch.randn(M, 2 * C, device=DEV, generator=g) * 1.5).to(dtype)
+    y = ops.geglu(h)
+    ref = ops.geglu_math(h)
+    assert y.shape == (M, C) and y.dtype == dtype
+    diff = (y.float() - ref.float()).abs()
+    ulp = (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) * ref.float().abs().clamp_min(1e-3)
+    assert bool((diff <= ulp).all())
+    assert float((diff > 0).float().mean()) < 1e-2
