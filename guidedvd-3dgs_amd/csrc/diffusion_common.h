@@ -1,0 +1,81 @@
+// diffusion_common.h -- shared by the translation units of libgvd_diffusion.so: error slot, vector types and the
+// per-element-type MFMA traits (32x32x16, 16-bit operands, fp32 accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/gvd_diffusion.h"
+
+namespace gvdd {
+
+int fail(int code, const char* what, hipError_t e = hipSuccess);   // records the message for gvd_diff_last_error()
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Tr;
+template <> struct Tr<_Float16> {
+    typedef h8 vec8;
+    static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi)
+    {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 p = { (_Float16)lo, (_Float16)hi };
+        return __builtin_bit_cast(unsigned, p);
+    }
+};
+template <> struct Tr<__bf16> {
+    typedef b8 vec8;
+    static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi)
+    {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        b2 p = { (__bf16)lo, (__bf16)hi };
+        return __builtin_bit_cast(unsigned, p);
+    }
+};
+
+constexpr int KV_TILE = 64;   // keys per iteration
+constexpr int LDS_ROW = 72;   // padded row length (elements): 144 B, 16-byte aligned, spreads bank groups
+
+// B operand of the second product from a 32x32 fp32 C block that holds [k-row][n-col] with n = lane & 31:
+// rows 8*k2 .. 8*k2+7 of this lane's 16 registers are packed to 16 bit and exchanged between the wave halves so
+// that lower lanes end with k = base+0..7 and upper lanes with k = base+8..15 (the operand's k = 8*hi + j map).
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::vec8 c_block_to_b_operand(const f16v& s, int k2)
+{
+    const int r0 = 8 * k2;
+    const unsigned u01 = Tr<T>::pack2(s[r0 + 0], s[r0 + 1]), u23 = Tr<T>::pack2(s[r0 + 2], s[r0 + 3]);
+    const unsigned u45 = Tr<T>::pack2(s[r0 + 4], s[r0 + 5]), u67 = Tr<T>::pack2(s[r0 + 6], s[r0 + 7]);
+    auto sa = __builtin_amdgcn_permlane32_swap(u01, u45, false, false);
+    auto sb = __builtin_amdgcn_permlane32_swap(u23, u67, false, false);
+    const u4 packed = { sa[0], sb[0], sa[1], sb[1] };
+    return __builtin_bit_cast(typename Tr<T>::vec8, packed);
+}
+
+// Same, from values already packed in pairs (u[j] = pack(c[2j], c[2j+1])).
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::vec8 packed_c_to_b_operand(const unsigned (&u)[8], int k2)
+{
+    auto sa = __builtin_amdgcn_permlane32_swap(u[4 * k2], u[4 * k2 + 2], false, false);
+    auto sb = __builtin_amdgcn_permlane32_swap(u[4 * k2 + 1], u[4 * k2 + 3], false, false);
+    const u4 packed = { sa[0], sb[0], sa[1], sb[1] };
+    return __builtin_bit_cast(typename Tr<T>::vec8, packed);
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// v_max3_f32 without the sNaN-quieting canonicalisation the IEEE-mode fmaxf lowering inserts per operand
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+}  // namespace gvdd

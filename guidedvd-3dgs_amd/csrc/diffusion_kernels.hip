@@ -16,18 +16,11 @@
 //     (V^T) with plain 16-byte ds_read_b128; K and V^T rows are padded to 72 elements (144 B) so the
 //     32 lanes of a half-wave hit different bank groups;
 //   * O^T = V^T P^T accumulates in 32 fp32 registers, rescaled by the per-lane alpha of the online softmax.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
+#include "diffusion_common.h"
 
-#include <string>
-
-#include "../../include/gvd_diffusion.h"
-
-namespace {
-
+namespace gvdd {
 thread_local std::string g_err;
-int fail(int code, const char* what, hipError_t e = hipSuccess)
+int fail(int code, const char* what, hipError_t e)
 {
     char buf[384];
     if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
@@ -35,40 +28,15 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
     g_err = buf;
     return code;
 }
+}  // namespace gvdd
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef __bf16 b8 __attribute__((ext_vector_type(8)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+using namespace gvdd;
 
-template <typename T> struct Tr;
-template <> struct Tr<_Float16> {
-    typedef h8 vec8;
-    static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ unsigned pack2(float lo, float hi)
-    {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        h2 p = { (_Float16)lo, (_Float16)hi };
-        return __builtin_bit_cast(unsigned, p);
-    }
-};
-template <> struct Tr<__bf16> {
-    typedef b8 vec8;
-    static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ unsigned pack2(float lo, float hi)
-    {
-        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-        b2 p = { (__bf16)lo, (__bf16)hi };
-        return __builtin_bit_cast(unsigned, p);
-    }
-};
-
-constexpr int KV_TILE = 64;   // keys per iteration
-constexpr int LDS_ROW = 72;   // padded row length (elements): 144 B, 16-byte aligned, spreads bank groups
+namespace {
 
 template <typename T, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                         T* __restrict__ out, int H, int Nq, int Nk, float scale_log2e,
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                         T* __restrict__ out, float* __restrict__ lse, int H, int Nq, int Nk, float scale_log2e,
                                                          long long q_bs, long long q_rs, long long kv_bs, long long kv_rs)
 {
     typedef typename Tr<T>::vec8 vec8;
@@ -164,21 +132,29 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
                 if (kt + 32 + krow >= Nk) s1[r] = -3.0e38f;
             }
         }
-        float mt = fmaxf(s0[0], s1[0]);
+        float mt = max3f(s0[0], s1[0], s0[1]);
+        mt = max3f(mt, s1[1], s0[2]);
 #pragma unroll
-        for (int r = 1; r < 16; r++) mt = fmaxf(mt, fmaxf(s0[r], s1[r]));
+        for (int r = 3; r < 16; r += 2) { mt = max3f(mt, s0[r], s1[r - 1]); mt = max3f(mt, s1[r], r + 1 < 16 ? s0[r + 1] : mt); }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m, mt * scale_log2e);
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        float rowsum = 0.f;
+        // P = exp2(s*c - m): packed fp32 fma / add (v_pk_*), rounded to 16 bit right away (the MFMA operand type)
+        const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m_new, -m_new };
+        f2 rs2 = { 0.f, 0.f };
+        unsigned pk0[8], pk1[8];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, -m_new));
-            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, -m_new));
-            s0[r] = p0;
-            s1[r] = p1;
-            rowsum += p0 + p1;
+        for (int j = 0; j < 8; j++) {
+            f2 a0 = { s0[2 * j], s0[2 * j + 1] }, a1 = { s1[2 * j], s1[2 * j + 1] };
+            a0 = __builtin_elementwise_fma(a0, c2, nm2);
+            a1 = __builtin_elementwise_fma(a1, c2, nm2);
+            const f2 p0 = { __builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y) };
+            const f2 p1 = { __builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y) };
+            rs2 += p0 + p1;
+            pk0[j] = Tr<T>::pack2(p0.x, p0.y);
+            pk1[j] = Tr<T>::pack2(p1.x, p1.y);
         }
+        float rowsum = rs2.x + rs2.y;
         rowsum += __shfl_xor(rowsum, 32, 64);
         l = l * alpha + rowsum;
         m = m_new;
@@ -187,26 +163,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
             for (int r = 0; r < 16; r++) { o0[r] *= alpha; o1[r] *= alpha; }
         }
 
-        // ---- O^T += V^T P^T : P^T fragments via pack + permlane32_swap ----
+        // ---- O^T += V^T P^T : P^T fragments via permlane32_swap of the packed pairs ----
 #pragma unroll
         for (int kbk = 0; kbk < 2; kbk++) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++) {
-                const int r0 = 8 * k2;
-                unsigned u01, u23, u45, u67;
-                if (kbk == 0) {
-                    u01 = Tr<T>::pack2(s0[r0 + 0], s0[r0 + 1]); u23 = Tr<T>::pack2(s0[r0 + 2], s0[r0 + 3]);
-                    u45 = Tr<T>::pack2(s0[r0 + 4], s0[r0 + 5]); u67 = Tr<T>::pack2(s0[r0 + 6], s0[r0 + 7]);
-                } else {
-                    u01 = Tr<T>::pack2(s1[r0 + 0], s1[r0 + 1]); u23 = Tr<T>::pack2(s1[r0 + 2], s1[r0 + 3]);
-                    u45 = Tr<T>::pack2(s1[r0 + 4], s1[r0 + 5]); u67 = Tr<T>::pack2(s1[r0 + 6], s1[r0 + 7]);
-                }
-                // upper half of (u01,u23) <-> lower half of (u45,u67): lower lanes end with keys base+0..7,
-                // upper lanes with keys base+8..15 -- exactly the B-operand k mapping (k = 8*hi + j)
-                auto sa = __builtin_amdgcn_permlane32_swap(u01, u45, false, false);
-                auto sb = __builtin_amdgcn_permlane32_swap(u23, u67, false, false);
-                const u4 packed = { sa[0], sb[0], sa[1], sb[1] };
-                const vec8 pf = __builtin_bit_cast(vec8, packed);
+                const vec8 pf = packed_c_to_b_operand<T>(kbk == 0 ? pk0 : pk1, k2);
                 const int kcol = 32 * kbk + 16 * k2 + 8 * hi;
                 const vec8 va0 = *reinterpret_cast<const vec8*>(&sVt[col][kcol]);
                 const vec8 va1 = *reinterpret_cast<const vec8*>(&sVt[32 + col][kcol]);
@@ -217,6 +179,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_fwd(const T* __restrict__ q
     }
     // ---- epilogue: O[query][d] = O^T / l ----
     if (valid_q) {
+        // log2-domain log-sum-exp of the scaled scores, kept for the backward kernels: P = exp2(s*c - lse)
+        if (lse && hi == 0) lse[(size_t)bh * Nq + query] = m + __builtin_amdgcn_logf(l);
         const float inv = 1.0f / l;
         T* orow = ob + (size_t)query * rs;
 #pragma unroll
@@ -509,18 +473,18 @@ __global__ void __launch_bounds__(256) k_geglu(const T* __restrict__ h, T* __res
 
 extern "C" {
 
-const char* gvd_diff_last_error(void) { return g_err.c_str(); }
+const char* gvd_diff_last_error(void) { return gvdd::g_err.c_str(); }
 
 int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
                       float scale, int is_bf16, void* stream_)
 {
     return gvd_attention_fwd_strided(q, k, v, out, B, H, Nq, Nk, D, scale, (long long)Nq * H * D, (long long)H * D,
-                                     (long long)Nk * H * D, (long long)H * D, is_bf16, stream_);
+                                     (long long)Nk * H * D, (long long)H * D, nullptr, is_bf16, stream_);
 }
 
 int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
-                              float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs, int is_bf16,
-                              void* stream_)
+                              float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs, float* lse,
+                              int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if ((q_bs | q_rs | kv_bs | kv_rs) & 7) return fail(-1, "gvd_attention_fwd: strides must be multiples of 8 elements");
@@ -532,11 +496,11 @@ int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void*
     const int rows = big ? 128 : 32;
     dim3 grid((unsigned)(B * H), (unsigned)((Nq + rows - 1) / rows));
     if (is_bf16) {
-        if (big) hipLaunchKernelGGL((k_attn_fwd<__bf16, 4>), grid, dim3(256), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
-        else hipLaunchKernelGGL((k_attn_fwd<__bf16, 1>), grid, dim3(64), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        if (big) hipLaunchKernelGGL((k_attn_fwd<__bf16, 4>), grid, dim3(256), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        else hipLaunchKernelGGL((k_attn_fwd<__bf16, 1>), grid, dim3(64), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
     } else {
-        if (big) hipLaunchKernelGGL((k_attn_fwd<_Float16, 4>), grid, dim3(256), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
-        else hipLaunchKernelGGL((k_attn_fwd<_Float16, 1>), grid, dim3(64), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        if (big) hipLaunchKernelGGL((k_attn_fwd<_Float16, 4>), grid, dim3(256), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        else hipLaunchKernelGGL((k_attn_fwd<_Float16, 1>), grid, dim3(64), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_attn_fwd", e);

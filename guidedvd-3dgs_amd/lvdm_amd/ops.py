@@ -74,50 +74,65 @@ def attention_math(q, k, v, heads, frame_major=False):
 
 
 class _FlashAttention(torch.autograd.Function):
-    """fp16/bf16 MFMA flash attention (csrc/diffusion_kernels.hip).  Forward is the hand-written
-    kernel; backward (guided sampler only) recomputes through the explicit math in fp32-softmax form."""
+    """fp16/bf16 MFMA flash attention, forward and backward both hand-written kernels (csrc/diffusion_kernels.hip,
+    csrc/attention_backward.hip).  The backward runs in the guided sampler only."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads, frame_major):
-        out = _hip_attention_fwd(q, k, v, heads, frame_major)
-        ctx.save_for_backward(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, lse = _hip_attention_fwd(q, k, v, heads, frame_major, want_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)
         ctx.heads, ctx.frame_major = heads, frame_major
         return out
 
     @staticmethod
     def backward(ctx, g):
-        q, k, v = ctx.saved_tensors
-        with torch.enable_grad():
-            q_, k_, v_ = (t.detach().requires_grad_(True) for t in (q, k, v))
-            o = attention_math(q_, k_, v_, ctx.heads, ctx.frame_major)
-            gq, gk, gv = torch.autograd.grad(o, (q_, k_, v_), g)
-        return gq, gk, gv, None, None
+        q, k, v, out, lse = ctx.saved_tensors
+        return _hip_attention_bwd(q, k, v, out, g, lse, ctx.heads, ctx.frame_major) + (None, None)
 
 
-def _hip_attention_fwd(q, k, v, heads, frame_major=False):
+def _attn_geometry(q, k, heads, frame_major):
+    C = q.shape[-1]
+    if frame_major:
+        Nq, B, Nk = q.shape[0], q.shape[1], k.shape[0]
+        return B, Nq, Nk, C // heads, (C, B * C, C, B * C)
+    B, Nq, Nk = q.shape[0], q.shape[1], k.shape[1]
+    return B, Nq, Nk, C // heads, (Nq * C, C, Nk * C, C)
+
+
+def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False):
     """q [B,Nq,C], k/v [B,Nk,C]; with frame_major=True the tensors are [N, B, C] (sequence outermost: the T
     frames of B pixels) and are read in place through the kernel's strided addressing."""
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    C = q.shape[-1]
-    d = C // heads
-    if frame_major:
-        Nq, B = q.shape[0], q.shape[1]
-        Nk = k.shape[0]
-        q_bs, q_rs, kv_bs, kv_rs = C, B * C, C, B * C
-    else:
-        B, Nq = q.shape[0], q.shape[1]
-        Nk = k.shape[1]
-        q_bs, q_rs, kv_bs, kv_rs = Nq * C, C, Nk * C, C
+    B, Nq, Nk, d, strides = _attn_geometry(q, k, heads, frame_major)
     out = torch.empty_like(q)
+    lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if want_lse else None
     is_bf16 = 1 if q.dtype == torch.bfloat16 else 0
     LL = ctypes.c_longlong
     with torch.cuda.device(q.device):
         rc = lib().gvd_attention_fwd_strided(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
                                              ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                             B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), LL(q_bs), LL(q_rs), LL(kv_bs),
-                                             LL(kv_rs), is_bf16, ctypes.c_void_p(_stream()))
+                                             B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), *(LL(s) for s in strides),
+                                             ctypes.c_void_p(lse.data_ptr() if want_lse else None),
+                                             is_bf16, ctypes.c_void_p(_stream()))
     _check(rc)
-    return out
+    return (out, lse) if want_lse else out
+
+
+def _hip_attention_bwd(q, k, v, out, g, lse, heads, frame_major=False):
+    g = g.contiguous()
+    B, Nq, Nk, d, strides = _attn_geometry(q, k, heads, frame_major)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    LL, P = ctypes.c_longlong, ctypes.c_void_p
+    with torch.cuda.device(q.device):
+        rc = lib().gvd_attention_bwd_strided(P(q.data_ptr()), P(k.data_ptr()), P(v.data_ptr()), P(out.data_ptr()),
+                                             P(g.data_ptr()), P(lse.data_ptr()), P(delta.data_ptr()), P(dq.data_ptr()),
+                                             P(dk.data_ptr()), P(dv.data_ptr()), B, heads, Nq, Nk, d,
+                                             ctypes.c_float(d ** -0.5), *(LL(s) for s in strides),
+                                             1 if q.dtype == torch.bfloat16 else 0, P(_stream()))
+    _check(rc)
+    return dq, dk, dv
 
 
 def attention(q, k, v, heads, frame_major=False):

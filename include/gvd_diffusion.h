@@ -29,6 +29,18 @@ int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out,
 int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void* out,
                               int B, int H, int Nq, int Nk, int D, float scale,
                               long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
+                              float* lse, int is_bf16, void* stream);
+
+/* Attention backward for the guided sampler's autograd pass (ddim_guidance.py:318-345 differentiates pred_x0 w.r.t.
+ * x_t through every attention layer; xformers' memory_efficient_attention backward in the reference).
+ * Inputs: q, k, v, out (forward result), d_out, and lse = the [B, H, Nq] fp32 log2-domain log-sum-exp the forward
+ * wrote (pass a buffer as `lse` above).  Outputs dq [same addressing as q], dk, dv [same addressing as k, v].
+ * delta: [B, H, Nq] fp32 device scratch (rowsum(d_out * out)).  Flash style, deterministic (no atomics):
+ * one pass over the K/V tiles accumulates dK, dV; a second pass over the Q tiles accumulates dQ. */
+int gvd_attention_bwd_strided(const void* q, const void* k, const void* v, const void* out, const void* d_out,
+                              const float* lse, float* delta, void* dq, void* dk, void* dv,
+                              int B, int H, int Nq, int Nk, int D, float scale,
+                              long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
                               int is_bf16, void* stream);
 
 /* One complete no-grad DDIM update for the v-parameterisation, batch 1, fp32 latents of n elements:

@@ -31,4 +31,15 @@ for name, B, H, Nq, Nk, fm in shapes:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     fl = 4.0 * B * H * Nq * Nk * 64
-    print(f"{name:28s} {dt * 1e3:8.3f} ms  {fl / dt / 1e12:7.1f} TFLOP/s")
+    # backward (guided sampler): dQ, dK, dV; algorithmic flops = 5 products (S, dP, dV, dK, dQ) = 2.5x forward
+    out, lse = ops._hip_attention_fwd(q, k, v, H, fm, want_lse=True)
+    go = torch.randn_like(out)
+    for _ in range(2):
+        ops._hip_attention_bwd(q, k, v, out, go, lse, H, fm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ops._hip_attention_bwd(q, k, v, out, go, lse, H, fm)
+    torch.cuda.synchronize()
+    db = (time.perf_counter() - t0) / n
+    print(f"{name:28s} fwd {dt * 1e3:8.3f} ms {fl / dt / 1e12:7.1f} TFLOP/s   bwd {db * 1e3:8.3f} ms {2.5 * fl / db / 1e12:7.1f} TFLOP/s")

@@ -234,3 +234,31 @@ def test_geglu_kernel_matches_torch_two_op_form_bitwise(dtype, M, C):
     ulp = (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) * ref.float().abs().clamp_min(1e-3)
     assert bool((diff <= ulp).all())
     assert float((diff > 0).float().mean()) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk,fm", [(2, 2, 70, 50, False), (1, 5, 300, 300, False), (3, 1, 129, 77, False),
+                                          (1, 2, 64, 256, False), (2, 3, 1, 1, False), (25, 2, 40, 40, True),
+                                          (7, 5, 25, 25, True)])
+def test_mfma_attention_backward_matches_explicit_softmax_gradients(dtype, B, H, Nq, Nk, fm):
+    """dQ, dK, dV of the flash backward kernels vs autograd through the fp32 explicit-softmax form.  Tolerance: the
+    kernel rounds P and dS to the 16-bit operand type (like xformers / the reference under fp16 autocast): 2^-8 rel
+    (bf16) / 2^-11 (f16) per product term, accumulated in fp32 -> bound relative to the largest gradient entry."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + Nq + Nk)
+    C = H * 64
+    shq, shk = ((Nq, B, C), (Nk, B, C)) if fm else ((B, Nq, C), (B, Nk, C))
+    q = torch.randn(shq, device=DEV, generator=g).to(dtype).requires_grad_(True)
+    k = torch.randn(shk, device=DEV, generator=g).to(dtype).requires_grad_(True)
+    v = torch.randn(shk, device=DEV, generator=g).to(dtype).requires_grad_(True)
+    o = ops.attention(q, k, v, H, frame_major=fm)
+    go = torch.randn(o.shape, device=DEV, generator=g).to(dtype)
+    gq, gk, gv = torch.autograd.grad(o, (q, k, v), go)
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    rq, rk, rv = torch.autograd.grad(ops.attention_math(qf, kf, vf, H, frame_major=fm), (qf, kf, vf), go.float())
+    tol = 6e-3 if dtype == torch.float16 else 3e-2
+    for name, a, b in (("dq", gq, rq), ("dk", gk, rk), ("dv", gv, rv)):
+        assert a.shape == b.shape and a.dtype == dtype
+        # (a single key makes dQ = dK = 0 exactly: keep the denominator at the O(1) scale of the inputs)
+        err = float((a.float() - b).abs().max()) / max(float(b.abs().max()), 1.0)
+        assert err < tol, (name, err)
