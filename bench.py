@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--workload", choices=["raster", "ddim"], default="raster",
+    ap.add_argument("--workload", choices=["raster", "ddim", "ddim_guided"], default="raster",
                     help="raster = BASELINE configs[1] (default, the driver's line); ddim = configs[2], ViewCrafter 25-frame DDIM")
     ap.add_argument("--ddim-height", type=int, default=576)
     ap.add_argument("--ddim-width", type=int, default=1024)
@@ -50,7 +50,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if args.workload == "ddim":
+    if args.workload in ("ddim", "ddim_guided"):
         return ddim_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -237,10 +237,31 @@ def ddim_main(args):
                 p_.copy_(torch.randn(p_.shape, device=dev, generator=g) * 0.02)
     unet = unet.half().eval().to_token_major()
 
+    guided = args.workload == "ddim_guided"
+    vae = None
+    if guided:  # B3/B13: per-frame KL-VAE decode inside the step, random-init decoder (no checkpoints offline)
+        from lvdm_amd.guidance import LossGuidance
+        from lvdm_amd.model import VIEWCRAFTER_VAE
+        from lvdm_amd.samplers import DDIMSamplerGuidance
+        from lvdm_amd.vae import AutoencoderKLDecoder
+        with torch.device(dev):
+            vae = AutoencoderKLDecoder(VIEWCRAFTER_VAE)
+        vae = vae.half().eval()
+        for p_ in list(unet.parameters()) + list(vae.parameters()):
+            p_.requires_grad_(False)
+
     class LD(DiffusionSchedule):
         def __init__(self):
             super().__init__()
             self.model = DiffusionWrapper(unet)
+            self.first_stage_model = vae
+            self.scale_factor = 0.18215
+
+        def differentiable_decode_first_stage(self, z, **kw):  # ddpm3d.py:646-675, perframe_ae, one frame at a time
+            b, c, t, hh, ww = z.shape
+            z2 = z.transpose(1, 2).reshape(b * t, c, hh, ww).half()
+            res = torch.cat([self.first_stage_model.decode(z2[i:i + 1] / self.scale_factor) for i in range(b * t)], 0)
+            return res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
 
         @property
         def device(self):
@@ -253,8 +274,14 @@ def ddim_main(args):
     cond = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g).half()],
             "c_concat": [(torch.randn(1, 4, T, h, w, device=dev, generator=g) * 0.18).half()]}
     uc = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g).half()], "c_concat": cond["c_concat"]}
-    sampler = DDIMSampler(ld)
+    sampler = DDIMSamplerGuidance(ld) if guided else DDIMSampler(ld)
     sampler.make_schedule(50, "uniform_trailing", 1.0)
+    lg = None
+    if guided:
+        lg = LossGuidance(ddim_steps=50, recur_steps=1, device=str(dev))
+        lg.set_hw(args.ddim_height, args.ddim_width)
+        lg.set_guidance_images(torch.rand(T, 3, args.ddim_height, args.ddim_width, device=dev, generator=g))
+        lg.set_guidance_masks((torch.rand(T, 1, args.ddim_height, args.ddim_width, device=dev, generator=g) > 0.3).float())
     x = torch.randn(1, 4, T, h, w, device=dev, generator=g)
     fs = torch.tensor([10], device=dev)
     steps, warm = min(args.steps, 50), min(args.warmup, 5)
@@ -263,6 +290,10 @@ def ddim_main(args):
     def one(i, x):
         index = idx[i % 50]
         t = torch.full((1,), int(sampler.ddim_timesteps[index]), device=dev, dtype=torch.long)
+        if guided:
+            xp, _ = sampler.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5,
+                                          unconditional_conditioning=uc, guidance_rescale=0.7, fs=fs, loss_guidance_fn=lg)
+            return xp
         with torch.no_grad():
             xp, _ = sampler.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5,
                                           unconditional_conditioning=uc, guidance_rescale=0.7, fs=fs)
@@ -275,10 +306,10 @@ def ddim_main(args):
     ev = []
     orig = ops._hip_attention_fwd
 
-    def timed_attn(q, k, v, heads, frame_major=False):
+    def timed_attn(q, k, v, heads, frame_major=False, want_lse=False):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        o = orig(q, k, v, heads, frame_major)
+        o = orig(q, k, v, heads, frame_major, want_lse)
         b.record()
         nb, nq, nk = (q.shape[1], q.shape[0], k.shape[0]) if frame_major else (q.shape[0], q.shape[1], k.shape[1])
         ev.append((a, b, nb * heads, nq, nk))
@@ -297,12 +328,15 @@ def ddim_main(args):
     MFMA_PEAK = 2500.0  # TFLOP/s dense f16/bf16 (MI355X_MICROARCH.md)
     unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
     line = {
-        "metric": "viewcrafter_ddim_steps_per_s", "value": round(steps / elapsed, 4), "unit": "steps/s", "n_gpus": 1,
+        "metric": "viewcrafter_guided_ddim_steps_per_s" if guided else "viewcrafter_ddim_steps_per_s", "value": round(steps / elapsed, 4), "unit": "steps/s", "n_gpus": 1,
         "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / steps, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": (round((steps / elapsed) / 0.42, 3) if (args.ddim_height, args.ddim_width, T) == (576, 1024, 25) else None),
+        "scaling": "weak", "vs_baseline": (round((steps / elapsed) / 0.42, 3) if (args.ddim_height, args.ddim_width, T) == (576, 1024, 25) and not guided else None),
         "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: ViewCrafter {T}-frame {args.ddim_height}x{args.ddim_width} DDIM, unguided, CFG 7.5, "
-                               "rescale 0.7, eta 1 (2 U-Net fwd / step), random-init U-Net 1.44 B params",
+        "config": {"workload": (f"ViewCrafter {T}-frame {args.ddim_height}x{args.ddim_width} GUIDED DDIM step (ddim_guidance.py:205-363): "
+                                "2 U-Net fwd + dgrad w.r.t. x_t through both, 25 x (VAE decode fwd + dgrad), masked-L2 guidance, CFG 7.5, "
+                                "rescale 0.7, random-init U-Net + VAE decoder") if guided else
+                               (f"BASELINE configs[2]: ViewCrafter {T}-frame {args.ddim_height}x{args.ddim_width} DDIM, unguided, CFG 7.5, "
+                                "rescale 0.7, eta 1 (2 U-Net fwd / step), random-init U-Net 1.44 B params"),
                    "latent": [1, 4, T, h, w], "context_tokens": 333, "unet_tflop_per_fwd": unet_tflop,
                    "baseline_note": "vs_baseline = steps/s over the ViewCrafter README A100 figure 0.42 steps/s (120 s / 50 steps, "
                                     "whole pipeline incl. VAE/CLIP; third_party/ViewCrafter/README.md:116-118)"},
@@ -310,7 +344,8 @@ def ddim_main(args):
                      "achieved": round(att_flops / (att_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
                      "frac": round(att_flops / (att_ms * 1e-3) / 1e12 / MFMA_PEAK, 4), "traffic": None,
                      "launches": len(ev), "attention_ms_per_step": round(att_ms / steps, 2)},
-        "unet_achieved_tflops": (round(2 * unet_tflop * steps / elapsed, 1) if unet_tflop else None),
+        "unet_achieved_tflops": (round(2 * unet_tflop * steps / elapsed, 1) if unet_tflop and not guided else None),
+        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
     }
     print(json.dumps(line), flush=True)
