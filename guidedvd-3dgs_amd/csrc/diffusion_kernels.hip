@@ -395,6 +395,184 @@ __global__ void __launch_bounds__(256) k_gn_apply_nsc(const T* __restrict__ x, T
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GroupNorm (+SiLU) backward w.r.t. the input only (the guided sampler needs d/dx_t; weights are frozen).
+//   z = a_c x + b_c (the forward's per-(n,c) affine),  y = silu(z) or z,  dz = dy silu'(z) or dy
+//   dx = a_c dz - rstd/cnt * A - rstd^2/cnt * (x - mean) * Bs,   A = sum_g gamma_c dz,  Bs = rstd * (sum_g gamma_c dz x - mean A)
+//      = a_c dz + k0 + k1 x        with per-group k1 = -rstd^2 Bs / cnt,  k0 = -rstd A / cnt - k1 mean
+// Pass 1 accumulates (A, sum gamma dz x) per (n, group) in fp64; a tiny kernel forms (k0, k1) per (n, c); pass 2 streams.
+__device__ __forceinline__ float silu_grad_f(float z)
+{
+    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * z));
+    return sg * fmaf(z, 1.f - sg, 1.f);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_bwd_stats_ncs(const T* __restrict__ x, const T* __restrict__ dy, const float2* __restrict__ coef,
+                                                          const float* __restrict__ gamma, double* __restrict__ bstats,
+                                                          int C, int G, long long S, int silu, int chunks)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const long long grp = blockIdx.x;            // n * G + g
+    const int cpg = C / G, g = (int)(grp % G);
+    const long long n = grp / G, L = (long long)cpg * S;
+    const T* px = x + grp * L;
+    const T* pg = dy + grp * L;
+    const long long per = ((L + chunks - 1) / chunks + 7) & ~7LL;
+    const long long beg = (long long)blockIdx.y * per, end = (beg + per < L) ? beg + per : L;
+    float sa = 0.f, sb = 0.f;
+    const bool vec = (S & 7) == 0;
+    for (long long i = beg + (long long)threadIdx.x * (vec ? 8 : 1); i < end; i += 256 * (vec ? 8 : 1)) {
+        const int c = g * cpg + (int)(i / S);
+        const float2 ab = coef[n * C + c];
+        const float gm = gamma[c];
+        if (vec) {
+            const vec8 vx = *reinterpret_cast<const vec8*>(px + i), vg = *reinterpret_cast<const vec8*>(pg + i);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xf = to_f(vx[k]);
+                float dz = to_f(vg[k]);
+                if (silu) dz *= silu_grad_f(fmaf(xf, ab.x, ab.y));
+                dz *= gm;
+                sa += dz;
+                sb = fmaf(dz, xf, sb);
+            }
+        } else {
+            const float xf = to_f(px[i]);
+            float dz = to_f(pg[i]);
+            if (silu) dz *= silu_grad_f(fmaf(xf, ab.x, ab.y));
+            dz *= gm;
+            sa += dz;
+            sb = fmaf(dz, xf, sb);
+        }
+    }
+    double da = wave_sum_d((double)sa), db = wave_sum_d((double)sb);
+    __shared__ double sh[8];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[2 * w] = da; sh[2 * w + 1] = db; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&bstats[2 * grp], sh[0] + sh[2] + sh[4] + sh[6]);
+        atomicAdd(&bstats[2 * grp + 1], sh[1] + sh[3] + sh[5] + sh[7]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_bwd_stats_nsc(const T* __restrict__ x, const T* __restrict__ dy, const float2* __restrict__ coef,
+                                                          const float* __restrict__ gamma, double* __restrict__ bstats,
+                                                          int C, int G, long long S, int silu, int rows_per_block)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    extern __shared__ float sh_g[];  // [G][2]
+    const int n = blockIdx.y, cpg = C / G, oct = C / 8;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.f;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
+    const T* bx = x + (long long)n * S * C;
+    const T* bg = dy + (long long)n * S * C;
+    for (int o = threadIdx.x % oct_stride(oct), lane_row = threadIdx.x / oct_stride(oct); o < oct; o += oct_stride(oct)) {
+        float a[8], b[8], s1[8], s2[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float2 ab = coef[(long long)n * C + o * 8 + k]; a[k] = ab.x; b[k] = ab.y; s1[k] = 0.f; s2[k] = 0.f; }
+        const int rstep = 256 / oct_stride(oct);
+        for (long long r = r0 + lane_row; r < r1; r += rstep) {
+            const vec8 vx = *reinterpret_cast<const vec8*>(bx + r * C + o * 8), vg = *reinterpret_cast<const vec8*>(bg + r * C + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xf = to_f(vx[k]);
+                float dz = to_f(vg[k]);
+                if (silu) dz *= silu_grad_f(fmaf(xf, a[k], b[k]));
+                s1[k] += dz;
+                s2[k] = fmaf(dz, xf, s2[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = o * 8 + k;
+            const float gm = gamma[c];
+            atomicAdd(&sh_g[2 * (c / cpg)], gm * s1[k]);
+            atomicAdd(&sh_g[2 * (c / cpg) + 1], gm * s2[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&bstats[(long long)n * 2 * G + i], (double)sh_g[i]);
+}
+
+__global__ void __launch_bounds__(256) k_gn_bwd_coef(const double* __restrict__ stats, const double* __restrict__ bstats,
+                                                     float2* __restrict__ coef2, int N, int C, int G, long long S, float eps)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C, cpg = C / G;
+    const double cnt = (double)cpg * (double)S;
+    const long long grp = (long long)n * G + c / cpg;
+    const double mean = stats[2 * grp] / cnt;
+    const double var = stats[2 * grp + 1] / cnt - mean * mean;
+    const double rstd = (double)rsqrtf((float)(var > 0 ? var : 0) + eps);
+    const double A = bstats[2 * grp], Bs = rstd * (bstats[2 * grp + 1] - mean * A);
+    const double k1 = -rstd * rstd * Bs / cnt;
+    coef2[i] = make_float2((float)(-rstd * A / cnt - k1 * mean), (float)k1);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_bwd_apply_ncs(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                          const float2* __restrict__ coef, const float2* __restrict__ coef2,
+                                                          long long S, int silu, long long total)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const bool vec = (S & 7) == 0;
+    const long long step = (long long)gridDim.x * 256 * (vec ? 8 : 1);
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * (vec ? 8 : 1); i < total; i += step) {
+        const float2 ab = coef[i / S], kk = coef2[i / S];
+        if (vec) {
+            const vec8 vx = *reinterpret_cast<const vec8*>(x + i), vg = *reinterpret_cast<const vec8*>(dy + i);
+            vec8 r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xf = to_f(vx[k]);
+                float dz = to_f(vg[k]);
+                if (silu) dz *= silu_grad_f(fmaf(xf, ab.x, ab.y));
+                r[k] = (T)fmaf(ab.x, dz, fmaf(kk.y, xf, kk.x));
+            }
+            *reinterpret_cast<vec8*>(dx + i) = r;
+        } else {
+            const float xf = to_f(x[i]);
+            float dz = to_f(dy[i]);
+            if (silu) dz *= silu_grad_f(fmaf(xf, ab.x, ab.y));
+            dx[i] = (T)fmaf(ab.x, dz, fmaf(kk.y, xf, kk.x));
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gn_bwd_apply_nsc(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                          const float2* __restrict__ coef, const float2* __restrict__ coef2,
+                                                          int C, long long S, int silu, long long total)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const long long step = (long long)gridDim.x * 256 * 8;
+    const long long SC = S * C;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < total; i += step) {
+        const long long n = i / SC;
+        const int c0 = (int)((i - n * SC) % C);
+        const float4* cf = reinterpret_cast<const float4*>(coef + n * C + c0);
+        const float4* kf = reinterpret_cast<const float4*>(coef2 + n * C + c0);
+        const vec8 vx = *reinterpret_cast<const vec8*>(x + i), vg = *reinterpret_cast<const vec8*>(dy + i);
+        vec8 r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 ab = cf[k], kk = kf[k];
+            const float x0 = to_f(vx[2 * k]), x1 = to_f(vx[2 * k + 1]);
+            float d0 = to_f(vg[2 * k]), d1 = to_f(vg[2 * k + 1]);
+            if (silu) { d0 *= silu_grad_f(fmaf(x0, ab.x, ab.y)); d1 *= silu_grad_f(fmaf(x1, ab.z, ab.w)); }
+            r[2 * k] = (T)fmaf(ab.x, d0, fmaf(kk.y, x0, kk.x));
+            r[2 * k + 1] = (T)fmaf(ab.z, d1, fmaf(kk.w, x1, kk.z));
+        }
+        *reinterpret_cast<vec8*>(dx + i) = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim of [M, C] 16-bit rows (nn.LayerNorm in BasicTransformerBlock, attention.py:283-285).
 // One wave per row, the row lives in registers (<= 4 octets per lane), fp32 two-pass statistics.
 template <typename T>
@@ -570,6 +748,46 @@ int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_*", e);
+    return 0;
+}
+
+int gvd_group_norm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const double* fwd_stats, double* scratch,
+                       int N, int C, long long S, int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !dy || !dx || !gamma || !fwd_stats || !scratch || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return fail(-1, "gvd_group_norm_bwd: bad arguments");
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return fail(-1, "gvd_group_norm_bwd: x / dy / dx must be 16-byte aligned");
+    if (channels_last && (C % 8)) return fail(-1, "gvd_group_norm_bwd: channels-last needs C % 8 == 0");
+    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * G * 2 * sizeof(double), stream);
+    if (e != hipSuccess) return fail(-2, "hipMemsetAsync(scratch)", e);
+    const float2* coef = reinterpret_cast<const float2*>(fwd_stats + (size_t)N * G * 2);
+    float2* coef2 = reinterpret_cast<float2*>(scratch + (size_t)N * G * 2);
+    const int cblocks = (N * C + 255) / 256;
+    const long long total = (long long)N * C * S;
+    const long long vecs = channels_last || (S % 8 == 0) ? total / 8 : total;
+    const int ablocks = (int)((vecs + 255) / 256 < 16384 ? (vecs + 255) / 256 : 16384);
+#define GVD_GN_BWD(T)                                                                                                              \
+    if (!channels_last) {                                                                                                          \
+        const long long L = (long long)(C / G) * S;                                                                                \
+        int chunks = (int)((L + 32767) / 32768);                                                                                   \
+        chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);                                                                   \
+        hipLaunchKernelGGL(k_gn_bwd_stats_ncs<T>, dim3((unsigned)(N * G), (unsigned)chunks), dim3(256), 0, stream, (const T*)x,    \
+                           (const T*)dy, coef, gamma, scratch, C, G, S, silu, chunks);                                             \
+        hipLaunchKernelGGL(k_gn_bwd_coef, dim3(cblocks), dim3(256), 0, stream, fwd_stats, (const double*)scratch, coef2, N, C, G, S, eps); \
+        hipLaunchKernelGGL(k_gn_bwd_apply_ncs<T>, dim3(ablocks), dim3(256), 0, stream, (const T*)x, (const T*)dy, (T*)dx, coef,    \
+                           (const float2*)coef2, S, silu, total);                                                                  \
+    } else {                                                                                                                       \
+        const int rows = 128;                                                                                                      \
+        hipLaunchKernelGGL(k_gn_bwd_stats_nsc<T>, dim3((unsigned)((S + rows - 1) / rows), (unsigned)N), dim3(256), (size_t)G * 8,  \
+                           stream, (const T*)x, (const T*)dy, coef, gamma, scratch, C, G, S, silu, rows);                          \
+        hipLaunchKernelGGL(k_gn_bwd_coef, dim3(cblocks), dim3(256), 0, stream, fwd_stats, (const double*)scratch, coef2, N, C, G, S, eps); \
+        hipLaunchKernelGGL(k_gn_bwd_apply_nsc<T>, dim3(ablocks), dim3(256), 0, stream, (const T*)x, (const T*)dy, (T*)dx, coef,    \
+                           (const float2*)coef2, C, S, silu, total);                                                               \
+    }
+    if (is_bf16) { GVD_GN_BWD(__bf16) } else { GVD_GN_BWD(_Float16) }
+#undef GVD_GN_BWD
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_gn_bwd_*", e);
     return 0;
 }
 

@@ -162,7 +162,7 @@ def group_norm_math(x, groups, weight, bias, eps=1e-5, silu=False, channels_last
     return y.movedim(1, -1).contiguous() if channels_last else y
 
 
-def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last):
+def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=False):
     x = x.contiguous()
     N = x.shape[0]
     C = x.shape[-1] if channels_last else x.shape[1]
@@ -177,27 +177,42 @@ def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last):
                                   groups, ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)),
                                   1 if x.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
     _check(rc)
-    return y
+    return (y, x, g, stats) if keep else y
+
+
+def _hip_group_norm_bwd(x, gy, gamma32, stats, groups, eps, silu, channels_last):
+    gy = gy.contiguous()
+    N = x.shape[0]
+    C = x.shape[-1] if channels_last else x.shape[1]
+    S = x.numel() // (N * C)
+    gx = torch.empty_like(x)
+    scratch = torch.empty(2 * N * groups + N * C, dtype=torch.float64, device=x.device)
+    P = ctypes.c_void_p
+    with torch.cuda.device(x.device):
+        rc = lib().gvd_group_norm_bwd(P(x.data_ptr()), P(gy.data_ptr()), P(gx.data_ptr()), P(gamma32.data_ptr()),
+                                      P(stats.data_ptr()), P(scratch.data_ptr()), N, C, ctypes.c_longlong(S), groups,
+                                      ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)),
+                                      1 if x.dtype == torch.bfloat16 else 0, P(_stream()))
+    _check(rc)
+    return gx
 
 
 class _GroupNormFn(torch.autograd.Function):
-    """Forward: the fused HIP kernel.  Backward (guided sampler only): autograd through the eager form."""
+    """Fused GroupNorm(+SiLU) kernels, forward and input-gradient.  Weight gradients are not produced: the only
+    autograd user is the guided sampler, which differentiates w.r.t. x_t with frozen weights."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, groups, eps, silu, channels_last):
-        ctx.save_for_backward(x, weight, bias)
+        y, xc, g32, stats = _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=True)
+        ctx.save_for_backward(xc, g32, stats)
         ctx.cfg = (groups, eps, silu, channels_last)
-        return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, bias = ctx.saved_tensors
+        x, g32, stats = ctx.saved_tensors
         groups, eps, silu, cl = ctx.cfg
-        with torch.enable_grad():
-            x_ = x.detach().requires_grad_(True)
-            y = group_norm_math(x_, groups, weight.detach(), bias.detach(), eps, silu, cl)
-            (gx,) = torch.autograd.grad(y, x_, gy)
-        return gx, None, None, None, None, None, None
+        return _hip_group_norm_bwd(x, gy, g32, stats, groups, eps, silu, cl), None, None, None, None, None, None
 
 
 def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False):
@@ -207,6 +222,8 @@ def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=Fals
     if (on_dev and x.dtype in (torch.float16, torch.bfloat16) and weight is not None and bias is not None
             and (not channels_last or C % 8 == 0)):
         if torch.is_grad_enabled() and x.requires_grad:
+            if weight.requires_grad or bias.requires_grad:
+                raise RuntimeError("lvdm_amd.ops.group_norm: only the input gradient is implemented (freeze the weights)")
             return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last)
         return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last)
     return group_norm_math(x, groups, weight, bias, eps, silu, channels_last)

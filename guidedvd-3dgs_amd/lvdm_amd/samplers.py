@@ -153,6 +153,15 @@ class DDIMSamplerGuidance(DDIMSampler):
     def _grad_ctx(self):
         return torch.enable_grad()
 
+    def _freeze_weights(self):
+        if getattr(self, "_frozen", False):
+            return
+        for name in ("model", "first_stage_model"):
+            mod = getattr(self.model, name, None)
+            if isinstance(mod, torch.nn.Module):
+                mod.requires_grad_(False)
+        self._frozen = True
+
     def p_sample_ddim(self, x, c, t, index, temperature=1., unconditional_guidance_scale=1.,
                       unconditional_conditioning=None, guidance_rescale=0.0, noise=None, renoise=None, **kwargs):
         loss_guidance_fn = kwargs.get("loss_guidance_fn")
@@ -167,9 +176,10 @@ class DDIMSamplerGuidance(DDIMSampler):
         w = 1.0
         if getattr(loss_guidance_fn, "scale_guidance_weight", False):
             w = loss_guidance_fn.guidance_weight_fn(loss_guidance_fn.current_train_iter)
-        # The reference flips requires_grad on all U-Net / VAE weights here (ddim_guidance.py:259-260) although
-        # only d/dx is ever requested (inputs=x prunes weight gradients); leaving the weights frozen gives the
-        # same x-gradient without retaining weight-gradient state.
+        # The reference flips requires_grad ON for all U-Net / VAE weights here (ddim_guidance.py:259-260) although
+        # only d/dx is ever requested (inputs=x prunes weight gradients).  We freeze them instead: same x-gradient,
+        # no weight-gradient state, and the fused norm kernels only implement the input gradient.
+        self._freeze_weights()
         beta_t = k["a_t"] / k["a_prev"]
         s = float(unconditional_guidance_scale)
         for _ in range(repeat):

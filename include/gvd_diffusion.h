@@ -66,6 +66,13 @@ int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, co
 int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta, double* stats,
                    int N, int C, long long S, int G, float eps, int silu, int channels_last, int is_bf16, void* stream);
 
+/* GroupNorm (+SiLU) backward w.r.t. the input (the guided sampler differentiates pred_x0 w.r.t. x_t only; weights are
+ * frozen -- ddim_guidance.py:318-345 requests inputs=x).  x, dy, dx share the forward's layout; fwd_stats is the scratch
+ * buffer gvd_group_norm filled for the same x (group sums + per-(n,c) affine); scratch: 16*N*G + 8*N*C bytes. */
+int gvd_group_norm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const double* fwd_stats,
+                       double* scratch, int N, int C, long long S, int G, float eps, int silu, int channels_last,
+                       int is_bf16, void* stream);
+
 /* LayerNorm over the last dim of [M, C] 16-bit rows, fp32 statistics, gamma/beta in the same 16-bit type as x.
  * Replaces nn.LayerNorm in BasicTransformerBlock (lvdm/modules/attention.py:283-285).  C % 8 == 0, C <= 2048. */
 int gvd_layer_norm(const void* x, void* y, const void* gamma, const void* beta, long long M, int C, float eps,

@@ -262,3 +262,27 @@ def test_mfma_attention_backward_matches_explicit_softmax_gradients(dtype, B, H,
         # (a single key makes dQ = dK = 0 exactly: keep the denominator at the O(1) scale of the inputs)
         err = float((a.float() - b).abs().max()) / max(float(b.abs().max()), 1.0)
         assert err < tol, (name, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,cl", [((3, 320, 40, 56), False), ((2, 64, 5, 7), False), ((1, 128, 37, 41), False),
+                                      ((1, 25, 192, 320), True), ((2, 7, 35, 1280), True), ((1, 4, 600, 64), True)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm_backward_kernel_matches_fp32_autograd(dtype, shape, cl, silu):
+    """dx of the fused GroupNorm(+SiLU) vs autograd through fp32 F.group_norm/F.silu on the same 16-bit inputs.
+    Tolerance: one rounding of the 16-bit output type relative to the largest gradient entry, plus the fp16 rounding
+    of the recomputed z inside silu'."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(sum(shape) + 1)
+    x = (torch.randn(shape, device=DEV, generator=g) * 1.7 + 0.4).to(dtype).requires_grad_(True)
+    C = shape[-1] if cl else shape[1]
+    w = (torch.randn(C, device=DEV, generator=g) * 0.3 + 1).to(dtype)
+    b = (torch.randn(C, device=DEV, generator=g) * 0.2).to(dtype)
+    y = ops.group_norm(x, 32, w, b, 1e-5, silu=silu, channels_last=cl)
+    gy = torch.randn(y.shape, device=DEV, generator=g).to(dtype)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    xf = x.detach().float().requires_grad_(True)
+    (rx,) = torch.autograd.grad(ops.group_norm_math(xf, 32, w.float(), b.float(), 1e-5, silu=silu, channels_last=cl), xf, gy.float())
+    assert gx.dtype == dtype and gx.shape == x.shape
+    err = float((gx.float() - rx).abs().max()) / float(rx.abs().max())
+    assert err < (4e-3 if dtype == torch.float16 else 2.5e-2), err
