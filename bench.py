@@ -348,7 +348,43 @@ def ddim_main(args):
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
     }
+    if not args.no_cpu_baseline and unet_tflop:
+        line["cpu_baseline"] = ddim_cpu_leg(unet, T, unet_tflop, guided)
     print(json.dumps(line), flush=True)
+
+
+def ddim_cpu_leg(unet, T, unet_tflop, guided):
+    """SURVEY 8(d) CPU baseline for the diffusion path: the same U-Net (same weights), explicit reference math
+    (einsum-style attention, F.group_norm, Conv3d ...) in PyTorch-CPU fp32 on the host cores, ONE forward at a reduced
+    latent size, extrapolated to the benchmarked configuration by counted FLOPs.  A port, not the target."""
+    import copy
+    import torch
+    from torch.utils.flop_counter import FlopCounterMode
+    from lvdm_amd import ops
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cpu_net = copy.deepcopy(unet).float().cpu()
+    hs, ws = 16, 24
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 8, T, hs, ws, generator=g)
+    ctx = torch.randn(1, 333, 1024, generator=g)
+    t = torch.full((1,), 500, dtype=torch.long)
+    fs = torch.tensor([10])
+    ops.use_reference_math(True)
+    try:
+        with torch.no_grad():
+            with FlopCounterMode(display=False) as fc:
+                t0 = time.perf_counter()
+                cpu_net(x, t, context=ctx, fs=fs)
+                el = time.perf_counter() - t0
+    finally:
+        ops.use_reference_math(False)
+    tf_small = fc.get_total_flops() / 1e12
+    tfps = tf_small / el
+    fwd_equiv = 2.0 if not guided else 4.0  # guided: 2 fwd + 2 dgrad (VAE part not included in this estimate)
+    return dict(value=round(tfps / (fwd_equiv * unet_tflop), 6), unit="steps/s", cores=ncores, kind="port",
+                sample=f"one fp32 U-Net forward, T={T}, latent {hs}x{ws}, 333 context tokens: {tf_small:.3f} TFLOP in {el:.1f} s "
+                       f"= {tfps:.3f} TFLOP/s on {ncores} threads; value = that rate / ({fwd_equiv:.0f} x {unet_tflop} TFLOP per step)")
 
 
 def cpu_leg(sc, args, np):

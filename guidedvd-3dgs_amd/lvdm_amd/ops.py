@@ -23,7 +23,7 @@ _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_diffusion.so")
 
 
 def use_reference_math(flag):
-    """TESTS ONLY: allow CPU tensors through plain torch math (never enabled by the product)."""
+    """Tests and bench.py's cpu_baseline leg ONLY: allow CPU tensors through plain torch math (never enabled by the product)."""
     global _REFERENCE_MATH
     _REFERENCE_MATH = bool(flag)
 
