@@ -215,9 +215,17 @@ def ddim_main(args):
     One step = one DDIM step.  Single GPU in this round (frame/CFG sharding is a later round)."""
     import numpy as np
     import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available()
-    dev = torch.device("cuda", 0)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    if world > 1:  # CFG pair x frame shards, one rank per GPU over RCCL (lvdm_amd/parallel.py)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
     torch.backends.cudnn.benchmark = os.environ.get("GVD_CONV_FIND", "1") == "1"  # let MIOpen time its NHWC solvers once per shape
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from lvdm_amd import ops
@@ -276,6 +284,10 @@ def ddim_main(args):
     uc = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g).half()], "c_concat": cond["c_concat"]}
     sampler = DDIMSamplerGuidance(ld) if guided else DDIMSampler(ld)
     sampler.make_schedule(50, "uniform_trailing", 1.0)
+    plan = None
+    if world > 1:
+        from lvdm_amd.parallel import ParallelPlan
+        plan = sampler.parallel = ParallelPlan(T)
     lg = None
     if guided:
         lg = LossGuidance(ddim_steps=50, recur_steps=1, device=str(dev))
@@ -299,9 +311,13 @@ def ddim_main(args):
                                           unconditional_conditioning=uc, guidance_rescale=0.7, fs=fs)
         return xp
 
+    torch.manual_seed(123)  # every rank draws the same per-step noise (the update is replicated)
     for i in range(warm):
         x = one(i, x)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     # attention kernel time inside the timed region (HIP events on torch's current stream = the launch stream)
     ev = []
     orig = ops._hip_attention_fwd
@@ -320,17 +336,28 @@ def ddim_main(args):
     for i in range(steps):
         x = one(warm + i, x)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops._hip_attention_fwd = orig
     assert torch.isfinite(x).all()
+    if world > 1:  # max over ranks
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        if rank != 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
     att_ms = sum(a.elapsed_time(b) for a, b, *_ in ev)
     att_flops = sum(4.0 * bh * nq * nk * 64 for _, _, bh, nq, nk in ev)
     MFMA_PEAK = 2500.0  # TFLOP/s dense f16/bf16 (MI355X_MICROARCH.md)
     unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
     line = {
-        "metric": "viewcrafter_guided_ddim_steps_per_s" if guided else "viewcrafter_ddim_steps_per_s", "value": round(steps / elapsed, 4), "unit": "steps/s", "n_gpus": 1,
+        "metric": "viewcrafter_guided_ddim_steps_per_s" if guided else "viewcrafter_ddim_steps_per_s", "value": round(steps / elapsed, 4), "unit": "steps/s", "n_gpus": world,
         "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / steps, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": (round((steps / elapsed) / 0.42, 3) if (args.ddim_height, args.ddim_width, T) == (576, 1024, 25) and not guided else None),
+        "scaling": "weak" if world == 1 else "strong", "vs_baseline": (round((steps / elapsed) / 0.42, 3) if (args.ddim_height, args.ddim_width, T) == (576, 1024, 25) and not guided else None),
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": (f"ViewCrafter {T}-frame {args.ddim_height}x{args.ddim_width} GUIDED DDIM step (ddim_guidance.py:205-363): "
                                 "2 U-Net fwd + dgrad w.r.t. x_t through both, 25 x (VAE decode fwd + dgrad), masked-L2 guidance, CFG 7.5, "
@@ -338,6 +365,7 @@ def ddim_main(args):
                                (f"BASELINE configs[2]: ViewCrafter {T}-frame {args.ddim_height}x{args.ddim_width} DDIM, unguided, CFG 7.5, "
                                 "rescale 0.7, eta 1 (2 U-Net fwd / step), random-init U-Net 1.44 B params"),
                    "latent": [1, 4, T, h, w], "context_tokens": 333, "unet_tflop_per_fwd": unet_tflop,
+                   "parallelism": "single GPU" if plan is None else f"cfg{plan.cfg} x frames{plan.F} (frame counts {plan.shard.counts})",
                    "baseline_note": "vs_baseline = steps/s over the ViewCrafter README A100 figure 0.42 steps/s (120 s / 50 steps, "
                                     "whole pipeline incl. VAE/CLIP; third_party/ViewCrafter/README.md:116-118)"},
         "roofline": {"bound": "mfma", "kernel": "k_attn_fwd (all spatial/cross/temporal attention launches)",
@@ -348,9 +376,12 @@ def ddim_main(args):
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
     }
-    if not args.no_cpu_baseline and unet_tflop:
+    if not args.no_cpu_baseline and unet_tflop and world == 1:
         line["cpu_baseline"] = ddim_cpu_leg(unet, T, unet_tflop, guided)
     print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def ddim_cpu_leg(unet, T, unet_tflop, guided):
@@ -361,10 +392,10 @@ def ddim_cpu_leg(unet, T, unet_tflop, guided):
     import torch
     from torch.utils.flop_counter import FlopCounterMode
     from lvdm_amd import ops
-    ncores = os.cpu_count() or 1
+    ncores = min(os.cpu_count() or 1, 32)  # small-operator graph: more threads than this only adds fork/join overhead
     torch.set_num_threads(ncores)
     cpu_net = copy.deepcopy(unet).float().cpu()
-    hs, ws = 16, 24
+    hs, ws = 8, 16
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 8, T, hs, ws, generator=g)
     ctx = torch.randn(1, 333, 1024, generator=g)

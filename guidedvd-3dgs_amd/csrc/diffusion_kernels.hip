@@ -705,90 +705,134 @@ int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, co
 }
 
 
-int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta, double* stats, int N, int C, long long S,
-                   int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
+namespace {
+int gn_check(const char* who, const void* a, const void* b, int N, int C, long long S, int G, int channels_last)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!x || !y || !gamma || !beta || !stats || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return fail(-1, "gvd_group_norm: bad arguments");
-    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(-1, "gvd_group_norm: x / y must be 16-byte aligned");
-    if (channels_last && (C % 8)) return fail(-1, "gvd_group_norm: channels-last needs C % 8 == 0");
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(double), stream);
-    if (e != hipSuccess) return fail(-2, "hipMemsetAsync(stats)", e);
-    float2* coef = reinterpret_cast<float2*>(stats + (size_t)N * G * 2);
-    const int cblocks = (N * C + 255) / 256;
+    char msg[160];
+    if (!a || !b || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) { snprintf(msg, sizeof msg, "%s: bad arguments", who); return fail(-1, msg); }
+    if (((uintptr_t)a | (uintptr_t)b) & 15) { snprintf(msg, sizeof msg, "%s: tensors must be 16-byte aligned", who); return fail(-1, msg); }
+    if (channels_last && (C % 8)) { snprintf(msg, sizeof msg, "%s: channels-last needs C %% 8 == 0", who); return fail(-1, msg); }
+    return 0;
+}
+int gn_apply_blocks(int N, int C, long long S, int channels_last)
+{
     const long long total = (long long)N * C * S;
     const long long vecs = channels_last || (S % 8 == 0) ? total / 8 : total;
-    const int ablocks = (int)((vecs + 255) / 256 < 16384 ? (vecs + 255) / 256 : 16384);
+    return (int)((vecs + 255) / 256 < 16384 ? (vecs + 255) / 256 : 16384);
+}
+int gn_chunks(int C, int G, long long S)
+{
+    const long long L = (long long)(C / G) * S;
+    const int chunks = (int)((L + 32767) / 32768);
+    return chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+}
+}  // namespace
+
+int gvd_group_norm_stats(const void* x, double* stats, int N, int C, long long S, int G, int channels_last, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = gn_check("gvd_group_norm_stats", x, stats, N, C, S, G, channels_last)) return rc;
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(double), stream);
+    if (e != hipSuccess) return fail(-2, "hipMemsetAsync(stats)", e);
     if (!channels_last) {
         const long long L = (long long)(C / G) * S;
-        int chunks = (int)((L + 32767) / 32768);
-        chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+        const int chunks = gn_chunks(C, G, S);
         dim3 grid((unsigned)(N * G), (unsigned)chunks);
-        if (is_bf16) {
-            hipLaunchKernelGGL(k_gn_stats_ncs<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, stats, L, chunks);
-            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
-            hipLaunchKernelGGL(k_gn_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, S, silu, total);
-        } else {
-            hipLaunchKernelGGL(k_gn_stats_ncs<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, stats, L, chunks);
-            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
-            hipLaunchKernelGGL(k_gn_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, S, silu, total);
-        }
+        if (is_bf16) hipLaunchKernelGGL(k_gn_stats_ncs<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, stats, L, chunks);
+        else hipLaunchKernelGGL(k_gn_stats_ncs<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, stats, L, chunks);
     } else {
         const int rows = 128;
         dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
-        if (is_bf16) {
-            hipLaunchKernelGGL(k_gn_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, stats, C, G, S, rows);
-            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
-            hipLaunchKernelGGL(k_gn_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, C, S, silu, total);
-        } else {
-            hipLaunchKernelGGL(k_gn_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, stats, C, G, S, rows);
-            hipLaunchKernelGGL(k_gn_coef, dim3(cblocks), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S, eps);
-            hipLaunchKernelGGL(k_gn_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, C, S, silu, total);
-        }
+        if (is_bf16) hipLaunchKernelGGL(k_gn_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, stats, C, G, S, rows);
+        else hipLaunchKernelGGL(k_gn_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, stats, C, G, S, rows);
     }
     e = hipGetLastError();
-    if (e != hipSuccess) return fail(-2, "launch k_gn_*", e);
+    if (e != hipSuccess) return fail(-2, "launch k_gn_stats_*", e);
+    return 0;
+}
+
+int gvd_group_norm_apply(const void* x, void* y, const float* gamma, const float* beta, double* stats, int N, int C, long long S,
+                         long long S_total, int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = gn_check("gvd_group_norm_apply", x, y, N, C, S, G, channels_last)) return rc;
+    if (!gamma || !beta || !stats || S_total < S) return fail(-1, "gvd_group_norm_apply: bad arguments");
+    float2* coef = reinterpret_cast<float2*>(stats + (size_t)N * G * 2);
+    const long long total = (long long)N * C * S;
+    const int ablocks = gn_apply_blocks(N, C, S, channels_last);
+    hipLaunchKernelGGL(k_gn_coef, dim3((N * C + 255) / 256), dim3(256), 0, stream, stats, gamma, beta, coef, N, C, G, S_total, eps);
+    if (!channels_last) {
+        if (is_bf16) hipLaunchKernelGGL(k_gn_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, S, silu, total);
+        else hipLaunchKernelGGL(k_gn_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, S, silu, total);
+    } else {
+        if (is_bf16) hipLaunchKernelGGL(k_gn_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, C, S, silu, total);
+        else hipLaunchKernelGGL(k_gn_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, C, S, silu, total);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_gn_apply_*", e);
+    return 0;
+}
+
+int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta, double* stats, int N, int C, long long S,
+                   int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
+{
+    if (int rc = gvd_group_norm_stats(x, stats, N, C, S, G, channels_last, is_bf16, stream_)) return rc;
+    return gvd_group_norm_apply(x, y, gamma, beta, stats, N, C, S, S, G, eps, silu, channels_last, is_bf16, stream_);
+}
+
+int gvd_group_norm_bwd_stats(const void* x, const void* dy, const float* gamma, const double* fwd_stats, double* scratch,
+                             int N, int C, long long S, int G, int silu, int channels_last, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = gn_check("gvd_group_norm_bwd_stats", x, dy, N, C, S, G, channels_last)) return rc;
+    if (!gamma || !fwd_stats || !scratch) return fail(-1, "gvd_group_norm_bwd_stats: bad arguments");
+    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * G * 2 * sizeof(double), stream);
+    if (e != hipSuccess) return fail(-2, "hipMemsetAsync(scratch)", e);
+    const float2* coef = reinterpret_cast<const float2*>(fwd_stats + (size_t)N * G * 2);
+    if (!channels_last) {
+        const int chunks = gn_chunks(C, G, S);
+        dim3 grid((unsigned)(N * G), (unsigned)chunks);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_stats_ncs<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, coef, gamma, scratch, C, G, S, silu, chunks);
+        else hipLaunchKernelGGL(k_gn_bwd_stats_ncs<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, coef, gamma, scratch, C, G, S, silu, chunks);
+    } else {
+        const int rows = 128;
+        dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, (const __bf16*)dy, coef, gamma, scratch, C, G, S, silu, rows);
+        else hipLaunchKernelGGL(k_gn_bwd_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, (const _Float16*)dy, coef, gamma, scratch, C, G, S, silu, rows);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_gn_bwd_stats_*", e);
+    return 0;
+}
+
+int gvd_group_norm_bwd_apply(const void* x, const void* dy, void* dx, const double* fwd_stats, double* scratch, int N, int C,
+                             long long S, long long S_total, int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = gn_check("gvd_group_norm_bwd_apply", x, dy, N, C, S, G, channels_last)) return rc;
+    if (!dx || ((uintptr_t)dx & 15) || !fwd_stats || !scratch || S_total < S) return fail(-1, "gvd_group_norm_bwd_apply: bad arguments");
+    const float2* coef = reinterpret_cast<const float2*>(fwd_stats + (size_t)N * G * 2);
+    float2* coef2 = reinterpret_cast<float2*>(scratch + (size_t)N * G * 2);
+    const long long total = (long long)N * C * S;
+    const int ablocks = gn_apply_blocks(N, C, S, channels_last);
+    hipLaunchKernelGGL(k_gn_bwd_coef, dim3((N * C + 255) / 256), dim3(256), 0, stream, fwd_stats, (const double*)scratch, coef2, N, C, G, S_total, eps);
+    if (!channels_last) {
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, coef, (const float2*)coef2, S, silu, total);
+        else hipLaunchKernelGGL(k_gn_bwd_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)dx, coef, (const float2*)coef2, S, silu, total);
+    } else {
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, coef, (const float2*)coef2, C, S, silu, total);
+        else hipLaunchKernelGGL(k_gn_bwd_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)dx, coef, (const float2*)coef2, C, S, silu, total);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_gn_bwd_apply_*", e);
     return 0;
 }
 
 int gvd_group_norm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const double* fwd_stats, double* scratch,
                        int N, int C, long long S, int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!x || !dy || !dx || !gamma || !fwd_stats || !scratch || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return fail(-1, "gvd_group_norm_bwd: bad arguments");
-    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return fail(-1, "gvd_group_norm_bwd: x / dy / dx must be 16-byte aligned");
-    if (channels_last && (C % 8)) return fail(-1, "gvd_group_norm_bwd: channels-last needs C % 8 == 0");
-    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * G * 2 * sizeof(double), stream);
-    if (e != hipSuccess) return fail(-2, "hipMemsetAsync(scratch)", e);
-    const float2* coef = reinterpret_cast<const float2*>(fwd_stats + (size_t)N * G * 2);
-    float2* coef2 = reinterpret_cast<float2*>(scratch + (size_t)N * G * 2);
-    const int cblocks = (N * C + 255) / 256;
-    const long long total = (long long)N * C * S;
-    const long long vecs = channels_last || (S % 8 == 0) ? total / 8 : total;
-    const int ablocks = (int)((vecs + 255) / 256 < 16384 ? (vecs + 255) / 256 : 16384);
-#define GVD_GN_BWD(T)                                                                                                              \
-    if (!channels_last) {                                                                                                          \
-        const long long L = (long long)(C / G) * S;                                                                                \
-        int chunks = (int)((L + 32767) / 32768);                                                                                   \
-        chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);                                                                   \
-        hipLaunchKernelGGL(k_gn_bwd_stats_ncs<T>, dim3((unsigned)(N * G), (unsigned)chunks), dim3(256), 0, stream, (const T*)x,    \
-                           (const T*)dy, coef, gamma, scratch, C, G, S, silu, chunks);                                             \
-        hipLaunchKernelGGL(k_gn_bwd_coef, dim3(cblocks), dim3(256), 0, stream, fwd_stats, (const double*)scratch, coef2, N, C, G, S, eps); \
-        hipLaunchKernelGGL(k_gn_bwd_apply_ncs<T>, dim3(ablocks), dim3(256), 0, stream, (const T*)x, (const T*)dy, (T*)dx, coef,    \
-                           (const float2*)coef2, S, silu, total);                                                                  \
-    } else {                                                                                                                       \
-        const int rows = 128;                                                                                                      \
-        hipLaunchKernelGGL(k_gn_bwd_stats_nsc<T>, dim3((unsigned)((S + rows - 1) / rows), (unsigned)N), dim3(256), (size_t)G * 8,  \
-                           stream, (const T*)x, (const T*)dy, coef, gamma, scratch, C, G, S, silu, rows);                          \
-        hipLaunchKernelGGL(k_gn_bwd_coef, dim3(cblocks), dim3(256), 0, stream, fwd_stats, (const double*)scratch, coef2, N, C, G, S, eps); \
-        hipLaunchKernelGGL(k_gn_bwd_apply_nsc<T>, dim3(ablocks), dim3(256), 0, stream, (const T*)x, (const T*)dy, (T*)dx, coef,    \
-                           (const float2*)coef2, C, S, silu, total);                                                               \
-    }
-    if (is_bf16) { GVD_GN_BWD(__bf16) } else { GVD_GN_BWD(_Float16) }
-#undef GVD_GN_BWD
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(-2, "launch k_gn_bwd_*", e);
-    return 0;
+    if (int rc = gvd_group_norm_bwd_stats(x, dy, gamma, fwd_stats, scratch, N, C, S, G, silu, channels_last, is_bf16, stream_)) return rc;
+    return gvd_group_norm_bwd_apply(x, dy, dx, fwd_stats, scratch, N, C, S, S, G, eps, silu, channels_last, is_bf16, stream_);
 }
 
 int gvd_layer_norm(const void* x, void* y, const void* gamma, const void* beta, long long M, int C, float eps, int is_bf16,

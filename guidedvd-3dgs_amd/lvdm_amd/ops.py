@@ -148,51 +148,98 @@ def attention(q, k, v, heads, frame_major=False):
 
 
 # --------------------------------------------------------------------------------------------------
-def group_norm_math(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False):
-    """Eager form: statistics and affine in fp32 (GroupNormSpecific, lvdm/basics.py:76-86), result cast back."""
-    if channels_last:  # [N, ..., C] -> [N, C, ...]
-        xc = x.movedim(-1, 1)
+def group_norm_math(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False, group=None):
+    """Eager form: statistics and affine in fp32 (GroupNormSpecific, lvdm/basics.py:76-86), result cast back.
+    `group`: process group whose ranks each hold a slice of every (sample, group)'s elements -- statistics are
+    summed across it (differentiably), see parallel.py."""
+    xc = x.movedim(-1, 1) if channels_last else x   # [N, ..., C] -> [N, C, ...]
+    if group is None:
+        y = F.group_norm(xc.float(), groups, None if weight is None else weight.float(),
+                         None if bias is None else bias.float(), eps)
     else:
-        xc = x
-    y = F.group_norm(xc.float(), groups, None if weight is None else weight.float(),
-                     None if bias is None else bias.float(), eps)
+        import torch.distributed.nn.functional as dist_fn
+        N, C = xc.shape[0], xc.shape[1]
+        xg = xc.float().reshape(N, groups, -1)
+        part = torch.stack([xg.sum(-1), (xg * xg).sum(-1), torch.full((N, groups), float(xg.shape[-1]), device=x.device)])
+        s1, s2, cnt = dist_fn.all_reduce(part, group=group)
+        mean = s1 / cnt
+        rstd = torch.rsqrt((s2 / cnt - mean * mean).clamp_min(0) + eps)
+        y = ((xg - mean[..., None]) * rstd[..., None]).reshape(xc.shape)
+        shp = (1, C) + (1,) * (xc.dim() - 2)
+        if weight is not None:
+            y = y * weight.float().reshape(shp)
+        if bias is not None:
+            y = y + bias.float().reshape(shp)
     if silu:
         y = F.silu(y)
     y = y.to(x.dtype)
     return y.movedim(1, -1).contiguous() if channels_last else y
 
 
-def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=False):
-    x = x.contiguous()
+def _gn_dims(x, channels_last):
     N = x.shape[0]
     C = x.shape[-1] if channels_last else x.shape[1]
-    S = x.numel() // (N * C)
+    return N, C, x.numel() // (N * C)
+
+
+def _global_count(S, group, device):
+    """Elements per (sample, channel) over the whole shard group."""
+    import torch.distributed as dist
+    t = torch.tensor([S], dtype=torch.int64, device=device)
+    dist.all_reduce(t, group=group)
+    return int(t.item())
+
+
+def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=False, group=None, S_total=None):
+    x = x.contiguous()
+    N, C, S = _gn_dims(x, channels_last)
     y = torch.empty_like(x)
     stats = torch.empty(2 * N * groups + N * C, dtype=torch.float64, device=x.device)  # group sums + (a, b) per (n, c)
     g = weight.float().contiguous()
     b = bias.float().contiguous()
+    P, LL = ctypes.c_void_p, ctypes.c_longlong
+    bf = 1 if x.dtype == torch.bfloat16 else 0
     with torch.cuda.device(x.device):
-        rc = lib().gvd_group_norm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(g.data_ptr()),
-                                  ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(stats.data_ptr()), N, C, ctypes.c_longlong(S),
-                                  groups, ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)),
-                                  1 if x.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
+        if group is None:
+            rc = lib().gvd_group_norm(P(x.data_ptr()), P(y.data_ptr()), P(g.data_ptr()), P(b.data_ptr()), P(stats.data_ptr()),
+                                      N, C, LL(S), groups, ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)), bf,
+                                      P(_stream()))
+            S_total = S
+        else:
+            import torch.distributed as dist
+            _check(lib().gvd_group_norm_stats(P(x.data_ptr()), P(stats.data_ptr()), N, C, LL(S), groups,
+                                              int(bool(channels_last)), bf, P(_stream())))
+            dist.all_reduce(stats[:2 * N * groups], group=group)
+            if S_total is None:
+                S_total = _global_count(S, group, x.device)
+            rc = lib().gvd_group_norm_apply(P(x.data_ptr()), P(y.data_ptr()), P(g.data_ptr()), P(b.data_ptr()),
+                                            P(stats.data_ptr()), N, C, LL(S), LL(S_total), groups, ctypes.c_float(eps),
+                                            int(bool(silu)), int(bool(channels_last)), bf, P(_stream()))
     _check(rc)
-    return (y, x, g, stats) if keep else y
+    return (y, x, g, stats, S_total) if keep else y
 
 
-def _hip_group_norm_bwd(x, gy, gamma32, stats, groups, eps, silu, channels_last):
+def _hip_group_norm_bwd(x, gy, gamma32, stats, groups, eps, silu, channels_last, group=None, S_total=None):
     gy = gy.contiguous()
-    N = x.shape[0]
-    C = x.shape[-1] if channels_last else x.shape[1]
-    S = x.numel() // (N * C)
+    N, C, S = _gn_dims(x, channels_last)
     gx = torch.empty_like(x)
     scratch = torch.empty(2 * N * groups + N * C, dtype=torch.float64, device=x.device)
-    P = ctypes.c_void_p
+    P, LL = ctypes.c_void_p, ctypes.c_longlong
+    bf = 1 if x.dtype == torch.bfloat16 else 0
     with torch.cuda.device(x.device):
-        rc = lib().gvd_group_norm_bwd(P(x.data_ptr()), P(gy.data_ptr()), P(gx.data_ptr()), P(gamma32.data_ptr()),
-                                      P(stats.data_ptr()), P(scratch.data_ptr()), N, C, ctypes.c_longlong(S), groups,
-                                      ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)),
-                                      1 if x.dtype == torch.bfloat16 else 0, P(_stream()))
+        if group is None:
+            rc = lib().gvd_group_norm_bwd(P(x.data_ptr()), P(gy.data_ptr()), P(gx.data_ptr()), P(gamma32.data_ptr()),
+                                          P(stats.data_ptr()), P(scratch.data_ptr()), N, C, LL(S), groups,
+                                          ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)), bf, P(_stream()))
+        else:
+            import torch.distributed as dist
+            _check(lib().gvd_group_norm_bwd_stats(P(x.data_ptr()), P(gy.data_ptr()), P(gamma32.data_ptr()), P(stats.data_ptr()),
+                                                  P(scratch.data_ptr()), N, C, LL(S), groups, int(bool(silu)),
+                                                  int(bool(channels_last)), bf, P(_stream())))
+            dist.all_reduce(scratch[:2 * N * groups], group=group)
+            rc = lib().gvd_group_norm_bwd_apply(P(x.data_ptr()), P(gy.data_ptr()), P(gx.data_ptr()), P(stats.data_ptr()),
+                                                P(scratch.data_ptr()), N, C, LL(S), LL(S_total), groups, ctypes.c_float(eps),
+                                                int(bool(silu)), int(bool(channels_last)), bf, P(_stream()))
     _check(rc)
     return gx
 
@@ -202,21 +249,24 @@ class _GroupNormFn(torch.autograd.Function):
     autograd user is the guided sampler, which differentiates w.r.t. x_t with frozen weights."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, silu, channels_last):
-        y, xc, g32, stats = _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=True)
+    def forward(ctx, x, weight, bias, groups, eps, silu, channels_last, group, S_total):
+        y, xc, g32, stats, S_total = _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=True,
+                                                     group=group, S_total=S_total)
         ctx.save_for_backward(xc, g32, stats)
-        ctx.cfg = (groups, eps, silu, channels_last)
+        ctx.cfg = (groups, eps, silu, channels_last, group, S_total)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, g32, stats = ctx.saved_tensors
-        groups, eps, silu, cl = ctx.cfg
-        return _hip_group_norm_bwd(x, gy, g32, stats, groups, eps, silu, cl), None, None, None, None, None, None
+        groups, eps, silu, cl, group, S_total = ctx.cfg
+        return (_hip_group_norm_bwd(x, gy, g32, stats, groups, eps, silu, cl, group, S_total),) + (None,) * 8
 
 
-def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False):
-    """GroupNorm with fp32 statistics + optional fused SiLU.  channels_last: x is [N, ..., C]."""
+def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False, group=None, S_total=None):
+    """GroupNorm with fp32 statistics + optional fused SiLU.  channels_last: x is [N, ..., C].
+    group / S_total: statistics span the slices held by the ranks of `group` (S_total = global elements per
+    (sample, channel); computed with one tiny all-reduce when omitted)."""
     on_dev = _require_device(x, "group_norm")
     C = x.shape[-1] if channels_last else x.shape[1]
     if (on_dev and x.dtype in (torch.float16, torch.bfloat16) and weight is not None and bias is not None
@@ -224,9 +274,9 @@ def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=Fals
         if torch.is_grad_enabled() and x.requires_grad:
             if weight.requires_grad or bias.requires_grad:
                 raise RuntimeError("lvdm_amd.ops.group_norm: only the input gradient is implemented (freeze the weights)")
-            return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last)
-        return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last)
-    return group_norm_math(x, groups, weight, bias, eps, silu, channels_last)
+            return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last, group, S_total)
+        return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, group=group, S_total=S_total)
+    return group_norm_math(x, groups, weight, bias, eps, silu, channels_last, group)
 
 
 # --------------------------------------------------------------------------------------------------

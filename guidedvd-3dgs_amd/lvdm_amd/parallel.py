@@ -1,0 +1,231 @@
+"""Multi-GPU decomposition of the DDIM step: CFG pair x frame shards, one process per GPU.
+
+The reference is single-GPU (`DDIMSampler.p_sample_ddim`, ddim.py:208-280, evaluates cond and uncond
+sequentially; every layer sees all 25 frames).  The path partitions two ways:
+
+* **CFG pair** (`cfg` group, size 1 or 2): the two `apply_model` calls of a step are independent given x_t, so rank
+  c evaluates one of them; one all-gather of e_t (3.7 MB @576x1024) per step.  Guided step: each rank back-propagates
+  through its own branch and the 3.7 MB x-gradients are summed with one all-reduce.
+* **Frame shards** (`frames` group, size F): spatial layers (ResBlock conv2d, SpatialTransformer, Down/Upsample)
+  are per-frame, so rank f keeps frames [t0_f, t1_f) of every feature map.  Temporal layers couple the T frames of
+  one pixel: around each TemporalTransformer / TemporalConvBlock the token-major activation is re-sharded
+  frames -> pixels with one all-to-all ([T_f, P, C] -> [T, P_f, C]) and back afterwards (Ulysses-style); their 5-D
+  GroupNorm statistics (over T, h, w) are completed with a 2*G-double all-reduce (ops.group_norm(group=...)).
+  xGMI is point-to-point, and an all-to-all uses all links at once: 147 MB / F per rank at L0.
+
+world = cfg x frames, rank = cfg_rank * F + frame_rank (frame shards of one CFG branch are neighbours).
+Everything here is `torch.distributed` (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU tests).
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+
+def split_counts(n, parts):
+    """n items over `parts` ranks, sizes differing by at most one (25 frames over 4 -> 7, 6, 6, 6)."""
+    base, rem = divmod(n, parts)
+    return [base + 1 if r < rem else base for r in range(parts)]
+
+
+class FrameShard:
+    """Frame-parallel group: which frames this rank owns, and the all-to-all geometry."""
+
+    def __init__(self, group, n_frames):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.T = n_frames
+        self.counts = split_counts(n_frames, self.world)
+        self.offsets = [sum(self.counts[:r]) for r in range(self.world)]
+        if min(self.counts) < 1:
+            raise ValueError(f"{n_frames} frames cannot be split over {self.world} ranks")
+
+    @property
+    def lo(self):
+        return self.offsets[self.rank]
+
+    @property
+    def hi(self):
+        return self.offsets[self.rank] + self.counts[self.rank]
+
+    def local(self, x, dim):
+        """This rank's frames of a full tensor whose `dim` is the frame axis."""
+        return x.narrow(dim, self.lo, self.counts[self.rank])
+
+    def gather(self, x_local, dim):
+        """All frames from every rank's local slice (no autograd; sampler-level tensors).  Slices are padded to the
+        largest count so the all-gather is equal-sized on every backend."""
+        dim = dim % x_local.dim()
+        cmax = max(self.counts)
+        pad = cmax - x_local.shape[dim]
+        if pad:
+            shp = list(x_local.shape)
+            shp[dim] = pad
+            x_local = torch.cat([x_local, x_local.new_zeros(shp)], dim=dim)
+        parts = [torch.empty_like(x_local) for _ in range(self.world)]
+        dist.all_gather(parts, x_local.contiguous(), group=self.group)
+        return torch.cat([p.narrow(dim, 0, c) for p, c in zip(parts, self.counts)], dim=dim)
+
+
+_ACTIVE = None
+
+
+def active():
+    """The FrameShard the U-Net is currently running under (None = all frames local)."""
+    return _ACTIVE
+
+
+@contextlib.contextmanager
+def frame_parallel(shard):
+    global _ACTIVE
+    prev, _ACTIVE = _ACTIVE, (shard if shard is not None and shard.world > 1 else None)
+    try:
+        yield
+    finally:
+        _ACTIVE = prev
+
+
+class _AllToAll(torch.autograd.Function):
+    """all_to_all_single with explicit split sizes; the backward is the transposed exchange."""
+
+    @staticmethod
+    def forward(ctx, flat, in_splits, out_splits, group):
+        ctx.cfg = (in_splits, out_splits, group)
+        out = flat.new_empty(sum(out_splits))
+        dist.all_to_all_single(out, flat.contiguous(), out_splits, in_splits, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        in_splits, out_splits, group = ctx.cfg
+        gi = g.new_empty(sum(in_splits))
+        dist.all_to_all_single(gi, g.contiguous(), in_splits, out_splits, group=group)
+        return gi, None, None, None
+
+
+def frames_to_pixels(tok, shard):
+    """[T_f, P, C] (this rank's frames, all pixels) -> [T, P_f, C] (all frames, this rank's pixels)."""
+    Tf, P, C = tok.shape
+    pc = split_counts(P, shard.world)
+    po = [sum(pc[:r]) for r in range(shard.world)]
+    send = torch.cat([tok[:, po[r]:po[r] + pc[r]].reshape(-1) for r in range(shard.world)])
+    mine = pc[shard.rank]
+    out = _AllToAll.apply(send, [Tf * pc[r] * C for r in range(shard.world)],
+                          [shard.counts[s] * mine * C for s in range(shard.world)], shard.group)
+    return out.view(shard.T, mine, C)   # rank s's block is [T_s, P_f, C]: stacking them IS the frame order
+
+
+def pixels_to_frames(t, shard, P):
+    """[T, P_f, C] -> [T_f, P, C]; inverse of frames_to_pixels (P = total pixels)."""
+    T, mine, C = t.shape
+    pc = split_counts(P, shard.world)
+    Tf = shard.counts[shard.rank]
+    recv = _AllToAll.apply(t.reshape(-1), [shard.counts[s] * mine * C for s in range(shard.world)],
+                           [Tf * pc[r] * C for r in range(shard.world)], shard.group)
+    blocks, off = [], 0
+    for r in range(shard.world):
+        n = Tf * pc[r] * C
+        blocks.append(recv[off:off + n].view(Tf, pc[r], C))
+        off += n
+    return torch.cat(blocks, dim=1)
+
+
+class ParallelPlan:
+    """cfg x frames layout of an initialised default process group."""
+
+    def __init__(self, n_frames, cfg=None, world=None, rank=None):
+        world = dist.get_world_size() if world is None else world
+        rank = dist.get_rank() if rank is None else rank
+        if cfg is None:
+            cfg = 2 if world % 2 == 0 else 1
+        if world % cfg:
+            raise ValueError(f"world {world} is not a multiple of the CFG degree {cfg}")
+        F = world // cfg
+        self.world, self.rank, self.cfg, self.F = world, rank, cfg, F
+        self.cfg_rank, self.frame_rank = rank // F, rank % F
+        # every rank must create every group, in the same order
+        self.frame_group = self.cfg_group = None
+        for c in range(cfg):
+            g = dist.new_group([c * F + f for f in range(F)])
+            if c == self.cfg_rank:
+                self.frame_group = g
+        for f in range(F):
+            g = dist.new_group([c * F + f for c in range(cfg)])
+            if f == self.frame_rank:
+                self.cfg_group = g
+        self.shard = FrameShard(self.frame_group, n_frames)
+        self._world_shards = {}
+
+    # -- one U-Net evaluation on this rank's frames, result gathered to all frames -----------------------------
+    def _shard_cond(self, cond):
+        out = dict(cond)
+        if "c_concat" in cond:
+            out["c_concat"] = [self.shard.local(c, 2).contiguous() for c in cond["c_concat"]]
+        return out
+
+    def apply_local(self, model, x, t, cond, **kw):
+        """model.apply_model on this rank's frame slice (x [b, C, T, h, w] full, replicated)."""
+        x_loc = self.shard.local(x, 2).contiguous()
+        with frame_parallel(self.shard):
+            return model.apply_model(x_loc, t, self._shard_cond(cond), **kw)
+
+    def eval_cfg(self, model, x, t, cond, uncond, **kw):
+        """(e_cond, e_uncond) for the full latent, no autograd: the plain sampler's two apply_model calls."""
+        branches = [cond, uncond]
+        mine = [self.cfg_rank] if self.cfg == 2 else [0, 1]
+        got = {}
+        for i in mine:
+            e_loc = self.apply_local(model, x, t, branches[i], **kw)
+            got[i] = self.shard.gather(e_loc, 2) if self.F > 1 else e_loc
+        if self.cfg == 2:
+            both = [torch.empty_like(got[self.cfg_rank]) for _ in range(2)]
+            dist.all_gather(both, got[self.cfg_rank].contiguous(), group=self.cfg_group)
+            return both[0], both[1]
+        return got[0], got[1]
+
+    # -- guided step: forward that keeps the local autograd graph, then the distributed x-gradient ---------------
+    def eval_cfg_with_graph(self, model, x, t, cond, uncond, **kw):
+        """Returns (e_cond, e_uncond) detached full tensors and an opaque handle for `input_gradient`."""
+        branches = [cond, uncond]
+        mine = [self.cfg_rank] if self.cfg == 2 else [0, 1]
+        full, graphs = {}, []
+        for i in mine:
+            x_loc = self.shard.local(x.detach(), 2).contiguous().requires_grad_(True)
+            with frame_parallel(self.shard):
+                e_loc = model.apply_model(x_loc, t, self._shard_cond(branches[i]), **kw)
+            graphs.append((i, x_loc, e_loc))
+            full[i] = self.shard.gather(e_loc.detach(), 2) if self.F > 1 else e_loc.detach()
+        if self.cfg == 2:
+            both = [torch.empty_like(full[self.cfg_rank]) for _ in range(2)]
+            dist.all_gather(both, full[self.cfg_rank].contiguous(), group=self.cfg_group)
+            full = {0: both[0], 1: both[1]}
+        return full[0], full[1], graphs
+
+    def input_gradient(self, graphs, g_cond, g_uncond, like):
+        """sum over branches of J(e_branch -> x)^T g_branch for the FULL x (replicated result).  g_* are the full
+        [b, 4, T, h, w] cotangents of e_cond / e_uncond (identical on every rank)."""
+        g = {0: g_cond, 1: g_uncond}
+        total = torch.zeros_like(like)
+        for i, x_loc, e_loc in graphs:
+            # every rank of the frame group runs this backward together: the reversed all-to-alls route the
+            # cotangents of other ranks' frames through the temporal layers into this rank's x_loc
+            (gx_loc,) = torch.autograd.grad(e_loc, x_loc, self.shard.local(g[i], 2).to(e_loc.dtype).contiguous())
+            gx = self.shard.gather(gx_loc.float(), 2) if self.F > 1 else gx_loc.float()
+            total += gx.to(total.dtype)
+        if self.cfg == 2:
+            dist.all_reduce(total, group=self.cfg_group)
+        return total
+
+    def frame_owner_slices(self, n_frames):
+        """Frames whose VAE decode + loss gradient this rank computes in the guided step (all `world` ranks share)."""
+        counts = split_counts(n_frames, self.world)
+        lo = sum(counts[:self.rank])
+        return lo, lo + counts[self.rank], counts
+
+    def gather_world_frames(self, g_local, n_frames):
+        """[b, 4, my frames, h, w] per-frame gradients of `frame_owner_slices` -> all frames, on every rank."""
+        ws = self._world_shards.get(n_frames)
+        if ws is None:
+            ws = self._world_shards[n_frames] = FrameShard(dist.group.WORLD, n_frames)
+        return ws.gather(g_local, 2)

@@ -131,8 +131,13 @@ class DDIMSampler(object):
         if self.model.parameterization != "v":
             raise NotImplementedError("ViewCrafter is v-parameterised")
         m = self.model
+        plan = getattr(self, "parallel", None)  # parallel.ParallelPlan: CFG pair x frame shards (one process per GPU)
         if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+            if plan is not None:
+                raise NotImplementedError("the multi-GPU plan partitions the CFG pair; run without a plan when CFG is off")
             e_cond, e_uncond = m.apply_model(x, t, c, **kwargs), None
+        elif plan is not None:
+            e_cond, e_uncond = plan.eval_cfg(m, x, t, c, unconditional_conditioning, **kwargs)
         else:
             e_cond = m.apply_model(x, t, c, **kwargs)
             e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
@@ -182,10 +187,18 @@ class DDIMSamplerGuidance(DDIMSampler):
         self._freeze_weights()
         beta_t = k["a_t"] / k["a_prev"]
         s = float(unconditional_guidance_scale)
+        plan = getattr(self, "parallel", None)
+        step_kw = {k_: v_ for k_, v_ in kwargs.items() if k_ != "loss_guidance_fn"}
         for _ in range(repeat):
             x = x.detach().requires_grad_(True)
-            e_cond = m.apply_model(x, t, c, **kwargs)
-            e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
+            if plan is None:
+                e_cond = m.apply_model(x, t, c, **kwargs)
+                e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
+            else:
+                # each rank keeps the autograd graph of ITS branch / frame slice; here e_cond, e_uncond are replicated
+                # leaves and the chain rule is closed by plan.input_gradient below
+                e_cond, e_uncond, graphs = plan.eval_cfg_with_graph(m, x, t, c, unconditional_conditioning, **step_kw)
+                e_cond, e_uncond = e_cond.requires_grad_(True), e_uncond.requires_grad_(True)
             v = e_uncond + s * (e_cond - e_uncond)
             correction = (e_cond - e_uncond).detach()
             v = rescale_noise_cfg(v, e_cond, guidance_rescale)  # unconditional in the guided sampler (:272)
@@ -198,7 +211,8 @@ class DDIMSamplerGuidance(DDIMSampler):
             # per-frame decode + loss gradient w.r.t. the (detached) x0 latent of that frame
             n_frames = pred_x0.shape[2]
             grads, decoded = [], []
-            for f in range(n_frames):
+            f_lo, f_hi = (0, n_frames) if plan is None else plan.frame_owner_slices(n_frames)[:2]
+            for f in range(f_lo, f_hi):
                 z = pred_x0[:, :, f:f + 1].clone().detach().requires_grad_(True)
                 D = m.differentiable_decode_first_stage(z)
                 loss_dict, numel = loss_guidance_fn(D[0], index, f, f + 1)
@@ -211,7 +225,12 @@ class DDIMSamplerGuidance(DDIMSampler):
             if decoded:
                 loss_guidance_fn.save_pred_x0(torch.cat(decoded, dim=2), index)
             G = torch.cat(grads, dim=2)
-            (gx,) = torch.autograd.grad(pred_x0, x, grad_outputs=G)
+            if plan is None:
+                (gx,) = torch.autograd.grad(pred_x0, x, grad_outputs=G)
+            else:
+                G = plan.gather_world_frames(G, n_frames)  # every rank decoded its share of the frames
+                gx, g_ec, g_eu = torch.autograd.grad(pred_x0, (x, e_cond, e_uncond), grad_outputs=G)
+                gx = gx + plan.input_gradient(graphs, g_ec, g_eu, like=gx)
             with torch.no_grad():
                 rms = torch.stack([(gx * gx).mean().sqrt(), (correction ** 2).mean().sqrt()]).tolist()  # one host sync
                 rho = 0.0 if rms[0] == 0 else rms[1] * s / rms[0] * (0.2 * w)

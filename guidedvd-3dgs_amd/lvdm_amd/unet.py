@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint as _ckpt
 
-from . import ops
+from . import ops, parallel
 from .schedule import timestep_embedding
 
 
@@ -52,10 +52,12 @@ def _img(tok):
     return tok.permute(0, 3, 1, 2)
 
 
-def _gn_tokens(gn, tok, n_stat, silu=False):
-    """GroupNorm over token-major data; statistics span tok.numel() / (n_stat * C) tokens per group."""
+def _gn_tokens(gn, tok, n_stat, silu=False, shard=None, tokens_total=None):
+    """GroupNorm over token-major data; statistics span tok.numel() / (n_stat * C) tokens per group -- completed
+    across the frame-shard group when `shard` is given (tokens_total = tokens per sample over all ranks)."""
     C = tok.shape[-1]
-    y = ops.group_norm(tok.reshape(n_stat, -1, C), gn.num_groups, gn.weight, gn.bias, gn.eps, silu=silu, channels_last=True)
+    y = ops.group_norm(tok.reshape(n_stat, -1, C), gn.num_groups, gn.weight, gn.bias, gn.eps, silu=silu, channels_last=True,
+                       group=None if shard is None else shard.group, S_total=tokens_total)
     return y.reshape(tok.shape)
 
 
@@ -238,11 +240,18 @@ class TemporalTransformer(nn.Module):
         bt, c, h, w = x.shape
         b, T = batch_size, bt // batch_size
         tok = _tok(x)
-        t = _gn_tokens(self.norm, tok, b).reshape(b, T, h * w, c)  # statistics over (C/32, T, h, w) per sample
+        shard = parallel.active()
+        if shard is None:
+            t = _gn_tokens(self.norm, tok, b).reshape(b, T, h * w, c)  # statistics over (C/32, T, h, w) per sample
+        else:  # frames are sharded: finish the statistics across the group, then re-shard frames -> pixels
+            t = _gn_tokens(self.norm, tok, b, shard=shard, tokens_total=shard.T * h * w)
+            t = parallel.frames_to_pixels(t.reshape(T, h * w, c), shard)[None]  # [1, all T, this rank's pixels, c]
         t = self._proj(self.proj_in, t)
         for blk in self.transformer_blocks:
             t = blk(t, frame_major=True)
         t = self._proj(self.proj_out, t)
+        if shard is not None:
+            t = parallel.pixels_to_frames(t[0], shard, h * w)
         return _img(t.reshape(bt, h, w, c) + tok)
 
 
@@ -294,11 +303,17 @@ class TemporalConvBlock(nn.Module):
 
     def forward_tokens(self, tok, b):  # tok [(b t), H, W, C] contiguous
         bt, hh, ww, c = tok.shape
-        h = tok.reshape(b, bt // b, hh * ww, c)
+        shard = parallel.active()
+        if shard is None:
+            h, total = tok.reshape(b, bt // b, hh * ww, c), None
+        else:  # the frame taps need t-1 / t+1 of a pixel: work on [all T, this rank's pixels] for the whole block
+            h, total = parallel.frames_to_pixels(tok.reshape(bt, hh * ww, c), shard)[None], shard.T * hh * ww
         for seq in (self.conv1, self.conv2, self.conv3, self.conv4):
             gn, conv = seq[0], seq[-1]
-            h = _gn_tokens(gn, h, b, silu=True)
+            h = _gn_tokens(gn, h, b, silu=True, shard=shard, tokens_total=total)
             h = self._temporal_gemm(h, self._tap_weights(conv), conv.bias)
+        if shard is not None:
+            h = parallel.pixels_to_frames(h[0], shard, hh * ww)
         return tok + h.reshape(bt, hh, ww, c)
 
     def forward(self, x):  # reference signature: [b, c, t, h, w]
@@ -461,7 +476,12 @@ class UNetModel(nn.Module):
         # otherwise the SAME context for every frame -> keep ONE copy per batch row and let the
         # cross-attention project it once (shared_frames = T) instead of T identical copies.
         shared = 1
-        if context.shape[1] == 77 + t * 16:
+        shard = parallel.active()
+        if shard is not None:  # x holds this rank's frames only (parallel.py); the context must be the shared kind
+            if b != 1 or context.shape[1] == 77 + shard.T * 16:
+                raise NotImplementedError("frame-sharded U-Net: batch 1 and a frame-independent context only")
+            shared = t
+        elif context.shape[1] == 77 + t * 16:
             ctx_text = context[:, :77].repeat_interleave(t, dim=0)
             ctx_img = context[:, 77:].reshape(b * t, 16, context.shape[-1])
             context = torch.cat([ctx_text, ctx_img], dim=1)

@@ -66,12 +66,29 @@ int gvd_ddim_step(const float* x, const float* e_cond, const float* e_uncond, co
 int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta, double* stats,
                    int N, int C, long long S, int G, float eps, int silu, int channels_last, int is_bf16, void* stream);
 
+/* The two phases of gvd_group_norm, for statistics that span more than this device's slice (frame-sharded temporal
+ * layers: the 5-D GroupNorm of TemporalConvBlock / TemporalTransformer, openaimodel3d.py:259-268, attention.py:370,
+ * normalises over all T frames).  Call _stats on the local slice, all-reduce (sum) the first 2*N*G doubles of `stats`
+ * across the shard group, then _apply with S_total = the global element count per (sample, channel). */
+int gvd_group_norm_stats(const void* x, double* stats, int N, int C, long long S, int G, int channels_last, int is_bf16,
+                         void* stream);
+int gvd_group_norm_apply(const void* x, void* y, const float* gamma, const float* beta, double* stats,
+                         int N, int C, long long S, long long S_total, int G, float eps, int silu, int channels_last,
+                         int is_bf16, void* stream);
+
 /* GroupNorm (+SiLU) backward w.r.t. the input (the guided sampler differentiates pred_x0 w.r.t. x_t only; weights are
  * frozen -- ddim_guidance.py:318-345 requests inputs=x).  x, dy, dx share the forward's layout; fwd_stats is the scratch
  * buffer gvd_group_norm filled for the same x (group sums + per-(n,c) affine); scratch: 16*N*G + 8*N*C bytes. */
 int gvd_group_norm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const double* fwd_stats,
                        double* scratch, int N, int C, long long S, int G, float eps, int silu, int channels_last,
                        int is_bf16, void* stream);
+
+/* Two-phase form of gvd_group_norm_bwd (all-reduce the first 2*N*G doubles of `scratch` between the calls). */
+int gvd_group_norm_bwd_stats(const void* x, const void* dy, const float* gamma, const double* fwd_stats, double* scratch,
+                             int N, int C, long long S, int G, int silu, int channels_last, int is_bf16, void* stream);
+int gvd_group_norm_bwd_apply(const void* x, const void* dy, void* dx, const double* fwd_stats, double* scratch,
+                             int N, int C, long long S, long long S_total, int G, float eps, int silu, int channels_last,
+                             int is_bf16, void* stream);
 
 /* LayerNorm over the last dim of [M, C] 16-bit rows, fp32 statistics, gamma/beta in the same 16-bit type as x.
  * Replaces nn.LayerNorm in BasicTransformerBlock (lvdm/modules/attention.py:283-285).  C % 8 == 0, C <= 2048. */

@@ -286,3 +286,39 @@ def test_group_norm_backward_kernel_matches_fp32_autograd(dtype, shape, cl, silu
     assert gx.dtype == dtype and gx.shape == x.shape
     err = float((gx.float() - rx).abs().max()) / float(rx.abs().max())
     assert err < (4e-3 if dtype == torch.float16 else 2.5e-2), err
+
+
+def test_shard_group_group_norm_and_resharding_on_device_single_rank_group():
+    """The two-phase GroupNorm (stats -> all-reduce -> apply, forward and backward) and the frame<->pixel all-to-all on
+    the device through RCCL with a 1-rank group: must equal the fused single-call path bit for bit (the multi-rank
+    arithmetic is covered by tests/test_ddim_parallel_gloo.py on CPU)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from lvdm_amd import ops, parallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        g = torch.Generator(device=DEV).manual_seed(77)
+        x = (torch.randn(1, 7 * 35, 320, device=DEV, generator=g) * 1.3 + 0.2).half().requires_grad_(True)
+        w = (torch.randn(320, device=DEV, generator=g) * 0.3 + 1).half()
+        b = (torch.randn(320, device=DEV, generator=g) * 0.2).half()
+        gy = torch.randn(x.shape, device=DEV, generator=g).half()
+        y0 = ops.group_norm(x, 32, w, b, 1e-5, silu=True, channels_last=True)
+        (g0,) = torch.autograd.grad(y0, x, gy)
+        y1 = ops.group_norm(x, 32, w, b, 1e-5, silu=True, channels_last=True, group=dist.group.WORLD, S_total=7 * 35)
+        (g1,) = torch.autograd.grad(y1, x, gy)
+        assert torch.equal(y0, y1) and torch.equal(g0, g1)
+        y2 = ops.group_norm(x.detach(), 32, w, b, 1e-5, silu=True, channels_last=True, group=dist.group.WORLD)  # count via all-reduce
+        assert torch.equal(y0, y2)
+        shard = parallel.FrameShard(dist.group.WORLD, 7)
+        tok = x.detach().reshape(7, 35, 320)
+        px = parallel.frames_to_pixels(tok, shard)
+        assert torch.equal(px, tok) and torch.equal(parallel.pixels_to_frames(px, shard, 35), tok)
+        assert torch.equal(shard.gather(tok, 0), tok)
+    finally:
+        dist.destroy_process_group()
