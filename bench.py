@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--ddim-width", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-cfg", action="store_true", help="ddim: evaluate cond/uncond as one batch-2 U-Net call")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -284,6 +285,7 @@ def ddim_main(args):
     uc = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g).half()], "c_concat": cond["c_concat"]}
     sampler = DDIMSamplerGuidance(ld) if guided else DDIMSampler(ld)
     sampler.make_schedule(50, "uniform_trailing", 1.0)
+    sampler.batch_cfg = bool(args.batch_cfg)
     plan = None
     if world > 1:
         from lvdm_amd.parallel import ParallelPlan

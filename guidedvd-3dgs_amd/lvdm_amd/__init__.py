@@ -21,3 +21,20 @@ _os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
 _db = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
 if _os.path.isdir(_db) and _os.access(_db, _os.W_OK):
     _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)
+
+# hipBLASLt / rocBLAS solution choices for the U-Net's GEMM shapes, recorded by PyTorch TunableOp on an MI355X
+# (tests/scripts/run_ddim_tunable.sh).  Read-only use: tuning stays off unless the caller turns it on; a file written
+# by another PyTorch / hipBLASLt build fails TunableOp's validators and is ignored.  TunableOp looks for
+# <name><device ordinal>.csv, so the one recorded file is mirrored for the 8 GPUs of a node.
+_tun = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tunableop")
+if _os.path.exists(_os.path.join(_tun, "tunableop0.csv")) and "PYTORCH_TUNABLEOP_ENABLED" not in _os.environ:
+    try:
+        import shutil as _sh
+        for _i in range(1, 8):
+            if not _os.path.exists(_os.path.join(_tun, f"tunableop{_i}.csv")):
+                _sh.copyfile(_os.path.join(_tun, "tunableop0.csv"), _os.path.join(_tun, f"tunableop{_i}.csv"))
+    except OSError:
+        pass
+    _os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+    _os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
+    _os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", _os.path.join(_tun, "tunableop.csv"))

@@ -23,6 +23,15 @@ from . import ops
 from .schedule import make_ddim_sampling_parameters, make_ddim_timesteps, rescale_noise_cfg
 
 
+def _same_structure(c, uc):
+    return (isinstance(c, dict) and isinstance(uc, dict) and c.keys() == uc.keys()
+            and all(len(c[k]) == len(uc[k]) and all(a.shape == b.shape for a, b in zip(c[k], uc[k])) for k in c))
+
+
+def _cat_cond(c, uc):
+    return {k: [torch.cat([a, b], dim=0) for a, b in zip(c[k], uc[k])] for k in c}
+
+
 class DDIMSampler(object):
     def __init__(self, model, schedule="linear", **kwargs):
         self.model = model
@@ -138,6 +147,13 @@ class DDIMSampler(object):
             e_cond, e_uncond = m.apply_model(x, t, c, **kwargs), None
         elif plan is not None:
             e_cond, e_uncond = plan.eval_cfg(m, x, t, c, unconditional_conditioning, **kwargs)
+        elif getattr(self, "batch_cfg", False) and _same_structure(c, unconditional_conditioning):
+            # one batch-2 evaluation instead of the reference's two sequential ones (ddim.py:222-223): every layer
+            # is per-sample (GroupNorm statistics, attention, convolutions), so each half equals its own batch-1 call
+            kw2 = {k_: (torch.cat([v_, v_]) if torch.is_tensor(v_) and v_.dim() >= 1 and v_.shape[0] == x.shape[0] else v_)
+                   for k_, v_ in kwargs.items()}
+            e = m.apply_model(torch.cat([x, x]), torch.cat([t, t]), _cat_cond(c, unconditional_conditioning), **kw2)
+            e_cond, e_uncond = e.chunk(2, dim=0)
         else:
             e_cond = m.apply_model(x, t, c, **kwargs)
             e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)

@@ -145,3 +145,23 @@ def test_split_counts_and_resharding_geometry():
     assert parallel.split_counts(25, 1) == [25]
     assert parallel.split_counts(9216, 4) == [2304] * 4
     assert sum(parallel.split_counts(2240, 3)) == 2240
+
+
+def test_batched_cfg_evaluation_equals_the_two_sequential_calls():
+    """DDIMSampler.batch_cfg: one batch-2 U-Net call vs the reference's two batch-1 calls (ddim.py:222-223), fp32 CPU."""
+    built = _build()   # switches the explicit-math CPU path on for this process: restored below
+    ld, x, cond, uc, noise = built[:5]
+    from lvdm_amd import ops
+    from lvdm_amd.samplers import DDIMSampler
+    outs = []
+    for flag in (False, True):
+        s = DDIMSampler(ld)
+        s.batch_cfg = flag
+        s.make_schedule(50, "uniform_trailing", 1.0)
+        t = torch.full((1,), int(s.ddim_timesteps[30]), dtype=torch.long)
+        with torch.no_grad():
+            outs.append(s.p_sample_ddim(x, cond, t, index=30, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                                        guidance_rescale=0.7, fs=torch.tensor([10]), noise=noise))
+    ops.use_reference_math(False)
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).abs().max()) < 2e-5 * float(a.abs().max())
