@@ -31,7 +31,8 @@ if _os.path.exists(_os.path.join(_tun, "tunableop0.csv")) and "PYTORCH_TUNABLEOP
     try:
         import shutil as _sh
         for _i in range(1, 8):
-            if not _os.path.exists(_os.path.join(_tun, f"tunableop{_i}.csv")):
+            _dst = _os.path.join(_tun, f"tunableop{_i}.csv")
+            if not _os.path.exists(_dst) or _os.path.getmtime(_dst) < _os.path.getmtime(_os.path.join(_tun, "tunableop0.csv")):
                 _sh.copyfile(_os.path.join(_tun, "tunableop0.csv"), _os.path.join(_tun, f"tunableop{_i}.csv"))
     except OSError:
         pass
