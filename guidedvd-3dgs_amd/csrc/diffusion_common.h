@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include <string>
+#include <type_traits>
 
 #include "../../include/gvd_diffusion.h"
 

@@ -34,11 +34,13 @@ using namespace gvdd;
 
 namespace {
 
-template <typename T, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                         T* __restrict__ out, float* __restrict__ lse, int H, int Nq, int Nk, float scale_log2e,
-                                                         long long q_bs, long long q_rs, long long kv_bs, long long kv_rs)
+template <typename T, int WAVES, int QB>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2)))
+k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out, float* __restrict__ lse,
+           int H, int Nq, int Nk, float scale_log2e, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs)
 {
+    // QB = query blocks (of 32) per wave.  QB = 2 halves the LDS reads and K/V staging per flop (every A operand feeds
+    // two MFMAs) and gives the wave two independent softmax chains to interleave with the matrix pipe.
     typedef typename Tr<T>::vec8 vec8;
     constexpr int NT = WAVES * 64;
     __shared__ __attribute__((aligned(16))) T sK[KV_TILE][LDS_ROW];
@@ -55,18 +57,23 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     const T* vb = v + (size_t)b * kv_bs + (size_t)h * 64;
     T* ob = out + (size_t)b * q_bs + (size_t)h * 64;
 
-    const int query = blockIdx.y * (32 * WAVES) + wave * 32 + col;
-    const bool valid_q = query < Nq;
-
-    vec8 qf[4];
+    int query[QB];
+    bool valid_q[QB];
+    vec8 qf[QB][4];
+    f16v o0[QB], o1[QB];
+    float m[QB], l[QB];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-        if (valid_q) qf[ks] = *reinterpret_cast<const vec8*>(qb + (size_t)query * rs + 16 * ks + 8 * hi);
-        else qf[ks] = vec8{};
+    for (int qi = 0; qi < QB; qi++) {
+        query[qi] = blockIdx.y * (32 * WAVES * QB) + (wave * QB + qi) * 32 + col;
+        valid_q[qi] = query[qi] < Nq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            qf[qi][ks] = valid_q[qi] ? *reinterpret_cast<const vec8*>(qb + (size_t)query[qi] * rs + 16 * ks + 8 * hi) : vec8{};
+        o0[qi] = f16v{};
+        o1[qi] = f16v{};
+        m[qi] = -1.0e30f;
+        l[qi] = 0.f;
     }
-
-    f16v o0 = {}, o1 = {};
-    float m = -1.0e30f, l = 0.f;
 
     // Staging maps (per pass of NT threads over the 512 16-byte chunks of a 64-key x 64-channel tile):
     //   K : chunk c -> key row c>>3, channels (c&7)*8..+7 : 8 lanes cover one 128-byte row (coalesced), ds_write_b128.
@@ -106,91 +113,111 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         }
     };
 
-    prefetch(0);
-    for (int kt = 0; kt < Nk; kt += KV_TILE) {
+    // One 64-key tile.  TAIL (only the last, partial tile) masks the keys past Nk; the full-tile body is branch-free
+    // so that the scheduler can interleave the two query blocks' softmax VALU with the other block's MFMAs.
+    auto tile = [&](int kt, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         __syncthreads();  // every wave is done reading the previous tile
         commit();
         __syncthreads();
-        if (kt + KV_TILE < Nk) prefetch(kt + KV_TILE);  // global loads of the next tile fly under this tile's math
+        if (!TAIL && kt + KV_TILE < Nk) prefetch(kt + KV_TILE);  // global loads of the next tile fly under this tile's math
 
-        // ---- S^T = K Q^T : two 32-key blocks ----
-        f16v s0 = {}, s1 = {};
+        // ---- S^T = K Q^T : two 32-key blocks per query block; each K fragment read feeds QB MFMAs ----
+        f16v s0[QB], s1[QB];
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++) { s0[qi] = f16v{}; s1[qi] = f16v{}; }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const vec8 a0 = *reinterpret_cast<const vec8*>(&sK[col][16 * ks + 8 * hi]);
             const vec8 a1 = *reinterpret_cast<const vec8*>(&sK[32 + col][16 * ks + 8 * hi]);
-            s0 = Tr<T>::mfma(a0, qf[ks], s0);
-            s1 = Tr<T>::mfma(a1, qf[ks], s1);
+#pragma unroll
+            for (int qi = 0; qi < QB; qi++) {
+                s0[qi] = Tr<T>::mfma(a0, qf[qi][ks], s0[qi]);
+                s1[qi] = Tr<T>::mfma(a1, qf[qi][ks], s1[qi]);
+            }
         }
         // ---- online softmax over this lane's 32 scores (+ the other half's 32); the 1/sqrt(d)*log2(e) scale is
         //      folded into the exp2 argument (one fma per score) ----
-        if (kt + KV_TILE > Nk) {
+        unsigned pk0[QB][8], pk1[QB][8];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (kt + krow >= Nk) s0[r] = -3.0e38f;
-                if (kt + 32 + krow >= Nk) s1[r] = -3.0e38f;
+        for (int qi = 0; qi < QB; qi++) {
+            f16v& t0 = s0[qi];
+            f16v& t1 = s1[qi];
+            if (TAIL) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kt + krow >= Nk) t0[r] = -3.0e38f;
+                    if (kt + 32 + krow >= Nk) t1[r] = -3.0e38f;
+                }
             }
-        }
-        float mt = max3f(s0[0], s1[0], s0[1]);
-        mt = max3f(mt, s1[1], s0[2]);
+            float mt = max3f(t0[0], t1[0], t0[1]);
+            mt = max3f(mt, t1[1], t0[2]);
 #pragma unroll
-        for (int r = 3; r < 16; r += 2) { mt = max3f(mt, s0[r], s1[r - 1]); mt = max3f(mt, s1[r], r + 1 < 16 ? s0[r + 1] : mt); }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m, mt * scale_log2e);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        // P = exp2(s*c - m): packed fp32 fma / add (v_pk_*), rounded to 16 bit right away (the MFMA operand type)
-        const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m_new, -m_new };
-        f2 rs2 = { 0.f, 0.f };
-        unsigned pk0[8], pk1[8];
+            for (int r = 3; r < 16; r += 2) { mt = max3f(mt, t0[r], t1[r - 1]); mt = max3f(mt, t1[r], r + 1 < 16 ? t0[r + 1] : mt); }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m[qi], mt * scale_log2e);
+            const float alpha = __builtin_amdgcn_exp2f(m[qi] - m_new);
+            // P = exp2(s*c - m): packed fp32 fma / add (v_pk_*), rounded to 16 bit right away (the MFMA operand type)
+            const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m_new, -m_new };
+            f2 rs2 = { 0.f, 0.f };
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            f2 a0 = { s0[2 * j], s0[2 * j + 1] }, a1 = { s1[2 * j], s1[2 * j + 1] };
-            a0 = __builtin_elementwise_fma(a0, c2, nm2);
-            a1 = __builtin_elementwise_fma(a1, c2, nm2);
-            const f2 p0 = { __builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y) };
-            const f2 p1 = { __builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y) };
-            rs2 += p0 + p1;
-            pk0[j] = Tr<T>::pack2(p0.x, p0.y);
-            pk1[j] = Tr<T>::pack2(p1.x, p1.y);
-        }
-        float rowsum = rs2.x + rs2.y;
-        rowsum += __shfl_xor(rowsum, 32, 64);
-        l = l * alpha + rowsum;
-        m = m_new;
-        if (__any(alpha != 1.0f)) {  // wave-uniform: after the first tiles the running max rarely moves
+            for (int j = 0; j < 8; j++) {
+                f2 a0 = { t0[2 * j], t0[2 * j + 1] }, a1 = { t1[2 * j], t1[2 * j + 1] };
+                a0 = __builtin_elementwise_fma(a0, c2, nm2);
+                a1 = __builtin_elementwise_fma(a1, c2, nm2);
+                const f2 p0 = { __builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y) };
+                const f2 p1 = { __builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y) };
+                rs2 += p0 + p1;
+                pk0[qi][j] = Tr<T>::pack2(p0.x, p0.y);
+                pk1[qi][j] = Tr<T>::pack2(p1.x, p1.y);
+            }
+            float rowsum = rs2.x + rs2.y;
+            rowsum += __shfl_xor(rowsum, 32, 64);
+            l[qi] = l[qi] * alpha + rowsum;
+            m[qi] = m_new;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; r++) { o0[qi][r] *= alpha; o1[qi][r] *= alpha; }
         }
 
-        // ---- O^T += V^T P^T : P^T fragments via permlane32_swap of the packed pairs ----
+        // ---- O^T += V^T P^T : P^T fragments via permlane32_swap of the packed pairs; each V^T read feeds QB MFMAs ----
 #pragma unroll
         for (int kbk = 0; kbk < 2; kbk++) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++) {
-                const vec8 pf = packed_c_to_b_operand<T>(kbk == 0 ? pk0 : pk1, k2);
                 const int kcol = 32 * kbk + 16 * k2 + 8 * hi;
                 const vec8 va0 = *reinterpret_cast<const vec8*>(&sVt[col][kcol]);
                 const vec8 va1 = *reinterpret_cast<const vec8*>(&sVt[32 + col][kcol]);
-                o0 = Tr<T>::mfma(va0, pf, o0);
-                o1 = Tr<T>::mfma(va1, pf, o1);
+#pragma unroll
+                for (int qi = 0; qi < QB; qi++) {
+                    const vec8 pf = packed_c_to_b_operand<T>(kbk == 0 ? pk0[qi] : pk1[qi], k2);
+                    o0[qi] = Tr<T>::mfma(va0, pf, o0[qi]);
+                    o1[qi] = Tr<T>::mfma(va1, pf, o1[qi]);
+                }
             }
         }
-    }
+    };
+
+    prefetch(0);
+    const int n_full = Nk / KV_TILE * KV_TILE;
+    for (int kt = 0; kt < n_full; kt += KV_TILE) tile(kt, std::false_type{});
+    if (n_full < Nk) tile(n_full, std::true_type{});
     // ---- epilogue: O[query][d] = O^T / l ----
-    if (valid_q) {
+#pragma unroll
+    for (int qi = 0; qi < QB; qi++) {
+        if (!valid_q[qi]) continue;
         // log2-domain log-sum-exp of the scaled scores, kept for the backward kernels: P = exp2(s*c - lse)
-        if (lse && hi == 0) lse[(size_t)bh * Nq + query] = m + __builtin_amdgcn_logf(l);
-        const float inv = 1.0f / l;
-        T* orow = ob + (size_t)query * rs;
+        if (lse && hi == 0) lse[(size_t)bh * Nq + query[qi]] = m[qi] + __builtin_amdgcn_logf(l[qi]);
+        const float inv = 1.0f / l[qi];
+        T* orow = ob + (size_t)query[qi] * rs;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             const int d0 = 8 * rg + 4 * hi;
             uint2 w0, w1;
-            w0.x = Tr<T>::pack2(o0[4 * rg] * inv, o0[4 * rg + 1] * inv);
-            w0.y = Tr<T>::pack2(o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
-            w1.x = Tr<T>::pack2(o1[4 * rg] * inv, o1[4 * rg + 1] * inv);
-            w1.y = Tr<T>::pack2(o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+            w0.x = Tr<T>::pack2(o0[qi][4 * rg] * inv, o0[qi][4 * rg + 1] * inv);
+            w0.y = Tr<T>::pack2(o0[qi][4 * rg + 2] * inv, o0[qi][4 * rg + 3] * inv);
+            w1.x = Tr<T>::pack2(o1[qi][4 * rg] * inv, o1[qi][4 * rg + 1] * inv);
+            w1.y = Tr<T>::pack2(o1[qi][4 * rg + 2] * inv, o1[qi][4 * rg + 3] * inv);
             *reinterpret_cast<uint2*>(orow + d0) = w0;
             *reinterpret_cast<uint2*>(orow + 32 + d0) = w1;
         }
@@ -670,16 +697,19 @@ int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void*
     if (D != 64) return fail(-1, "gvd_attention_fwd: head dim must be 64");
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(-1, "gvd_attention_fwd: pointers must be 16-byte aligned");
     const float sl2 = scale * 1.4426950408889634f;
-    const bool big = Nq > 64;
-    const int rows = big ? 128 : 32;
+    // 4 waves x 2 query blocks (256 queries / workgroup) for long sequences, 4 x 1 for medium, one wave for short ones
+    const int mode = Nq >= 512 ? 2 : (Nq > 64 ? 1 : 0);
+    const int rows = mode == 2 ? 256 : (mode == 1 ? 128 : 32);
     dim3 grid((unsigned)(B * H), (unsigned)((Nq + rows - 1) / rows));
+#define GVD_ATTN_LAUNCH(T, W, Q)                                                                                          \
+    hipLaunchKernelGGL((k_attn_fwd<T, W, Q>), grid, dim3(W * 64), 0, stream, (const T*)q, (const T*)k, (const T*)v, (T*)out, lse, \
+                       H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs)
     if (is_bf16) {
-        if (big) hipLaunchKernelGGL((k_attn_fwd<__bf16, 4>), grid, dim3(256), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
-        else hipLaunchKernelGGL((k_attn_fwd<__bf16, 1>), grid, dim3(64), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        if (mode == 2) GVD_ATTN_LAUNCH(__bf16, 4, 2); else if (mode == 1) GVD_ATTN_LAUNCH(__bf16, 4, 1); else GVD_ATTN_LAUNCH(__bf16, 1, 1);
     } else {
-        if (big) hipLaunchKernelGGL((k_attn_fwd<_Float16, 4>), grid, dim3(256), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
-        else hipLaunchKernelGGL((k_attn_fwd<_Float16, 1>), grid, dim3(64), 0, stream, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (_Float16*)out, lse, H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs);
+        if (mode == 2) GVD_ATTN_LAUNCH(_Float16, 4, 2); else if (mode == 1) GVD_ATTN_LAUNCH(_Float16, 4, 1); else GVD_ATTN_LAUNCH(_Float16, 1, 1);
     }
+#undef GVD_ATTN_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_attn_fwd", e);
     return 0;
