@@ -71,6 +71,13 @@ __device__ __forceinline__ typename Tr<T>::vec8 packed_c_to_b_operand(const unsi
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ f2 exp2_pair(f2 a)
+{
+    // (a Cody-Waite + cubic VALU exp2 was tried to offload v_exp_f32: 726 -> 539 TFLOP/s; removing the exp altogether
+    // only gave 769, so the transcendental rate is not what bounds the loop)
+    return f2{ __builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y) };
+}
+
 // v_max3_f32 without the sNaN-quieting canonicalisation the IEEE-mode fmaxf lowering inserts per operand
 __device__ __forceinline__ float max3f(float a, float b, float c)
 {

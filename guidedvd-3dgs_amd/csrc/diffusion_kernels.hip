@@ -43,8 +43,8 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     // two MFMAs) and gives the wave two independent softmax chains to interleave with the matrix pipe.
     typedef typename Tr<T>::vec8 vec8;
     constexpr int NT = WAVES * 64;
-    __shared__ __attribute__((aligned(16))) T sK[KV_TILE][LDS_ROW];
-    __shared__ __attribute__((aligned(16))) T sVt[64][LDS_ROW];
+    __shared__ __attribute__((aligned(16))) T sKb[2][KV_TILE][LDS_ROW];   // double-buffered: one barrier per tile
+    __shared__ __attribute__((aligned(16))) T sVtb[2][64][LDS_ROW];
 
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,7 +95,9 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
             rv1[ps] = (key + 1 < Nk) ? *reinterpret_cast<const vec8*>(vb + (size_t)(key + 1) * krs + c8) : vec8{};
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        T (*sK)[LDS_ROW] = sKb[buf];
+        T (*sVt)[LDS_ROW] = sVtb[buf];
 #pragma unroll
         for (int ps = 0; ps < PASSES; ps++) {
             const int c = tid + ps * NT, row = c >> 3, c8 = (c & 7) * 8;
@@ -115,12 +117,16 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 
     // One 64-key tile.  TAIL (only the last, partial tile) masks the keys past Nk; the full-tile body is branch-free
     // so that the scheduler can interleave the two query blocks' softmax VALU with the other block's MFMAs.
-    auto tile = [&](int kt, auto tail_tag) {
+    // Pipeline: while tile i is computed from LDS buffer i&1, tile i+1 (already in registers) is written to the other
+    // buffer and the global loads of tile i+2 are issued; ONE barrier per tile publishes the writes and retires the reads.
+    auto tile = [&](int kt, int buf, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        __syncthreads();  // every wave is done reading the previous tile
-        commit();
-        __syncthreads();
-        if (!TAIL && kt + KV_TILE < Nk) prefetch(kt + KV_TILE);  // global loads of the next tile fly under this tile's math
+        const T (*sK)[LDS_ROW] = sKb[buf];
+        const T (*sVt)[LDS_ROW] = sVtb[buf];
+        if (!TAIL && kt + KV_TILE < Nk) {
+            commit(buf ^ 1);
+            if (kt + 2 * KV_TILE < Nk) prefetch(kt + 2 * KV_TILE);
+        }
 
         // ---- S^T = K Q^T : two 32-key blocks per query block; each K fragment read feeds QB MFMAs ----
         f16v s0[QB], s1[QB];
@@ -138,7 +144,13 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         }
         // ---- online softmax over this lane's 32 scores (+ the other half's 32); the 1/sqrt(d)*log2(e) scale is
         //      folded into the exp2 argument (one fma per score) ----
+        //      Lazy rescaling: the running max m is only raised (and O, l rescaled -- 32 accumulator registers per query
+        //      block, a VALU -> MFMA hazard on every one) when some query's tile max exceeds it by more than 2^8;
+        //      otherwise the stale m is kept and P = exp2(s*c - m) <= 256, exact in the softmax ratio because O and l
+        //      share the same m, and well inside the 16-bit operand range.  After the first tiles this is the cold path.
         unsigned pk0[QB][8], pk1[QB][8];
+        float m_cand[QB];
+        bool grow = false;
 #pragma unroll
         for (int qi = 0; qi < QB; qi++) {
             f16v& t0 = s0[qi];
@@ -156,28 +168,39 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 #pragma unroll
             for (int r = 3; r < 16; r += 2) { mt = max3f(mt, t0[r], t1[r - 1]); mt = max3f(mt, t1[r], r + 1 < 16 ? t0[r + 1] : mt); }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float m_new = fmaxf(m[qi], mt * scale_log2e);
-            const float alpha = __builtin_amdgcn_exp2f(m[qi] - m_new);
+            m_cand[qi] = fmaxf(m[qi], mt * scale_log2e);
+            grow |= (m_cand[qi] - m[qi]) > 8.0f;
+        }
+        if (__any(grow)) {
+#pragma unroll
+            for (int qi = 0; qi < QB; qi++) {
+                const float alpha = __builtin_amdgcn_exp2f(m[qi] - m_cand[qi]);
+                l[qi] *= alpha;
+                m[qi] = m_cand[qi];
+#pragma unroll
+                for (int r = 0; r < 16; r++) { o0[qi][r] *= alpha; o1[qi][r] *= alpha; }
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++) {
+            const f16v& t0 = s0[qi];
+            const f16v& t1 = s1[qi];
             // P = exp2(s*c - m): packed fp32 fma / add (v_pk_*), rounded to 16 bit right away (the MFMA operand type)
-            const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m_new, -m_new };
+            const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m[qi], -m[qi] };
             f2 rs2 = { 0.f, 0.f };
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 f2 a0 = { t0[2 * j], t0[2 * j + 1] }, a1 = { t1[2 * j], t1[2 * j + 1] };
                 a0 = __builtin_elementwise_fma(a0, c2, nm2);
                 a1 = __builtin_elementwise_fma(a1, c2, nm2);
-                const f2 p0 = { __builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y) };
-                const f2 p1 = { __builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y) };
+                const f2 p0 = exp2_pair(a0), p1 = exp2_pair(a1);
                 rs2 += p0 + p1;
                 pk0[qi][j] = Tr<T>::pack2(p0.x, p0.y);
                 pk1[qi][j] = Tr<T>::pack2(p1.x, p1.y);
             }
             float rowsum = rs2.x + rs2.y;
             rowsum += __shfl_xor(rowsum, 32, 64);
-            l[qi] = l[qi] * alpha + rowsum;
-            m[qi] = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { o0[qi][r] *= alpha; o1[qi][r] *= alpha; }
+            l[qi] += rowsum;
         }
 
         // ---- O^T += V^T P^T : P^T fragments via permlane32_swap of the packed pairs; each V^T read feeds QB MFMAs ----
@@ -196,12 +219,17 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
                 }
             }
         }
+        __syncthreads();
     };
 
     prefetch(0);
+    commit(0);
+    if (KV_TILE < Nk) prefetch(KV_TILE);
+    __syncthreads();
     const int n_full = Nk / KV_TILE * KV_TILE;
-    for (int kt = 0; kt < n_full; kt += KV_TILE) tile(kt, std::false_type{});
-    if (n_full < Nk) tile(n_full, std::true_type{});
+    int buf = 0;
+    for (int kt = 0; kt < n_full; kt += KV_TILE, buf ^= 1) tile(kt, buf, std::false_type{});
+    if (n_full < Nk) tile(n_full, buf, std::true_type{});
     // ---- epilogue: O[query][d] = O^T / l ----
 #pragma unroll
     for (int qi = 0; qi < QB; qi++) {

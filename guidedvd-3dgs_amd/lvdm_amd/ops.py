@@ -19,7 +19,7 @@ import torch.nn.functional as F
 _REFERENCE_MATH = False
 _LIB = None
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_diffusion.so")
+_LIB_PATH = os.environ.get("GVD_DIFFUSION_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libgvd_diffusion.so")  # env: A/B builds
 
 
 def use_reference_math(flag):
