@@ -176,6 +176,23 @@ def group_norm_math(x, groups, weight, bias, eps=1e-5, silu=False, channels_last
     return y.movedim(1, -1).contiguous() if channels_last else y
 
 
+def _f32_param(p):
+    """fp32 copy of a (frozen) 16-bit norm parameter, cached ON the parameter object until it is modified in place
+    (two tiny cast launches per GroupNorm call otherwise: ~4000 per U-Net forward)."""
+    if p.dtype == torch.float32:
+        return p.detach().contiguous()
+    if p.requires_grad:
+        return p.float().contiguous()
+    hit = getattr(p, "_gvd_f32", None)
+    if hit is None or hit[0] != p._version or hit[1] != p.data_ptr() or hit[2].device != p.device:
+        hit = (p._version, p.data_ptr(), p.detach().float().contiguous())
+        try:
+            p._gvd_f32 = hit
+        except AttributeError:
+            pass
+    return hit[2]
+
+
 def _gn_dims(x, channels_last):
     N = x.shape[0]
     C = x.shape[-1] if channels_last else x.shape[1]
@@ -195,8 +212,8 @@ def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=Fals
     N, C, S = _gn_dims(x, channels_last)
     y = torch.empty_like(x)
     stats = torch.empty(2 * N * groups + N * C, dtype=torch.float64, device=x.device)  # group sums + (a, b) per (n, c)
-    g = weight.float().contiguous()
-    b = bias.float().contiguous()
+    g = _f32_param(weight)
+    b = _f32_param(bias)
     P, LL = ctypes.c_void_p, ctypes.c_longlong
     bf = 1 if x.dtype == torch.bfloat16 else 0
     with torch.cuda.device(x.device):
