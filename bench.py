@@ -256,6 +256,8 @@ def ddim_main(args):
         with torch.device(dev):
             vae = AutoencoderKLDecoder(VIEWCRAFTER_VAE)
         vae = vae.half().eval()
+        if os.environ.get("GVD_VAE_TOKEN_MAJOR", "0") == "1":  # measured: 0.520 vs 0.533 steps/s for NCHW @576x1024 -> off
+            vae = vae.to_token_major()
         for p_ in list(unet.parameters()) + list(vae.parameters()):
             p_.requires_grad_(False)
 

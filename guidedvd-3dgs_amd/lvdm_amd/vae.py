@@ -16,8 +16,17 @@ def _norm(c):
     return nn.GroupNorm(32, c, eps=1e-6, affine=True)
 
 
+def _gn(gn, x, silu):
+    """GroupNorm(+swish) of a 4-D feature map in whichever memory format it is in: a channels_last tensor is
+    normalised through its [N, H, W, C] view by the token-major kernels (no NCHW round trip)."""
+    if x.dim() == 4 and x.shape[1] % 8 == 0 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last):
+        y = ops.group_norm(x.permute(0, 2, 3, 1), 32, gn.weight, gn.bias, gn.eps, silu=silu, channels_last=True)
+        return y.permute(0, 3, 1, 2)
+    return ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, silu=silu)
+
+
 def _gn_swish(gn, x):
-    return ops.group_norm(x, 32, gn.weight, gn.bias, gn.eps, silu=True)  # x*sigmoid(x) == SiLU
+    return _gn(gn, x, True)  # x*sigmoid(x) == SiLU
 
 
 class ResnetBlock(nn.Module):
@@ -47,7 +56,7 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
-        hn = ops.group_norm(x, 32, self.norm.weight, self.norm.bias, self.norm.eps)
+        hn = _gn(self.norm, x, False)
         tok = lambda t: t.flatten(2).transpose(1, 2)  # [b, hw, c]
         o = ops.attention(tok(self.q(hn)), tok(self.k(hn)), tok(self.v(hn)), heads=1)
         return x + self.proj_out(o.transpose(1, 2).reshape(b, c, h, w))
@@ -109,5 +118,18 @@ class AutoencoderKLDecoder(nn.Module):
         self.decoder = Decoder(**ddconfig)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
 
+        self._token_major = False
+
+    def to_token_major(self):
+        """Keep every feature map channels_last (NHWC convolution kernels, token-major GroupNorm): same values, same
+        state_dict; Conv2d weights are stored channels_last."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        self._token_major = True
+        return self
+
     def decode(self, z, **kwargs):
+        if self._token_major:
+            z = z.contiguous(memory_format=torch.channels_last)
         return self.decoder(self.post_quant_conv(z))

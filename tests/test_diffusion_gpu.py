@@ -324,3 +324,27 @@ def test_shard_group_group_norm_and_resharding_on_device_single_rank_group():
         assert torch.equal(shard.gather(tok, 0), tok)
     finally:
         dist.destroy_process_group()
+
+
+def test_vae_decoder_token_major_matches_nchw_forward_and_input_gradient():
+    """AutoencoderKLDecoder.to_token_major(): same module, channels_last feature maps (NHWC convolutions, token-major
+    GroupNorm kernels).  f16 on the device, compared with the NCHW path of the same weights; tolerance = 16-bit
+    rounding accumulated over the decoder depth, relative to the largest entry."""
+    from lvdm_amd.vae import AutoencoderKLDecoder
+    cfg = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4],
+               num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    vae = fill_by_name(AutoencoderKLDecoder(cfg), std=0.05).half().eval().to(DEV).requires_grad_(False)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    z = torch.randn(1, 4, 12, 20, device=DEV, generator=g).half()
+    outs = []
+    for tm in (False, True):
+        if tm:
+            vae.to_token_major()
+        zz = z.clone().requires_grad_(True)
+        y = vae.decode(zz)
+        (gz,) = torch.autograd.grad((y.float() ** 2).sum(), zz)
+        outs.append((y.float(), gz.float()))
+    (y0, g0), (y1, g1) = outs
+    assert y1.shape == (1, 3, 48, 80)
+    assert float((y0 - y1).abs().max()) < 2e-2 * float(y0.abs().max())
+    assert float((g0 - g1).abs().max()) < 3e-2 * float(g0.abs().max())
