@@ -18,6 +18,13 @@
 //   * O^T = V^T P^T accumulates in 32 fp32 registers, rescaled by the per-lane alpha of the online softmax.
 #include "diffusion_common.h"
 
+#ifndef GVD_ATTN_QMAJOR
+#define GVD_ATTN_QMAJOR 0
+#endif
+#ifndef GVD_ATTN_HOIST
+#define GVD_ATTN_HOIST 0   // 1 = pin the clustered LDS fragment reads with sched_barrier (measured 774 vs 788 TFLOP/s: off)
+#endif
+
 namespace gvdd {
 thread_local std::string g_err;
 int fail(int code, const char* what, hipError_t e)
@@ -132,16 +139,47 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         f16v s0[QB], s1[QB];
 #pragma unroll
         for (int qi = 0; qi < QB; qi++) { s0[qi] = f16v{}; s1[qi] = f16v{}; }
+        vec8 ka[4][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const vec8 a0 = *reinterpret_cast<const vec8*>(&sK[col][16 * ks + 8 * hi]);
-            const vec8 a1 = *reinterpret_cast<const vec8*>(&sK[32 + col][16 * ks + 8 * hi]);
+        for (int ks = 0; ks < 4; ks++) {   // all eight K fragments in flight before the first MFMA needs one
+            ka[ks][0] = *reinterpret_cast<const vec8*>(&sK[col][16 * ks + 8 * hi]);
+            ka[ks][1] = *reinterpret_cast<const vec8*>(&sK[32 + col][16 * ks + 8 * hi]);
+        }
+#if GVD_ATTN_HOIST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if GVD_ATTN_QMAJOR
 #pragma unroll
-            for (int qi = 0; qi < QB; qi++) {
-                s0[qi] = Tr<T>::mfma(a0, qf[qi][ks], s0[qi]);
-                s1[qi] = Tr<T>::mfma(a1, qf[qi][ks], s1[qi]);
+        for (int qi = 0; qi < QB; qi++) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                s0[qi] = Tr<T>::mfma(ka[ks][0], qf[qi][ks], s0[qi]);
+                s1[qi] = Tr<T>::mfma(ka[ks][1], qf[qi][ks], s1[qi]);
             }
         }
+#else
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int qi = 0; qi < QB; qi++) {
+                s0[qi] = Tr<T>::mfma(ka[ks][0], qf[qi][ks], s0[qi]);
+                s1[qi] = Tr<T>::mfma(ka[ks][1], qf[qi][ks], s1[qi]);
+            }
+        }
+#endif
+        // the V^T fragments of this tile are requested now and land under the softmax arithmetic
+        vec8 va[2][2][2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; kbk++)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const int kcol = 32 * kbk + 16 * k2 + 8 * hi;
+                va[kbk][k2][0] = *reinterpret_cast<const vec8*>(&sVt[col][kcol]);
+                va[kbk][k2][1] = *reinterpret_cast<const vec8*>(&sVt[32 + col][kcol]);
+            }
+#if GVD_ATTN_HOIST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- online softmax over this lane's 32 scores (+ the other half's 32); the 1/sqrt(d)*log2(e) scale is
         //      folded into the exp2 argument (one fma per score) ----
         //      Lazy rescaling: the running max m is only raised (and O, l rescaled -- 32 accumulator registers per query
@@ -208,14 +246,11 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         for (int kbk = 0; kbk < 2; kbk++) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++) {
-                const int kcol = 32 * kbk + 16 * k2 + 8 * hi;
-                const vec8 va0 = *reinterpret_cast<const vec8*>(&sVt[col][kcol]);
-                const vec8 va1 = *reinterpret_cast<const vec8*>(&sVt[32 + col][kcol]);
 #pragma unroll
                 for (int qi = 0; qi < QB; qi++) {
                     const vec8 pf = packed_c_to_b_operand<T>(kbk == 0 ? pk0[qi] : pk1[qi], k2);
-                    o0[qi] = Tr<T>::mfma(va0, pf, o0[qi]);
-                    o1[qi] = Tr<T>::mfma(va1, pf, o1[qi]);
+                    o0[qi] = Tr<T>::mfma(va[kbk][k2][0], pf, o0[qi]);
+                    o1[qi] = Tr<T>::mfma(va[kbk][k2][1], pf, o1[qi]);
                 }
             }
         }
