@@ -43,6 +43,11 @@ def main():
     ap.add_argument("--ddim-width", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-loss", choices=["none", "fused", "fused1", "torch"], default="none",
+                    help="raster: add the training loss 0.8 L1 + 0.2 (1 - SSIM) (train_baseline.py / train_guidedvd.py:339-340) "
+                         "between forward and backward: 'fused' = fused_loss HIP kernels, 'torch' = the reference's conv2d form")
+    ap.add_argument("--instance-capacity", type=int, default=0,
+                    help="raster: sync-free forward with this (Gaussian, tile) instance capacity (0 = reference behaviour)")
     ap.add_argument("--batch-cfg", action="store_true", help="ddim: evaluate cond/uncond as one batch-2 U-Net call")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -87,7 +92,30 @@ def main():
     gC = torch.randn((3, H, W), device=dev, generator=gen) / (H * W)
     params = [means3D, opac, scales, rots, shs, means2D]
 
+    if args.instance_capacity:
+        _C.set_instance_capacity(args.instance_capacity)
     R_seen = []
+    gt_img = torch.rand((3, H, W), device=dev, generator=gen)
+    loss_fn = None
+    if args.with_loss == "fused":
+        import fused_loss
+        loss_fn = lambda im: 0.8 * fused_loss.l1_loss(im, gt_img) + 0.2 * (1.0 - fused_loss.ssim(im, gt_img))
+    elif args.with_loss == "fused1":  # the whole photometric loss as one op
+        import fused_loss
+        loss_fn = lambda im: fused_loss.photometric_loss(im, gt_img, 0.2)[0]
+    elif args.with_loss == "torch":  # utils/loss_utils.py:36-82 restated with stock torch ops, for the comparison only
+        import torch.nn.functional as F
+        import fused_loss
+        g1 = fused_loss.gaussian(11, 1.5).to(dev)
+        win = (g1[:, None] @ g1[None, :])[None, None].expand(3, 1, 11, 11).contiguous()
+
+        def torch_ssim(a, b):
+            mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
+            s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1 * mu1
+            s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2 * mu2
+            s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
+            return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+        loss_fn = lambda im: 0.8 * torch.abs(im - gt_img).mean() + 0.2 * (1.0 - torch_ssim(im, gt_img))
 
     def step(i):
         s = cams[(i * world + rank) % len(cams)]
@@ -95,7 +123,10 @@ def main():
                                                            scales=scales, rotations=rots)
         for p_ in params:
             p_.grad = None
-        torch.autograd.backward([color], [gC])
+        if loss_fn is None:
+            torch.autograd.backward([color], [gC])
+        else:
+            loss_fn(color).backward()
         return color
 
     L = _C.lib()
@@ -153,6 +184,7 @@ def main():
     if rank == 0:
         # workload statistics for the algorithmic byte counts (mean over the cameras rank 0 used)
         Rs, vis = [], []
+        _C.set_instance_capacity(0)  # the statistics below need the exact num_rendered
         with torch.no_grad():
             for s in cams:
                 out = _C.rasterize_gaussians(bg, means3D.detach(), torch.Tensor([]), opac.detach(), scales.detach(), rots.detach(),
@@ -194,7 +226,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Replica-like room, raster fwd+bwd only",
+            "config": {"workload": "BASELINE configs[1]: Replica-like room, raster fwd+bwd only" if loss_fn is None else
+                       f"Replica-like room, raster fwd + loss 0.8 L1 + 0.2 (1 - SSIM) [{args.with_loss}] + bwd",
                        "gaussians": P, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cams),
                        "num_rendered_mean": int(R_mean), "visible_mean": int(vis_mean),
                        "mean_tile_list": round(R_mean / (((W + 15) // 16) * ((H + 15) // 16)), 1),

@@ -44,7 +44,7 @@ __device__ __forceinline__ void load_halo(const float* __restrict__ plane, int H
 
 __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, Gauss gw, int H, int W,
                                                   float* __restrict__ partials, float* __restrict__ dmaps, float* __restrict__ ssim_map,
-                                                  long long plane_stride_all)
+                                                  long long plane_stride_all, float* __restrict__ l1_partials)
 {
     __shared__ float sx[HALO][HALO + 1], sy[HALO][HALO + 1];
     __shared__ float hz[5][HALO][TILE + 1];
@@ -95,12 +95,43 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1
     float s = wave_sum(val);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) partials[((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    const size_t tile = ((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0) partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (l1_partials) {   // |x - y| of the same tile from the halo already in LDS (photometric loss: L1 term)
+        __syncthreads();
+        const float a = in ? fabsf(sx[ty + R][tx + R] - sy[ty + R][tx + R]) : 0.f;
+        s = wave_sum(a);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) l1_partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// loss = (1 - lambda) mean|x - y| + lambda (1 - mean ssim): fixed-order sums of the per-tile partials by one workgroup
+__global__ void __launch_bounds__(256) k_photo_finalize(const float* __restrict__ ssim_part, const float* __restrict__ l1_part, long long n,
+                                                        float inv_count, float lambda, float* __restrict__ out3)
+{
+    __shared__ double sh[2][256];
+    double a = 0.0, b = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) { a += (double)ssim_part[i]; b += (double)l1_part[i]; }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) {
+        if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ssim_mean = (float)(sh[0][0] * inv_count), l1_mean = (float)(sh[1][0] * inv_count);
+        out3[0] = (1.f - lambda) * l1_mean + lambda * (1.f - ssim_mean);
+        out3[1] = l1_mean;
+        out3[2] = ssim_mean;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, Gauss gw, int H, int W,
                                                   const float* __restrict__ dmaps, const float* __restrict__ plane_scale,
-                                                  float* __restrict__ d_img1, long long plane_stride_all)
+                                                  float* __restrict__ d_img1, long long plane_stride_all,
+                                                  const float* __restrict__ upstream, float w_ssim, float w_l1)
 {
     __shared__ float sm[3][HALO][HALO + 1];
     __shared__ float hz[3][HALO][TILE + 1];
@@ -130,7 +161,13 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1
     const int x = x0 + tx, y = y0 + ty;
     if (x < W && y < H) {
         const size_t p = poff + (size_t)y * W + x;
-        d_img1[p] = plane_scale[plane] * (a + 2.f * img1[p] * b + img2[p] * d);
+        const float xv = img1[p], yv = img2[p], gs = a + 2.f * xv * b + yv * d;
+        if (upstream) {   // photometric loss: upstream * (w_ssim dssim + w_l1 sign(x - y))
+            const float df = xv - yv, sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            d_img1[p] = upstream[0] * (w_ssim * gs + w_l1 * sg);
+        } else {
+            d_img1[p] = plane_scale[plane] * gs;
+        }
     }
 }
 
@@ -162,9 +199,43 @@ int gvd_ssim_forward(const float* img1, const float* img2, const float* gauss, i
     for (int i = 0; i < 11; i++) gw.g[i] = gauss[i];
     dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, planes);
     hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, (hipStream_t)stream_, img1, img2, gw, H, W, partials, dmaps, ssim_map,
-                       (long long)planes * H * W);
+                       (long long)planes * H * W, (float*)nullptr);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_ssim_fwd", e);
+    return 0;
+}
+
+int gvd_photometric_forward(const float* img1, const float* img2, const float* gauss, int planes, int H, int W, float lambda_dssim,
+                            float* partials, float* dmaps, float* out3, void* stream_)
+{
+    if (int rc = check("gvd_photometric_forward", img1, img2, gauss, planes, H, W)) return rc;
+    if (!partials || !out3) return fail(-1, "gvd_photometric_forward: null pointer");
+    Gauss gw;
+    for (int i = 0; i < 11; i++) gw.g[i] = gauss[i];
+    dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, planes);
+    const long long n = gvd_ssim_partial_count(planes, H, W);
+    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, (hipStream_t)stream_, img1, img2, gw, H, W, partials, dmaps, (float*)nullptr,
+                       (long long)planes * H * W, partials + n);
+    hipLaunchKernelGGL(k_photo_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream_, (const float*)partials, (const float*)(partials + n), n,
+                       1.0f / ((float)planes * (float)H * (float)W), lambda_dssim, out3);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_photo_*", e);
+    return 0;
+}
+
+int gvd_photometric_backward(const float* img1, const float* img2, const float* gauss, const float* dmaps, const float* upstream,
+                             int planes, int H, int W, float lambda_dssim, float* d_img1, void* stream_)
+{
+    if (int rc = check("gvd_photometric_backward", img1, img2, gauss, planes, H, W)) return rc;
+    if (!dmaps || !upstream || !d_img1) return fail(-1, "gvd_photometric_backward: null pointer");
+    Gauss gw;
+    for (int i = 0; i < 11; i++) gw.g[i] = gauss[i];
+    dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, planes);
+    const float inv = 1.0f / ((float)planes * (float)H * (float)W);
+    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, (hipStream_t)stream_, img1, img2, gw, H, W, dmaps, (const float*)nullptr, d_img1,
+                       (long long)planes * H * W, upstream, -lambda_dssim * inv, (1.f - lambda_dssim) * inv);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_ssim_bwd (photometric)", e);
     return 0;
 }
 
@@ -177,7 +248,7 @@ int gvd_ssim_backward(const float* img1, const float* img2, const float* gauss, 
     for (int i = 0; i < 11; i++) gw.g[i] = gauss[i];
     dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, planes);
     hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, (hipStream_t)stream_, img1, img2, gw, H, W, dmaps, plane_scale, d_img1,
-                       (long long)planes * H * W);
+                       (long long)planes * H * W, (const float*)nullptr, 0.f, 0.f);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_ssim_bwd", e);
     return 0;

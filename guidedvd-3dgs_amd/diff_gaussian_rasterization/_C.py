@@ -104,6 +104,35 @@ class _Chunk:
         return self.tensor.data_ptr()
 
 
+# ---- opt-in sync-free forward -----------------------------------------------------------------------------------
+# The reference's forward returns num_rendered as a host int (rasterize_points.cu:35-115), which costs one device->host
+# round trip per render and stops the host from queueing the loss and the backward while the forward still runs.
+# With an instance capacity set (set_instance_capacity(n) or GVD_RASTER_CAPACITY=n) the binning chunk is sized for n
+# instances up front, nothing is read back, `num_rendered` is reported as n, and an overflow (more than n instances)
+# raises at the NEXT rasterize call of the process (the flag has landed by then; that render showed background only).
+_CAPACITY = int(os.environ.get("GVD_RASTER_CAPACITY", "0") or 0)
+_PENDING = []   # (event, pinned int32 tensor) of earlier capped calls whose status has not been looked at yet
+
+
+def set_instance_capacity(n):
+    """0 = reference behaviour (one sync per forward, exact num_rendered); n > 0 = sync-free forward for up to n
+    (Gaussian, tile) instances per render."""
+    global _CAPACITY
+    _CAPACITY = int(n)
+
+
+def _drain_status(block=False):
+    while _PENDING:
+        ev, host = _PENDING[0]
+        if not block and not ev.query():
+            return
+        ev.synchronize()
+        _PENDING.pop(0)
+        if int(host[0]) != 0:
+            raise RuntimeError(f"diff_gaussian_rasterization: a sync-free forward exceeded the instance capacity "
+                               f"({_CAPACITY}); raise it with set_instance_capacity() / GVD_RASTER_CAPACITY")
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug):
@@ -125,6 +154,26 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         out_alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        if _CAPACITY > 0 and P > 0:
+            _drain_status()
+            u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+            geom_t, img_t = u8(L.gvd_raster_geometry_bytes(P, W, H)), u8(L.gvd_raster_image_bytes(W, H))
+            bin_t = u8(L.gvd_raster_binning_bytes(_CAPACITY))
+            status = torch.empty(1, dtype=torch.int32, device=dev)
+            rc = L.gvd_raster_forward_capped(geom_t.data_ptr(), bin_t.data_ptr(), img_t.data_ptr(), _CAPACITY, P, int(degree), M,
+                                             _ptr(bg), W, H, _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa), _ptr(sc),
+                                             float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cam),
+                                             float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), out_color.data_ptr(),
+                                             out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr(), status.data_ptr(),
+                                             int(bool(debug)), _stream())
+            if rc < 0:
+                raise _err(rc)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _PENDING.append((ev, host))
+            return _CAPACITY, out_color, out_depth, out_alpha, radii, geom_t, bin_t, img_t
         geom, binning, img = _Chunk(dev), _Chunk(dev), _Chunk(dev)
         rc = L.gvd_raster_forward(geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H,
                                   _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot),

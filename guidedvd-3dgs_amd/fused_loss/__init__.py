@@ -118,3 +118,56 @@ def ssim(img1, img2, mask=None, window_size=11, size_average=True):
         img1, img2 = img1[None], img2[None]
     out = _SSIM.apply(img1, img2, not size_average)
     return out
+
+
+class _Photometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        x = image.detach().contiguous().float()
+        y = gt.detach().contiguous().float()
+        if x.dim() == 3:
+            x, y = x[None], y[None]
+        N, C, H, W = x.shape
+        planes = N * C
+        need_grad = image.requires_grad
+        L = lib()
+        partials = torch.empty(2 * L.gvd_ssim_partial_count(planes, H, W), dtype=torch.float32, device=x.device)
+        dmaps = torch.empty((3, planes, H, W), dtype=torch.float32, device=x.device) if need_grad else None
+        out3 = torch.empty(3, dtype=torch.float32, device=x.device)
+        P = ctypes.c_void_p
+        with torch.cuda.device(x.device):
+            _check(L.gvd_photometric_forward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, planes, H, W, ctypes.c_float(lambda_dssim),
+                                             P(partials.data_ptr()), P(dmaps.data_ptr() if need_grad else None),
+                                             P(out3.data_ptr()), P(torch.cuda.current_stream().cuda_stream)))
+        ctx.cfg = (planes, H, W, float(lambda_dssim), image.shape)
+        if need_grad:
+            ctx.save_for_backward(x, y, dmaps)
+        ctx.mark_non_differentiable(out3)
+        return out3[0], out3
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        x, y, dmaps = ctx.saved_tensors
+        planes, H, W, lam, shape = ctx.cfg
+        d = torch.empty_like(x)
+        g = g.detach().float().contiguous()
+        P = ctypes.c_void_p
+        with torch.cuda.device(x.device):
+            _check(lib().gvd_photometric_backward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, P(dmaps.data_ptr()), P(g.data_ptr()),
+                                                  planes, H, W, ctypes.c_float(lam), P(d.data_ptr()),
+                                                  P(torch.cuda.current_stream().cuda_stream)))
+        return d.view(shape), None, None
+
+
+def photometric_loss(image, gt_image, lambda_dssim=0.2):
+    """The two lines train_guidedvd.py:339-340 / train_baseline.py in one fused pass:
+
+        Ll1  = l1_loss_mask(image, gt_image)
+        loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image))
+
+    Returns (loss, stats) with stats = device tensor [loss, Ll1, ssim] (no gradient) for logging."""
+    if not image.is_cuda or not gt_image.is_cuda:
+        raise RuntimeError("fused_loss.photometric_loss: tensors must live on a ROCm device (this build has no CPU path)")
+    if gt_image.requires_grad:
+        raise NotImplementedError("fused photometric loss: the ground-truth image is a constant")
+    return _Photometric.apply(image, gt_image, float(lambda_dssim))

@@ -28,6 +28,18 @@ int gvd_ssim_forward(const float* img1, const float* img2, const float* gauss, i
 int gvd_ssim_backward(const float* img1, const float* img2, const float* gauss, const float* dmaps, const float* plane_scale,
                       int planes, int H, int W, float* d_img1, void* stream);
 
+/* The training loss of train_baseline.py / train_guidedvd.py:339-340 in one pass,
+ *     loss = (1 - lambda_dssim) * mean|img1 - img2| + lambda_dssim * (1 - mean ssim_map),
+ * out3 (DEVICE) = {loss, L1 mean, ssim mean}.  partials: 2 * gvd_ssim_partial_count floats of device scratch;
+ * dmaps as in gvd_ssim_forward (needed for the backward, may be NULL for evaluation only). */
+int gvd_photometric_forward(const float* img1, const float* img2, const float* gauss, int planes, int H, int W,
+                            float lambda_dssim, float* partials, float* dmaps, float* out3, void* stream);
+
+/* d loss / d img1 times the DEVICE scalar `upstream`. */
+int gvd_photometric_backward(const float* img1, const float* img2, const float* gauss, const float* dmaps,
+                             const float* upstream, int planes, int H, int W, float lambda_dssim, float* d_img1,
+                             void* stream);
+
 const char* gvd_loss_last_error(void);
 
 #ifdef __cplusplus

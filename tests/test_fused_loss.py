@@ -42,7 +42,8 @@ def test_loss_library_exports_and_host_helpers():
     import fused_loss as fl
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gvd_loss.h")).read(), flags=re.S)
     names = set(re.findall(r"\b(gvd_[a-z_0-9]+)\s*\(", hdr))
-    assert {"gvd_ssim_forward", "gvd_ssim_backward", "gvd_ssim_partial_count", "gvd_loss_last_error"} <= names
+    assert {"gvd_ssim_forward", "gvd_ssim_backward", "gvd_ssim_partial_count", "gvd_loss_last_error",
+            "gvd_photometric_forward", "gvd_photometric_backward"} <= names
     L = fl.lib()
     for n in sorted(names):
         assert hasattr(L, n), f"libgvd_loss.so does not export {n}"
@@ -101,3 +102,21 @@ def test_fused_ssim_full_size_against_the_oracle_and_properties():
     xx = y.clone().requires_grad_(True)
     one = fl.ssim(xx, y)
     assert abs(float(one) - 1.0) < 1e-6 and float(torch.autograd.grad(one, xx)[0].abs().max()) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "d"])
+def test_fused_photometric_loss_equals_its_two_term_form_and_the_goldens(tag):
+    """loss = 0.8 L1 + 0.2 (1 - ssim) (train_guidedvd.py:339-340) as one op: value from the reference goldens of both
+    terms; gradient = 0.8 sign(x - y)/N - 0.2 * golden ssim gradient (tolerance as for ssim alone)."""
+    import fused_loss as fl
+    x = torch.tensor(G[f"{tag}_x"], device="cuda:0").requires_grad_(True)
+    y = torch.tensor(G[f"{tag}_y"], device="cuda:0")
+    loss, stats = fl.photometric_loss(x, y, 0.2)
+    (g,) = torch.autograd.grad(loss * 3.0, x)   # non-trivial upstream factor
+    ref = 0.8 * float(G[f"{tag}_l1"]) + 0.2 * (1.0 - float(G[f"{tag}_ssim"]))
+    assert abs(float(loss) - ref) < 3e-6
+    assert abs(float(stats[1]) - float(G[f"{tag}_l1"])) < 2e-6 and abs(float(stats[2]) - float(G[f"{tag}_ssim"])) < 2e-6
+    gref = 3.0 * (0.8 * np.sign(G[f"{tag}_x"] - G[f"{tag}_y"]) / G[f"{tag}_x"].size - 0.2 * G[f"{tag}_grad"])
+    assert g.shape == x.shape and np.abs(g.cpu().numpy() - gref).max() < 1e-4 * np.abs(gref).max()
+    assert not stats.requires_grad

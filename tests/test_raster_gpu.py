@@ -295,3 +295,44 @@ def test_full_size_properties():
     for key in ga:
         lin = 0.7 * ga[key] - 1.3 * gb[key]
         assert rel_to_max(gm[key], lin) < 1e-4, key  # fp32 rounding of the cancelling rotation/scale terms
+
+
+def test_operator_sync_free_mode_matches_and_reports_overflow_late():
+    """set_instance_capacity(n): the drop-in operator renders and differentiates without the host read-back; images and
+    gradients are bit-identical to the default mode; an overflow raises at the next rasterize call."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    dev = torch.device("cuda:0")
+    sc = syn.scene_c1()
+    cam = sc["cameras"][0]
+    t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev, requires_grad=rg)
+    P = sc["means3D"].shape[0]
+
+    def run():
+        prm = [t(sc[k], True) for k in ("means3D", "opacities", "scales", "rotations", "shs")]
+        m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+        s = GaussianRasterizationSettings(image_height=128, image_width=128, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                          bg=t(sc["bg"]), scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]),
+                                          projmatrix=t(cam["projmatrix"]), sh_degree=3, campos=t(cam["campos"]),
+                                          prefiltered=False, debug=False, confidence=torch.ones((P, 1), device=dev))
+        color, radii, depth, alpha = GaussianRasterizer(s)(means3D=prm[0], means2D=m2, opacities=prm[1], shs=prm[4],
+                                                           scales=prm[2], rotations=prm[3])
+        g = torch.Generator(device=dev).manual_seed(5)
+        (color * torch.randn(color.shape, device=dev, generator=g)).sum().backward()
+        return [color.detach(), depth.detach(), alpha.detach(), radii] + [p.grad for p in prm] + [m2.grad]
+
+    ref = run()
+    try:
+        _C.set_instance_capacity(20000)
+        got = run()
+        torch.cuda.synchronize()
+        _C._drain_status(block=True)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        _C.set_instance_capacity(500)   # too small for this view
+        run()
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="instance capacity"):
+            run()
+    finally:
+        _C._PENDING.clear()
+        _C.set_instance_capacity(0)
