@@ -234,3 +234,29 @@ def test_diffusion_library_exports_every_declared_symbol():
     L = ops.lib()
     for n in sorted(names):
         assert hasattr(L, n), f"libgvd_diffusion.so does not export {n}"
+
+
+@pytest.mark.parametrize("tag,no_guidance", [("plain", True), ("guided", False)])
+def test_pipeline_entry_matches_the_reference_image_guided_synthesis(tag, no_guidance):
+    """lvdm_amd.pipeline.{run_video_diffusion, run_diffusion, image_guided_synthesis} against the video
+    the REFERENCE's image_guided_synthesis produced with its own samplers on the same stand-in model
+    (tests/golden/make_golden_pipeline.py): conditioning dicts, RNG order, 4 DDIM steps, decode.  fp32 CPU."""
+    import pipeline_duck as pd
+    from lvdm_amd import pipeline
+    from lvdm_amd.guidance import LossGuidance
+    from lvdm_amd.schedule import DiffusionSchedule
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_ref.npz"))[f"{tag}_video"]
+    duck = pd.PipeDuck(DiffusionSchedule())
+    renderings, guide, masks, noise_shape = pd.inputs()
+    lg = None
+    if not no_guidance:
+        lg = LossGuidance(ddim_steps=pd.Opts.ddim_steps, recur_steps=1, device="cpu")
+        lg.set_hw(renderings.shape[1], renderings.shape[2])
+    torch.manual_seed(123)
+    frames = pipeline.run_video_diffusion(duck, renderings, noise_shape, pd.Opts, lg, guidance_images=guide,
+                                          guidance_masks=masks, no_guidance=no_guidance)
+    assert frames.shape == (renderings.shape[0], 3, renderings.shape[1], renderings.shape[2])
+    want = (np.clip(ref[0, 0].transpose(1, 2, 3, 0), -1, 1) + 1.0) / 2.0          # [T,H,W,3] in [0,1]
+    got = frames.detach().permute(0, 2, 3, 1).numpy()
+    assert 0.05 < want.std()                                                       # not a saturated / constant video
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
