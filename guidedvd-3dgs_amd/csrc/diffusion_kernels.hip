@@ -738,6 +738,104 @@ __global__ void __launch_bounds__(256) k_geglu(const T* __restrict__ h, T* __res
     }
 }
 
+// LayerNorm backward w.r.t. the input (weights frozen: guided sampler).  x_hat = (x - mu) rstd, g = dy gamma,
+// dx = rstd (g - mean(g) - x_hat mean(g x_hat)).  One wave per row, statistics recomputed from the row in registers.
+template <typename T>
+__global__ void __launch_bounds__(256) k_layer_norm_bwd(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ gamma,
+                                                        T* __restrict__ dx, long long M, int C, float eps)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int lane = threadIdx.x & 63, oct = C >> 3;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * C;
+    const T* gr = dy + row * C;
+    vec8 v[4], g[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int o = lane + 64 * j;
+        if (o < oct) {
+            v[j] = *reinterpret_cast<const vec8*>(xr + o * 8);
+            g[j] = *reinterpret_cast<const vec8*>(gr + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += to_f(v[j][k]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (lane + 64 * j < oct) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float d = to_f(v[j][k]) - mean; q = fmaf(d, d, q); }
+        }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    float sg = 0.f, sgx = 0.f;
+    float gg[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int o = lane + 64 * j;
+        if (o < oct) {
+            const vec8 gm = *reinterpret_cast<const vec8*>(gamma + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float gk = to_f(g[j][k]) * to_f(gm[k]);
+                gg[j][k] = gk;
+                sg += gk;
+                sgx = fmaf(gk, (to_f(v[j][k]) - mean) * rstd, sgx);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgx += __shfl_xor(sgx, off, 64); }
+    const float mg = sg / (float)C, mgx = sgx / (float)C;
+    T* dr = dx + row * C;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int o = lane + 64 * j;
+        if (o < oct) {
+            vec8 r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = (T)(rstd * (gg[j][k] - mg - (to_f(v[j][k]) - mean) * rstd * mgx));
+            *reinterpret_cast<vec8*>(dr + o * 8) = r;
+        }
+    }
+}
+
+// GEGLU backward: y = a gelu(g) for h = [a | g]:  da = dy gelu(g),  dg = dy a gelu'(g),
+// gelu'(g) = 0.5 (1 + erf(g / sqrt 2)) + g exp(-g^2 / 2) / sqrt(2 pi).
+template <typename T>
+__global__ void __launch_bounds__(256) k_geglu_bwd(const T* __restrict__ h, const T* __restrict__ dy, T* __restrict__ dh, long long M, int C)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int oct = C >> 3;
+    const long long total = M * oct, step = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) {
+        const long long m = i / oct;
+        const int o = (int)(i - m * oct);
+        const T* hr = h + m * 2 * C + o * 8;
+        const vec8 a = *reinterpret_cast<const vec8*>(hr), g = *reinterpret_cast<const vec8*>(hr + C);
+        const vec8 d = *reinterpret_cast<const vec8*>(dy + m * C + o * 8);
+        vec8 ra, rg;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float gf = to_f(g[k]), df = to_f(d[k]);
+            const float cdf = 0.5f * (1.f + erff(gf * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * gf * gf);
+            ra[k] = (T)(df * gf * cdf);
+            rg[k] = (T)(df * to_f(a[k]) * fmaf(gf, pdf, cdf));
+        }
+        T* dr = dh + m * 2 * C + o * 8;
+        *reinterpret_cast<vec8*>(dr) = ra;
+        *reinterpret_cast<vec8*>(dr + C) = rg;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -961,6 +1059,34 @@ int gvd_geglu(const void* h, void* y, long long M, int C, int is_bf16, void* str
     else hipLaunchKernelGGL(k_geglu<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)h, (_Float16*)y, M, C);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_geglu", e);
+    return 0;
+}
+
+int gvd_layer_norm_bwd(const void* x, const void* dy, const void* gamma, void* dx, long long M, int C, float eps, int is_bf16,
+                       void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !dy || !gamma || !dx || M <= 0 || C <= 0 || (C % 8) || C > 2048) return fail(-1, "gvd_layer_norm_bwd: bad arguments (C % 8 == 0, C <= 2048)");
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx) & 15) return fail(-1, "gvd_layer_norm_bwd: pointers must be 16-byte aligned");
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (is_bf16) hipLaunchKernelGGL(k_layer_norm_bwd<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (const __bf16*)gamma, (__bf16*)dx, M, C, eps);
+    else hipLaunchKernelGGL(k_layer_norm_bwd<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (const _Float16*)gamma, (_Float16*)dx, M, C, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_layer_norm_bwd", e);
+    return 0;
+}
+
+int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h || !dy || !dh || M <= 0 || C <= 0 || (C % 8)) return fail(-1, "gvd_geglu_bwd: bad arguments (C % 8 == 0)");
+    if (((uintptr_t)h | (uintptr_t)dy | (uintptr_t)dh) & 15) return fail(-1, "gvd_geglu_bwd: pointers must be 16-byte aligned");
+    const long long vecs = M * (C / 8);
+    const int blocks = (int)((vecs + 255) / 256 < 32768 ? (vecs + 255) / 256 : 32768);
+    if (is_bf16) hipLaunchKernelGGL(k_geglu_bwd<__bf16>, dim3(blocks), dim3(256), 0, stream, (const __bf16*)h, (const __bf16*)dy, (__bf16*)dh, M, C);
+    else hipLaunchKernelGGL(k_geglu_bwd<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)h, (const _Float16*)dy, (_Float16*)dh, M, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_geglu_bwd", e);
     return 0;
 }
 

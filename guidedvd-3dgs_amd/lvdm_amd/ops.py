@@ -314,15 +314,62 @@ def _hip_layer_norm(x, weight, bias, eps):
     return y
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """Row LayerNorm kernels, forward and input gradient (weights frozen: guided sampler)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc, weight)
+        ctx.eps = eps
+        return _hip_layer_norm(xc, weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        C = x.shape[-1]
+        gx = torch.empty_like(x)
+        P = ctypes.c_void_p
+        with torch.cuda.device(x.device):
+            _check(lib().gvd_layer_norm_bwd(P(x.data_ptr()), P(gy.data_ptr()), P(weight.data_ptr()), P(gx.data_ptr()),
+                                            ctypes.c_longlong(x.numel() // C), C, ctypes.c_float(ctx.eps),
+                                            1 if x.dtype == torch.bfloat16 else 0, P(_stream())))
+        return gx, None, None, None
+
+
+class _GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        hc = h.contiguous()
+        ctx.save_for_backward(hc)
+        return _hip_geglu(hc)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (h,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        C = h.shape[-1] // 2
+        gh = torch.empty_like(h)
+        P = ctypes.c_void_p
+        with torch.cuda.device(h.device):
+            _check(lib().gvd_geglu_bwd(P(h.data_ptr()), P(gy.data_ptr()), P(gh.data_ptr()), ctypes.c_longlong(h.numel() // (2 * C)),
+                                       C, 1 if h.dtype == torch.bfloat16 else 0, P(_stream())))
+        return gh
+
+
 def layer_norm(x, weight, bias, eps=1e-5):
     """nn.LayerNorm over the last dim (attention.py:283-285).  HIP kernel for no-grad 16-bit activations with 16-bit
     affine; everything else (fp32 parity runs, autocast with fp32 weights, the guided sampler's autograd pass) takes
     F.layer_norm, which is what the reference calls."""
     on_dev = _require_device(x, "layer_norm")
     C = x.shape[-1]
-    if (on_dev and _half_pair(x, weight, bias) and C % 8 == 0 and C <= 2048
-            and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))):
-        return _hip_layer_norm(x, weight, bias, eps)
+    if on_dev and _half_pair(x, weight, bias) and C % 8 == 0 and C <= 2048:
+        grad = torch.is_grad_enabled()
+        if not (grad and (x.requires_grad or weight.requires_grad or bias.requires_grad)):
+            return _hip_layer_norm(x, weight, bias, eps)
+        if not (weight.requires_grad or bias.requires_grad):   # guided sampler: input gradient only
+            return _LayerNormFn.apply(x, weight, bias, eps)
     return F.layer_norm(x, (C,), weight, bias, eps)
 
 
@@ -335,17 +382,22 @@ def geglu(h):
     """x * gelu(gate) on the two halves of the GEGLU projection (attention.py:420-423)."""
     on_dev = _require_device(h, "geglu")
     C = h.shape[-1] // 2
-    if (on_dev and h.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0
-            and not (torch.is_grad_enabled() and h.requires_grad)):
-        h = h.contiguous()
-        y = torch.empty(h.shape[:-1] + (C,), dtype=h.dtype, device=h.device)
-        with torch.cuda.device(h.device):
-            rc = lib().gvd_geglu(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(y.data_ptr()),
-                                 ctypes.c_longlong(h.numel() // (2 * C)), C,
-                                 1 if h.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
-        _check(rc)
-        return y
+    if on_dev and h.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0:
+        if torch.is_grad_enabled() and h.requires_grad:
+            return _GegluFn.apply(h)
+        return _hip_geglu(h.contiguous())
     return geglu_math(h)
+
+
+def _hip_geglu(h):
+    C = h.shape[-1] // 2
+    y = torch.empty(h.shape[:-1] + (C,), dtype=h.dtype, device=h.device)
+    with torch.cuda.device(h.device):
+        rc = lib().gvd_geglu(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                             ctypes.c_longlong(h.numel() // (2 * C)), C,
+                             1 if h.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
+    _check(rc)
+    return y
 
 
 # --------------------------------------------------------------------------------------------------

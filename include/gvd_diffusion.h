@@ -99,6 +99,13 @@ int gvd_layer_norm(const void* x, void* y, const void* gamma, const void* beta, 
  * Replaces `x, gate = self.proj(x).chunk(2, dim=-1); return x * F.gelu(gate)` (lvdm/modules/attention.py:420-423). */
 int gvd_geglu(const void* h, void* y, long long M, int C, int is_bf16, void* stream);
 
+/* Input gradients of the two ops above for the guided sampler's autograd pass (weights frozen):
+ *   gvd_layer_norm_bwd : dx [M, C] from x, dy and gamma (statistics recomputed per row)
+ *   gvd_geglu_bwd      : dh [M, 2C] from h [M, 2C] and dy [M, C] */
+int gvd_layer_norm_bwd(const void* x, const void* dy, const void* gamma, void* dx, long long M, int C, float eps,
+                       int is_bf16, void* stream);
+int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, int is_bf16, void* stream);
+
 const char* gvd_diff_last_error(void);
 
 #ifdef __cplusplus

@@ -230,7 +230,8 @@ def test_diffusion_library_exports_every_declared_symbol():
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "gvd_diffusion.h")).read(), flags=re.S)
     names = set(re.findall(r"\b(gvd_[a-z_0-9]+)\s*\(", hdr))
     assert {"gvd_attention_fwd", "gvd_attention_fwd_strided", "gvd_ddim_step", "gvd_group_norm", "gvd_layer_norm",
-            "gvd_geglu", "gvd_diff_last_error"} <= names
+            "gvd_geglu", "gvd_diff_last_error", "gvd_layer_norm_bwd", "gvd_geglu_bwd", "gvd_attention_bwd_strided",
+            "gvd_group_norm_bwd", "gvd_group_norm_stats", "gvd_group_norm_apply"} <= names
     L = ops.lib()
     for n in sorted(names):
         assert hasattr(L, n), f"libgvd_diffusion.so does not export {n}"

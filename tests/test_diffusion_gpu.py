@@ -348,3 +348,30 @@ def test_vae_decoder_token_major_matches_nchw_forward_and_input_gradient():
     assert y1.shape == (1, 3, 48, 80)
     assert float((y0 - y1).abs().max()) < 2e-2 * float(y0.abs().max())
     assert float((g0 - g1).abs().max()) < 3e-2 * float(g0.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (33, 1280), (3, 8)])
+def test_layer_norm_and_geglu_input_gradients_match_fp32_autograd(dtype, M, C):
+    """The guided sampler's autograd pass: dx of LayerNorm (frozen affine) and dh of GEGLU vs fp32 autograd of the same
+    ops; tolerance = one rounding of the 16-bit result relative to the largest gradient entry."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + C)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    x = (torch.randn(M, C, device=DEV, generator=g) * 1.7 + 0.3).to(dtype).requires_grad_(True)
+    w = (torch.randn(C, device=DEV, generator=g) * 0.3 + 1).to(dtype)
+    b = (torch.randn(C, device=DEV, generator=g) * 0.2).to(dtype)
+    gy = torch.randn(M, C, device=DEV, generator=g).to(dtype)
+    y = ops.layer_norm(x, w, b, 1e-5)
+    assert "LayerNormFn" in type(y.grad_fn).__name__
+    (gx,) = torch.autograd.grad(y, x, gy)
+    xf = x.detach().float().requires_grad_(True)
+    (rx,) = torch.autograd.grad(torch.nn.functional.layer_norm(xf, (C,), w.float(), b.float(), 1e-5), xf, gy.float())
+    assert float((gx.float() - rx).abs().max()) < tol * float(rx.abs().max())
+    h = (torch.randn(M, 2 * C, device=DEV, generator=g) * 1.5).to(dtype).requires_grad_(True)
+    yh = ops.geglu(h)
+    assert "GegluFn" in type(yh.grad_fn).__name__
+    (gh,) = torch.autograd.grad(yh, h, gy)
+    hf = h.detach().float().requires_grad_(True)
+    (rh,) = torch.autograd.grad(ops.geglu_math(hf), hf, gy.float())
+    assert gh.shape == h.shape and float((gh.float() - rh).abs().max()) < tol * float(rh.abs().max())
