@@ -436,12 +436,12 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;  // overflowed forward: render background, status already flagged
 
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, D = 0.f;
+    float T = inside ? 1.0f : 0.0f, T_keep = 1.0f;   // live transmittance (0 = pixel finished) / value kept for the background
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
 
     for (uint32_t b = r0; b < r1; b += 256) {
-        const int num_done = __syncthreads_count(done);
+        const int num_done = __syncthreads_count(T == 0.0f);
         if (num_done == 256) break;
         // ---- stage + cull + compact ----
         const uint32_t e = b + tid;
@@ -479,28 +479,33 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         // T-recurrence is serial.  Per-pixel semantics are exactly forward.cu:329-368: an entry
         // contributes iff power<=0, alpha>=1/255 and the pixel is not done; the first entry with
         // T*(1-alpha) < 1e-4 marks the pixel done and is not blended.
+// `done` is folded into the running transmittance: T is the LIVE transmittance (0 once the pixel has stopped, so
+// every later product is exactly 0) and T_keep holds the value the reference keeps for the background term.  An
+// entry the reference skips (power > 0 or alpha < 1/255) runs with alpha = 0: test_T == T exactly and every
+// accumulator gets +0.  The per-entry critical path is then mul -> v_cmp -> v_cndmask on the VALU only (the old form
+// went VALU -> SALU mask logic -> VALU through `done` on every entry).
 #define GVD_BLEND_ONE(XY, CO, CD, POS)                                                            \
         {                                                                                         \
             const float dx = (XY).x - pixfx, dy = (XY).y - pixfy;                                 \
             const float power = gauss_power((CO).x, (CO).y, (CO).z, dx, dy);                      \
-            const float alpha = fminf(0.99f, (CO).w * __expf(power));                             \
-            const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);              \
+            const float alpha_raw = fminf(0.99f, (CO).w * __expf(power));                         \
+            const bool hit = !(power > 0.0f) && !(alpha_raw < 1.0f / 255.0f);                     \
+            const float alpha = hit ? alpha_raw : 0.0f;                                           \
             const float test_T = T * (1.f - alpha);                                               \
-            const bool stop = valid && (test_T < 0.0001f);                                        \
-            const bool contrib = valid && !stop;                                                  \
-            done = done || stop;                                                                  \
-            const float Tc = contrib ? T : 0.0f;                                                  \
+            const bool go = !(test_T < 0.0001f);        /* false when stopping now or already stopped (T == 0) */ \
+            const float Tc = go ? T : 0.0f;                                                       \
             C0 = fmaf((CD).x * alpha, Tc, C0);                                                    \
             C1 = fmaf((CD).y * alpha, Tc, C1);                                                    \
             C2 = fmaf((CD).z * alpha, Tc, C2);                                                    \
             weight = fmaf(alpha, Tc, weight);                                                     \
             D = fmaf((CD).w * alpha, Tc, D);                                                      \
-            T = contrib ? test_T : T;                                                             \
-            last_contributor = contrib ? (POS) : last_contributor;                                \
+            T_keep = go ? test_T : T_keep;                                                        \
+            T = go ? test_T : 0.0f;                                                               \
+            last_contributor = (go && hit) ? (POS) : last_contributor;                            \
         }
         uint32_t j = 0;
         for (; j + 4 <= n; j += 4) {
-            if (__all(done)) break;  // wave-uniform: this strip is finished
+            if (__all(T == 0.0f)) break;  // wave-uniform: this strip is finished
             const float2 xy0 = s_xy[j], xy1 = s_xy[j + 1], xy2 = s_xy[j + 2], xy3 = s_xy[j + 3];
             const float4 co0 = s_co[j], co1 = s_co[j + 1], co2 = s_co[j + 2], co3 = s_co[j + 3];
             const float4 cd0 = s_cd[j], cd1 = s_cd[j + 1], cd2 = s_cd[j + 2], cd3 = s_cd[j + 3];
@@ -523,9 +528,9 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         const size_t pid = (size_t)py * a.W + px;
         const size_t HW = (size_t)a.H * a.W;
         a.n_contrib[pid] = last_contributor;
-        a.out_color[pid] = fmaf(T, a.bg[0], C0);
-        a.out_color[HW + pid] = fmaf(T, a.bg[1], C1);
-        a.out_color[2 * HW + pid] = fmaf(T, a.bg[2], C2);
+        a.out_color[pid] = fmaf(T_keep, a.bg[0], C0);
+        a.out_color[HW + pid] = fmaf(T_keep, a.bg[1], C1);
+        a.out_color[2 * HW + pid] = fmaf(T_keep, a.bg[2], C2);
         a.out_alpha[pid] = weight;
         a.out_depth[pid] = D;
     }
