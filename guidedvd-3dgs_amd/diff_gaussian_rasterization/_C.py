@@ -15,7 +15,7 @@ import os
 import torch  # must be imported before the .so so that ONE libamdhip64 (torch's) serves both
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_raster.so")
+_LIB_PATH = os.environ.get("GVD_RASTER_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libgvd_raster.so")  # env: A/B builds
 _lib = None
 
 _ALLOC = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
