@@ -74,6 +74,21 @@ class LatentDiffusion(DiffusionSchedule):
         return res
 
     @torch.no_grad()
+    def encode_first_stage(self, x):  # ddpm3d.py:611-644: per-frame posterior SAMPLE times scale_factor
+        reshape_back = x.dim() == 5
+        if reshape_back:
+            b, _, t, _, _ = x.shape
+            x = x.transpose(1, 2).reshape(b * t, x.shape[1], x.shape[3], x.shape[4])
+        if not self.perframe_ae:
+            res = self.scale_factor * self.first_stage_model.encode(x).sample()
+        else:
+            res = torch.cat([self.scale_factor * self.first_stage_model.encode(x[i:i + 1]).sample()
+                             for i in range(x.shape[0])], dim=0)
+        if reshape_back:
+            res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
+        return res.detach()
+
+    @torch.no_grad()
     def decode_first_stage(self, z, **kwargs):
         return self.decode_core(z, **kwargs)
 

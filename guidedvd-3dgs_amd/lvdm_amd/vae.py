@@ -110,11 +110,89 @@ class Decoder(nn.Module):
         return self.conv_out(_gn_swish(self.norm_out, h))
 
 
-class AutoencoderKLDecoder(nn.Module):
-    """`first_stage_model` as far as the DDIM loop needs it: decode() only (encode is a 'next' row, N2)."""
+class Downsample(nn.Module):
+    """ae_modules.py:90-109: stride-2 3x3 convolution on an input padded by one pixel on the right / bottom only."""
 
-    def __init__(self, ddconfig, embed_dim=4):
+    def __init__(self, c):
         super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+
+
+class Encoder(nn.Module):
+    """ae_modules.py:360-462 (runs once per video, before the DDIM loop): conv-in, per level
+    `num_res_blocks` ResnetBlocks + Downsample, mid (Res, single-head attention, Res), GN -> swish -> conv-out to
+    2*z_channels moments.  Same parameter names as the reference (`encoder.down.1.block.0.norm1.weight`, ...)."""
+
+    def __init__(self, *, ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions=(), dropout=0.0, in_channels=3,
+                 resolution=256, z_channels=4, double_z=True, **ignored):
+        super().__init__()
+        if len(attn_resolutions) != 0:
+            raise NotImplementedError("per-level attention is not used by the ViewCrafter VAE (yaml: attn_resolutions: [])")
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            down = nn.Module()
+            down.block = nn.ModuleList()
+            down.attn = nn.ModuleList()
+            for _ in range(num_res_blocks):
+                down.block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in)
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.norm_out = _norm(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
+
+    def forward(self, x):
+        h = self.conv_in(x)
+        for i_level in range(self.num_resolutions):
+            for blk in self.down[i_level].block:
+                h = blk(h)
+            if i_level != self.num_resolutions - 1:
+                h = self.down[i_level].downsample(h)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        return self.conv_out(_gn_swish(self.norm_out, h))
+
+
+class DiagonalGaussianDistribution:
+    """lvdm/distributions.py:24-41 (the parts the sampling path uses)."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, noise=None):
+        if noise is None:
+            noise = torch.randn(self.mean.shape)   # drawn on the CPU generator, exactly like the reference (:36-37)
+        return self.mean + self.std * noise.to(device=self.parameters.device)
+
+    def mode(self):
+        return self.mean
+
+
+class AutoencoderKLDecoder(nn.Module):
+    """`first_stage_model` as far as the DDIM loop needs it: decode() (autoencoder.py:104-107).  `with_encoder=True`
+    adds the encoder + quant_conv so that `encode()` (:97-102) works too and the whole
+    `first_stage_model.*` part of the checkpoint loads strict."""
+
+    def __init__(self, ddconfig, embed_dim=4, with_encoder=False):
+        super().__init__()
+        if with_encoder:
+            self.encoder = Encoder(**ddconfig)
+            self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
         self.decoder = Decoder(**ddconfig)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
 
@@ -128,6 +206,11 @@ class AutoencoderKLDecoder(nn.Module):
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         self._token_major = True
         return self
+
+    def encode(self, x, **kwargs):
+        if not hasattr(self, "encoder"):
+            raise RuntimeError("AutoencoderKLDecoder was built without the encoder (with_encoder=True)")
+        return DiagonalGaussianDistribution(self.quant_conv(self.encoder(x)))
 
     def decode(self, z, **kwargs):
         if self._token_major:

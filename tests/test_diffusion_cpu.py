@@ -261,3 +261,31 @@ def test_pipeline_entry_matches_the_reference_image_guided_synthesis(tag, no_gui
     got = frames.detach().permute(0, 2, 3, 1).numpy()
     assert 0.05 < want.std()                                                       # not a saturated / constant video
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_vae_encoder_and_posterior_match_reference():
+    """SURVEY 8f N2 (VAE encode of the conditioning frames): lvdm_amd.vae.Encoder / DiagonalGaussianDistribution against
+    the reference's ae_modules.Encoder + distributions (tests/golden/make_golden_vae_encoder.py); same parameter names."""
+    from lvdm_amd import ops
+    from lvdm_amd.vae import AutoencoderKLDecoder
+    R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_encoder_ref.npz"))
+    cfg = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4], num_res_blocks=2,
+               attn_resolutions=[], dropout=0.0)
+    ops.use_reference_math(True)
+    try:
+        ae = AutoencoderKLDecoder(cfg, with_encoder=True).eval()
+        fill_by_name(ae.encoder, std=0.05)
+        assert sorted(ae.encoder.state_dict().keys()) == list(R["keys"])
+        with torch.no_grad():
+            ae.quant_conv.weight.copy_(torch.tensor(R["quant_w"]))
+            ae.quant_conv.bias.copy_(torch.tensor(R["quant_b"]))
+            x = torch.tensor(R["x"])
+            h = ae.encoder(x)
+            post = ae.encode(x)
+            z = post.sample(noise=torch.tensor(R["noise"]))
+    finally:
+        ops.use_reference_math(False)
+    np.testing.assert_allclose(h.numpy(), R["h"], rtol=1e-4, atol=1e-5 * np.abs(R["h"]).max())
+    np.testing.assert_allclose(post.mean.numpy(), R["mean"], rtol=1e-4, atol=1e-5 * np.abs(R["mean"]).max())
+    np.testing.assert_allclose(post.std.numpy(), R["std"], rtol=1e-4)
+    np.testing.assert_allclose(z.numpy(), R["z"], rtol=1e-4, atol=1e-5 * np.abs(R["z"]).max())
