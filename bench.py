@@ -246,7 +246,7 @@ def ddim_main(args):
     """BASELINE configs[2]: ViewCrafter 25-frame DDIM (unguided: 2 U-Net forwards + fused update per step),
     random-init U-Net with the zero-init modules re-randomised (SURVEY 7 'random-init U-Net is degenerate'),
     fp16 weights/activations with fp32 GroupNorm statistics and fp32 sampler math, synthetic conditioning.
-    One step = one DDIM step.  Single GPU in this round (frame/CFG sharding is a later round)."""
+    One step = one DDIM step.  --gpus N > 1: CFG pair x frame shards over RCCL (lvdm_amd/parallel.py), strong scaling."""
     import numpy as np
     import torch
     import torch.distributed as dist
