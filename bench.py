@@ -48,6 +48,7 @@ def main():
                          "between forward and backward: 'fused' = fused_loss HIP kernels, 'torch' = the reference's conv2d form")
     ap.add_argument("--instance-capacity", type=int, default=0,
                     help="raster: sync-free forward with this (Gaussian, tile) instance capacity (0 = reference behaviour)")
+    ap.add_argument("--graph", action="store_true", help="ddim: replay the U-Net evaluations from a captured hipGraph")
     ap.add_argument("--batch-cfg", action="store_true", help="ddim: evaluate cond/uncond as one batch-2 U-Net call")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -321,6 +322,7 @@ def ddim_main(args):
     sampler = DDIMSamplerGuidance(ld) if guided else DDIMSampler(ld)
     sampler.make_schedule(50, "uniform_trailing", 1.0)
     sampler.batch_cfg = bool(args.batch_cfg)
+    sampler.graph_apply = bool(args.graph)
     plan = None
     if world > 1:
         from lvdm_amd.parallel import ParallelPlan
@@ -406,8 +408,8 @@ def ddim_main(args):
                    "baseline_note": "vs_baseline = steps/s over the ViewCrafter README A100 figure 0.42 steps/s (120 s / 50 steps, "
                                     "whole pipeline incl. VAE/CLIP; third_party/ViewCrafter/README.md:116-118)"},
         "roofline": {"bound": "mfma", "kernel": "k_attn_fwd (all spatial/cross/temporal attention launches)",
-                     "achieved": round(att_flops / (att_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                     "frac": round(att_flops / (att_ms * 1e-3) / 1e12 / MFMA_PEAK, 4), "traffic": None,
+                     "achieved": round(att_flops / (att_ms * 1e-3) / 1e12, 2) if att_ms else None, "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                     "frac": round(att_flops / (att_ms * 1e-3) / 1e12 / MFMA_PEAK, 4) if att_ms else None, "traffic": None,
                      "launches": len(ev), "attention_ms_per_step": round(att_ms / steps, 2)},
         "unet_achieved_tflops": (round(2 * unet_tflop * steps / elapsed, 1) if unet_tflop and not guided else None),
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

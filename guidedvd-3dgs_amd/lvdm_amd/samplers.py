@@ -154,6 +154,13 @@ class DDIMSampler(object):
                    for k_, v_ in kwargs.items()}
             e = m.apply_model(torch.cat([x, x]), torch.cat([t, t]), _cat_cond(c, unconditional_conditioning), **kw2)
             e_cond, e_uncond = e.chunk(2, dim=0)
+        elif getattr(self, "graph_apply", False) and x.is_cuda and not torch.is_grad_enabled():
+            # hipGraph replay of the two U-Net evaluations (graphs.py): same kernels, no per-launch host cost
+            if getattr(self, "_graphed", None) is None or self._graphed.model is not m:
+                from .graphs import GraphedApplyModel
+                self._graphed = GraphedApplyModel(m)
+            e_cond = self._graphed.apply(x, t, c, **kwargs)
+            e_uncond = self._graphed.apply(x, t, unconditional_conditioning, **kwargs)
         else:
             e_cond = m.apply_model(x, t, c, **kwargs)
             e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)

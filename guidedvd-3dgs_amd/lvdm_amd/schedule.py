@@ -61,9 +61,15 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta):
     return sigmas, alphas, alphas_prev
 
 
+_FREQS = {}
+
+
 def timestep_embedding(timesteps, dim, max_period=10000):
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+    key = (half, max_period, timesteps.device)
+    freqs = _FREQS.get(key)
+    if freqs is None:  # formed on the CPU exactly like the reference (utils_diffusion.py:18-20), moved to the device ONCE
+        freqs = _FREQS[key] = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
     args = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
