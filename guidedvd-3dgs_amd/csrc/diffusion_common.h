@@ -78,12 +78,14 @@ __device__ __forceinline__ f2 exp2_pair(f2 a)
     return f2{ __builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y) };
 }
 
-// v_max3_f32 without the sNaN-quieting canonicalisation the IEEE-mode fmaxf lowering inserts per operand
+// max of three.  Plain fmaxf so that the compiler sees the instruction: an inline-asm v_max3_f32 reading MFMA results
+// hid the XDL-write -> VALU-read hazard from the hazard recognizer (no wait states were inserted, the max was taken
+// over partly stale registers, and peaky score rows overflowed -- found by the randomized sweep in
+// tests/test_diffusion_gpu.py).  The translation unit is built with -fno-honor-nans, which drops the per-operand
+// sNaN-quieting v_max the IEEE-mode lowering would otherwise add and lets the two maxima fuse into v_max3_f32.
 __device__ __forceinline__ float max3f(float a, float b, float c)
 {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 
 }  // namespace gvdd

@@ -430,3 +430,40 @@ def test_graph_replayed_unet_evaluation_matches_eager():
     # (eager or replayed) agree to f16 rounding, not bit for bit
     for a, b in zip(outs[False], outs[True]):
         assert float((a - b).abs().max()) < 3e-3 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("seed", list(range(14)))
+def test_attention_randomized_shapes_and_score_ranges(seed):
+    """Seeded sweep around the kernel's tile boundaries (32-query blocks, 64-key tiles, the 64 / 512-query dispatch
+    thresholds), both layouts, both 16-bit types, and score magnitudes from flat to peaky (the lazy-rescaling path:
+    running max jumps by far more than 2^8 between tiles), forward and backward, against the fp32 explicit form."""
+    from lvdm_amd import ops
+    rng = np.random.default_rng(500 + seed)
+    edges = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 700]
+    Nq, Nk = int(rng.choice(edges)), int(rng.choice(edges))
+    B, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    fm = bool(rng.integers(0, 2))
+    dtype = torch.float16 if rng.integers(0, 2) else torch.bfloat16
+    gain = float(rng.choice([0.2, 1.0, 6.0, 25.0]))          # |scores| up to ~gain^2 * 8 / 8
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    C = H * 64
+    shq, shk = ((Nq, B, C), (Nk, B, C)) if fm else ((B, Nq, C), (B, Nk, C))
+    q = (torch.randn(shq, device=DEV, generator=g) * gain).to(dtype).requires_grad_(True)
+    k = (torch.randn(shk, device=DEV, generator=g) * gain).to(dtype).requires_grad_(True)
+    v = torch.randn(shk, device=DEV, generator=g).to(dtype).requires_grad_(True)
+    if Nk >= 64:   # a key that dominates late in the sequence: forces a large jump of the running max in the last tile
+        with torch.no_grad():
+            (k[-1] if fm else k[:, -1]).mul_(4.0)
+    o = ops.attention(q, k, v, H, frame_major=fm)
+    go = torch.randn(o.shape, device=DEV, generator=g).to(dtype)
+    gq, gk, gv = torch.autograd.grad(o, (q, k, v), go)
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ref = ops.attention_math(qf, kf, vf, H, frame_major=fm)
+    rq, rk, rv = torch.autograd.grad(ref, (qf, kf, vf), go.float())
+    tol = 6e-3 if dtype == torch.float16 else 4e-2
+    assert torch.isfinite(o).all()
+    assert float((o.float() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max())), (Nq, Nk, B, H, fm, gain)
+    for name, a, b in (("dq", gq, rq), ("dk", gk, rk), ("dv", gv, rv)):
+        assert torch.isfinite(a).all()
+        err = float((a.float() - b).abs().max()) / max(float(b.abs().max()), 1.0)
+        assert err < tol, (name, err, Nq, Nk, B, H, fm, gain)
