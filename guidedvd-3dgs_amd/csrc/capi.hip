@@ -342,6 +342,7 @@ int gvd_raster_backward_conf(
     ra.ranges = (const uint32_t*)(img + L.ranges); ra.point_list = (const uint32_t*)(bin + L.point_list);
     ra.tile_order = (const uint32_t*)(img + L.tile_order);
     ra.n_contrib = (const uint32_t*)(img + L.n_contrib); ra.point_offsets = (const uint32_t*)(geom + L.point_offsets);
+    ra.scalars = (const uint32_t*)(geom + L.scalars);
     ra.radii = radii; ra.means2D = (const float*)(geom + L.means2D); ra.conic_opacity = (const float*)(geom + L.conic_opacity);
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = background; ra.alphas = alphas;
     ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials;
@@ -358,6 +359,7 @@ int gvd_raster_backward_conf(
     ga.cov3D = cov3D_precomp ? cov3D_precomp : (const float*)(geom + L.cov3D);
     ga.viewmatrix = viewmatrix; ga.projmatrix = projmatrix; ga.campos = campos; ga.radii = radii;
     ga.clamped = (const uint32_t*)(geom + L.clamped); ga.point_offsets = (const uint32_t*)(geom + L.point_offsets);
+    ga.scalars = (const uint32_t*)(geom + L.scalars);
     ga.partials = partials;
     ga.confidence = confidence;
     ga.has_sh = (shs != nullptr && M > 0 && colors_precomp == nullptr) ? 1 : 0;

@@ -44,6 +44,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     const size_t pid = (size_t)py * a.W + px;
     const size_t HW = (size_t)a.H * a.W;
 
+    // A capped forward that overflowed left truncated lists and point_offsets that index past the partial buffer:
+    // do nothing (k_gather_bwd then writes zero gradients); the overflow itself is reported through d_status.
+    if (a.scalars[2]) return;
     const uint32_t r0 = a.ranges[2 * tile];
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;
@@ -252,7 +255,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 // or a row of the block's LDS staging tile).
 __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int idx, float* dsh)
 {
-    const bool visible = a.radii[idx] > 0;
+    const bool visible = a.radii[idx] > 0 && a.scalars[2] == 0;  // overflowed forward: all-zero gradients
     float s[kNV];
 #pragma unroll
     for (int q = 0; q < kNV; q++) s[q] = 0.f;

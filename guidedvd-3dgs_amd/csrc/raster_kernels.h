@@ -56,6 +56,7 @@ struct RenderBwdArgs {
     int W, H, gx, gy;
     uint32_t capacity;
     const uint32_t *ranges, *point_list, *n_contrib, *point_offsets, *tile_order;
+    const uint32_t* scalars;  // [2] != 0: the (capped) forward overflowed its instance capacity -> no work, zero gradients
     const int* radii;
     const float *means2D, *conic_opacity, *rgbd, *bg, *alphas;
     const float *dL_dpix, *dL_dpix_depth, *dL_dalphas;
@@ -67,7 +68,7 @@ struct GatherBwdArgs {
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
     const float *means3D, *shs, *scales, *rotations, *cov3D, *viewmatrix, *projmatrix, *campos;
     const int* radii;
-    const uint32_t *clamped, *point_offsets;
+    const uint32_t *clamped, *point_offsets, *scalars;
     const float* partials;
     const float* confidence;  // [P] or NULL
     int has_sh, has_scales;

@@ -328,9 +328,10 @@ def test_operator_sync_free_mode_matches_and_reports_overflow_late():
         _C._drain_status(block=True)
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
-        _C.set_instance_capacity(500)   # too small for this view
-        run()
+        _C.set_instance_capacity(500)   # too small for this view: background image, all-zero gradients, no fault
+        over = run()
         torch.cuda.synchronize()
+        assert all(float(g.abs().max()) == 0.0 for g in over[4:])
         with pytest.raises(RuntimeError, match="instance capacity"):
             run()
     finally:
