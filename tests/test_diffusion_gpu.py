@@ -467,3 +467,50 @@ def test_attention_randomized_shapes_and_score_ranges(seed):
         assert torch.isfinite(a).all()
         err = float((a.float() - b).abs().max()) / max(float(b.abs().max()), 1.0)
         assert err < tol, (name, err, Nq, Nk, B, H, fm, gain)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_norm_kernels_randomized_shapes(seed):
+    """GroupNorm(+SiLU) fwd/bwd in both layouts, LayerNorm and GEGLU fwd/bwd at random sizes (tiny strips, sizes not
+    divisible by the vector width where the layout allows it, large means relative to the variance) against fp32 torch."""
+    from lvdm_amd import ops
+    rng = np.random.default_rng(300 + seed)
+    dtype = torch.float16 if rng.integers(0, 2) else torch.bfloat16
+    tol = 6e-3 if dtype == torch.float16 else 4e-2
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    C = int(rng.choice([32, 64, 96, 320, 640, 1280]))
+    N = int(rng.integers(1, 4))
+    cl = bool(rng.integers(0, 2))
+    sp = (int(rng.integers(1, 40)), int(rng.integers(1, 23)))
+    shape = (N,) + sp + (C,) if cl else (N, C) + sp
+    shift = float(rng.choice([0.0, 3.0, -10.0]))
+    x = (torch.randn(shape, device=DEV, generator=g) * float(rng.choice([0.1, 1.0, 4.0])) + shift).to(dtype).requires_grad_(True)
+    w = (torch.randn(C, device=DEV, generator=g) * 0.3 + 1).to(dtype)
+    b = (torch.randn(C, device=DEV, generator=g) * 0.2).to(dtype)
+    silu = bool(rng.integers(0, 2))
+    y = ops.group_norm(x, 32, w, b, 1e-5, silu=silu, channels_last=cl)
+    gy = torch.randn(y.shape, device=DEV, generator=g).to(dtype)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    xf = x.detach().float().requires_grad_(True)
+    yr = ops.group_norm_math(xf, 32, w.float(), b.float(), 1e-5, silu=silu, channels_last=cl)
+    (rx,) = torch.autograd.grad(yr, xf, gy.float())
+    assert float((y.float() - yr).abs().max()) < tol * max(1.0, float(yr.abs().max())), (shape, cl, silu)
+    assert float((gx.float() - rx).abs().max()) < tol * max(float(rx.abs().max()), 1e-6), (shape, cl, silu)
+    M = int(rng.integers(1, 700))
+    xl = (torch.randn(M, C, device=DEV, generator=g) * 2 + shift).to(dtype).requires_grad_(True)
+    yl = ops.layer_norm(xl, w, b, 1e-5)
+    gl = torch.randn(M, C, device=DEV, generator=g).to(dtype)
+    (gxl,) = torch.autograd.grad(yl, xl, gl)
+    xlf = xl.detach().float().requires_grad_(True)
+    ylr = torch.nn.functional.layer_norm(xlf, (C,), w.float(), b.float(), 1e-5)
+    (rxl,) = torch.autograd.grad(ylr, xlf, gl.float())
+    assert float((yl.float() - ylr).abs().max()) < tol * max(1.0, float(ylr.abs().max()))
+    assert float((gxl.float() - rxl).abs().max()) < tol * max(float(rxl.abs().max()), 1e-6)
+    h = (torch.randn(M, 2 * C, device=DEV, generator=g) * 1.5).to(dtype).requires_grad_(True)
+    yg = ops.geglu(h)
+    (gh,) = torch.autograd.grad(yg, h, gl)
+    hf = h.detach().float().requires_grad_(True)
+    ygr = ops.geglu_math(hf)
+    (rh,) = torch.autograd.grad(ygr, hf, gl.float())
+    assert float((yg.float() - ygr).abs().max()) < tol * max(1.0, float(ygr.abs().max()))
+    assert float((gh.float() - rh).abs().max()) < tol * max(float(rh.abs().max()), 1e-6)

@@ -120,3 +120,23 @@ def test_fused_photometric_loss_equals_its_two_term_form_and_the_goldens(tag):
     gref = 3.0 * (0.8 * np.sign(G[f"{tag}_x"] - G[f"{tag}_y"]) / G[f"{tag}_x"].size - 0.2 * G[f"{tag}_grad"])
     assert g.shape == x.shape and np.abs(g.cpu().numpy() - gref).max() < 1e-4 * np.abs(gref).max()
     assert not stats.requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fused_ssim_randomized_sizes_against_the_oracle(seed):
+    """Sizes around the 16-pixel tile and the 5-pixel window radius (1x1 ... ragged), 1-4 planes, batch or not."""
+    import fused_loss as fl
+    from oracle import ssim_oracle as so
+    rng = np.random.default_rng(900 + seed)
+    H, W = int(rng.choice([1, 2, 5, 6, 11, 15, 16, 17, 31, 33, 50])), int(rng.choice([1, 3, 5, 10, 16, 17, 32, 47, 64, 65]))
+    C = int(rng.integers(1, 5))
+    shp = (C, H, W) if rng.integers(0, 2) else (int(rng.integers(1, 3)), C, H, W)
+    x = rng.random(shp).astype(np.float32)
+    y = np.clip(x + 0.2 * rng.normal(size=shp), 0, 1).astype(np.float32)
+    tx = torch.tensor(x, device="cuda:0").requires_grad_(True)
+    v = fl.ssim(tx, torch.tensor(y, device="cuda:0"))
+    (g,) = torch.autograd.grad(v, tx)
+    vo, go = so.ssim(x, y)
+    assert abs(float(v) - float(vo)) < 3e-6, (shp, float(v), float(vo))
+    assert np.abs(g.cpu().numpy() - go).max() < 1e-4 * max(np.abs(go).max(), 1e-12), shp

@@ -125,3 +125,30 @@ def test_hip_knn_full_size_properties_and_empty_input():
     assert torch.allclose(best.mean(1).float(), m[q], rtol=1e-5, atol=1e-10)
     m0, i0 = distCUDA2(torch.zeros(0, 3, device="cuda:0"))
     assert m0.shape == (0,) and i0.shape == (0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_hip_knn_randomized_clouds_bit_exact(seed):
+    """Random sizes around the 256-query workgroup and the 1024-point box, clustered / duplicated / degenerate
+    (collinear, coplanar, all-equal) clouds, large coordinate offsets."""
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(700 + seed)
+    P = int(rng.choice([6, 255, 256, 257, 1023, 1024, 1025, 2049, 3333]))
+    kind = rng.choice(["gauss", "clusters", "line", "plane", "same", "offset"])
+    pts = rng.normal(size=(P, 3))
+    if kind == "clusters":
+        pts = pts * 0.01 + rng.normal(size=(8, 3))[rng.integers(0, 8, size=P)] * 5
+    elif kind == "line":
+        pts[:, 1:] = 0.0
+    elif kind == "plane":
+        pts[:, 2] = 1.5
+    elif kind == "same":
+        pts[:] = pts[0]
+    elif kind == "offset":
+        pts = pts * 0.05 + np.array([1000.0, -2000.0, 500.0])
+    pts = np.ascontiguousarray(pts, np.float32)
+    m_ref, i_ref = ko.dist2(pts)
+    m, i = distCUDA2(torch.tensor(pts, device="cuda:0"))
+    assert np.array_equal(m.cpu().numpy().view(np.uint32), m_ref.view(np.uint32)), (P, kind)
+    assert np.array_equal(i.cpu().numpy(), i_ref), (P, kind)
