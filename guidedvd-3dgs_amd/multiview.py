@@ -50,3 +50,33 @@ def render_views_sharded(render_fn, cameras, group=None):
         c, d, a = render_fn(cameras[0])  # shape probe for ranks that own no view
         local = torch.cat([c, d, a], 0).new_zeros((0, 5) + tuple(c.shape[1:]))
     return gather_views(local, len(cameras), group)
+
+
+def allreduce_gradients(params, group=None):
+    """SURVEY 8e row 2 (training step, width 2: train view on one GPU, pseudo view on the other, train_guidedvd.py:334,357):
+    sum the per-Gaussian gradients of `params` over the ranks with ONE all-reduce of a flat fp32 bucket
+    (~62 floats per Gaussian: 49.6 MB at 200k) instead of one collective per tensor -- xGMI all-reduce at this size is
+    latency-dominated.  A parameter without a gradient on this rank contributes zeros.  In place; returns the bucket
+    size in bytes.  Densify / prune decisions taken from the summed gradients are then identical on every replica."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    dev = params[0].device
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+    off = 0
+    for p in params:
+        if p.grad is not None:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        off += p.numel()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+    return flat.numel() * 4

@@ -68,3 +68,50 @@ def test_sharded_render_allgather_uneven_25_views():
 def test_single_view_fewer_than_ranks():
     res = _run(1)
     assert all(ok for _, ok, _ in res)
+
+
+def _grad_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "guidedvd-3dgs_amd"))
+    import multiview
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(3)
+    P = 37
+    base = [torch.randn(P, 3, generator=g), torch.randn(P, 16, 3, generator=g), torch.randn(P, 1, generator=g)]
+    views = [torch.randn(P, 3, generator=g) for _ in range(world)]
+
+    def loss(params, v):   # stand-in for render(view v) + photometric loss
+        out = (params[0] * views[v]).sum() ** 2 + (params[1].sum(-1).sum(-1) * views[v][:, 0]).sum()
+        return out + params[2].sum() if v == 0 else out
+
+    full = [b.clone().requires_grad_(True) for b in base]
+    sum(loss(full, v) for v in range(world)).backward()
+    mine = [b.clone().requires_grad_(True) for b in base]
+    frozen = torch.zeros(3, requires_grad=False)
+    loss(mine, rank).backward()
+    if rank != 0:
+        assert mine[2].grad is None            # this rank's view does not touch the third parameter
+    nbytes = multiview.allreduce_gradients(mine + [frozen])
+    ok = nbytes == 4 * sum(b.numel() for b in base)
+    for a, b in zip(mine, full):
+        ok = ok and torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)
+    q.put((rank, bool(ok), None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_step_gradient_allreduce_over_two_views():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
