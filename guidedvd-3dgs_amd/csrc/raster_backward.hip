@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_d = 0.f, acc_a = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
-    const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);  // uniform; x + (-0)*.. == x
+    const float nTf = -T_final;
+    const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);  // wave-uniform (kernel argument)
 
     for (uint32_t bdone = 0; bdone < tile_max; bdone += 256) {
         // ---- stage (descending list order) + cull + compact ----
@@ -128,18 +129,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         // per-pixel recurrences (T, accum_rec*, last_*), whose loop-carried part is one multiply/fma
         // each; the bodies are predicated (no divergent branches) so the scheduler can overlap entry
         // j+1's geometry with entry j's gradient terms and reduction.
-// T / (1 - alpha) (backward.cu:510).  GVD_BWD_DIV_MODE 1 (default): v_rcp_f32 + one Newton step, 4 VALU instead of
-// the 10 of the IEEE division sequence (mode 0).  Measured against the oracle on the C2 scene the gradient errors are
-// the same in both modes (dL_dscales 5.9e-5 vs 6.0e-5 of the largest entry, bar 1e-4; tests/scripts/err_probe.py),
-// whereas the raw v_rcp_f32 (1 ulp) alone doubled the dL_dscales error and was rejected.
-#ifndef GVD_BWD_DIV_MODE
-#define GVD_BWD_DIV_MODE 1
-#endif
-#if GVD_BWD_DIV_MODE == 1
-#define GVD_BWD_DIV(N, D) ([&] { const float r0_ = __builtin_amdgcn_rcpf(D); const float r1_ = fmaf(fmaf(-(D), r0_, 1.0f), r0_, r0_); return (N) * r1_; }())
-#else
-#define GVD_BWD_DIV(N, D) ((N) / (D))
-#endif
+// 1 / (1 - alpha) for T / (1 - alpha) (backward.cu:510) and for the background term -T_final / (1 - alpha) * (bg . dL_dpix)
+// (backward.cu:575-577): v_rcp_f32 + one Newton step, 3 VALU, shared by both uses, instead of two 10-instruction IEEE
+// division sequences.  Measured against the oracle on the C2 scene the gradient errors are unchanged (dL_dscales
+// 5.9e-5 vs 6.0e-5 of the largest entry, bar 1e-4; tests/scripts/err_probe.py); the raw v_rcp_f32 (1 ulp) alone
+// doubled the dL_dscales error and was rejected.
+#define GVD_BWD_RCP(D) ([&] { const float r0_ = __builtin_amdgcn_rcpf(D); return fmaf(fmaf(-(D), r0_, 1.0f), r0_, r0_); }())
 #define GVD_BWD_GEOM(J, DX, DY, G, ALPHA, ACT)                                                    \
         const float2 gxy##J = s_xy[j + J];                                                        \
         const float4 con##J = s_co[j + J];                                                        \
@@ -158,7 +153,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             const float am = ACT ? ALPHA : 0.f;                                                   \
             const float gm = ACT ? G : 0.f;                                                       \
             const float one_m_a = 1.f - am;                                                       \
-            T = GVD_BWD_DIV(T, one_m_a);                                                          \
+            const float rinv = GVD_BWD_RCP(one_m_a);                                              \
+            T = T * rinv;                                                                         \
             const float dchannel_dcolor = am * T;                                                 \
             const float oml = 1.f - last_alpha;                                                   \
             acc0 = fmaf(oml, acc0, last_alpha * lc0);                                             \
@@ -172,7 +168,11 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             dL_dopa = fmaf(c.w - acc_d, dLd, dL_dopa);                                            \
             dL_dopa = fmaf(1.f - acc_a, dLa, dL_dopa);                                            \
             dL_dopa *= T;                                                                         \
-            if (has_bg) dL_dopa += (-T_final / one_m_a) * bg_dot;                                 \
+            if (has_bg) { /* (-T_final / (1 - alpha)) * (bg . dL_dpix): quotient refined by one residual step */ \
+                float qb = nTf * rinv;                                                            \
+                qb = fmaf(fmaf(-one_m_a, qb, nTf), rinv, qb);                                     \
+                dL_dopa = fmaf(qb, bg_dot, dL_dopa);                                              \
+            }                                                                                     \
             lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
             const float dL_dG = con##J.w * dL_dopa;                                               \
             const float gdx = gm * DX, gdy = gm * DY;                                             \
