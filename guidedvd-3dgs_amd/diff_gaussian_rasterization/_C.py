@@ -90,6 +90,24 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Noop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOOP = _Noop()
+
+
+def _on(dev):
+    """Device guard; a no-op when `dev` is already current (torch.cuda.device() costs ~25 us of host time per use,
+    which matters in the 150-us window the host has to queue the backward behind the forward)."""
+    idx = dev.index
+    return _NOOP if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 class _Chunk:
     """Allocator callback target: a torch uint8 tensor sized on demand (resizeFunctional,
     rasterize_points.cu:27-33)."""
@@ -143,7 +161,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a ROCm device; got " + str(dev))
     L = lib()
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    with torch.cuda.device(dev):
+    with _on(dev):
         f = lambda t, n: _dev_f32(t, n, dev)
         bg, m3, col, opa, sc, rot, cov, vm, pm, shs, cam = (
             f(background, "bg"), f(means3D, "means3D"), f(colors, "colors_precomp"), f(opacity, "opacities"),
@@ -198,7 +216,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     L = lib()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
-    with torch.cuda.device(dev):
+    with _on(dev):
         f = lambda t, n: _dev_f32(t, n, dev)
         bg, m3, col, sc, rot, cov, vm, pm, shs, cam = (
             f(background, "bg"), f(means3D, "means3D"), f(colors, "colors_precomp"), f(scales, "scales"),
@@ -234,7 +252,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     P = means3D.size(0)
     present = torch.zeros((P,), dtype=torch.bool, device=dev)
     if P != 0:
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = lib().gvd_raster_mark_visible(P, _dev_f32(means3D, "means3D", dev).data_ptr(),
                                                _dev_f32(viewmatrix, "viewmatrix", dev).data_ptr(),
                                                _dev_f32(projmatrix, "projmatrix", dev).data_ptr(),
