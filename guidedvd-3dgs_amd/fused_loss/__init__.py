@@ -18,6 +18,23 @@ _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_loss.so")
 _LIB = None
 
 
+class _Noop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOOP = _Noop()
+
+
+def _on(dev):
+    """Device guard that is free when `dev` is already the current device (torch.cuda.device() costs ~25 us per use)."""
+    idx = dev.index
+    return _NOOP if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -72,7 +89,7 @@ class _SSIM(torch.autograd.Function):
         partials = torch.empty(L.gvd_ssim_partial_count(planes, H, W), dtype=torch.float32, device=x.device)
         dmaps = torch.empty((3, planes, H, W), dtype=torch.float32, device=x.device) if need_grad else None
         P = ctypes.c_void_p
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _check(L.gvd_ssim_forward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, planes, H, W, P(partials.data_ptr()),
                                       P(dmaps.data_ptr() if need_grad else None), P(None),
                                       P(torch.cuda.current_stream().cuda_stream)))
@@ -95,7 +112,7 @@ class _SSIM(torch.autograd.Function):
             scale = (g.float() / float(planes * H * W)).expand(planes).contiguous()
         d = torch.empty_like(x)
         P = ctypes.c_void_p
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _check(lib().gvd_ssim_backward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, P(dmaps.data_ptr()), P(scale.data_ptr()),
                                            planes, H, W, P(d.data_ptr()), P(torch.cuda.current_stream().cuda_stream)))
         return d, None, None
@@ -135,7 +152,7 @@ class _Photometric(torch.autograd.Function):
         dmaps = torch.empty((3, planes, H, W), dtype=torch.float32, device=x.device) if need_grad else None
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
         P = ctypes.c_void_p
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _check(L.gvd_photometric_forward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, planes, H, W, ctypes.c_float(lambda_dssim),
                                              P(partials.data_ptr()), P(dmaps.data_ptr() if need_grad else None),
                                              P(out3.data_ptr()), P(torch.cuda.current_stream().cuda_stream)))
@@ -152,7 +169,7 @@ class _Photometric(torch.autograd.Function):
         d = torch.empty_like(x)
         g = g.detach().float().contiguous()
         P = ctypes.c_void_p
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _check(lib().gvd_photometric_backward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, P(dmaps.data_ptr()), P(g.data_ptr()),
                                                   planes, H, W, ctypes.c_float(lam), P(d.data_ptr()),
                                                   P(torch.cuda.current_stream().cuda_stream)))

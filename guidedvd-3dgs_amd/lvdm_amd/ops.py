@@ -28,6 +28,23 @@ def use_reference_math(flag):
     _REFERENCE_MATH = bool(flag)
 
 
+class _Noop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOOP = _Noop()
+
+
+def _on(dev):
+    """Device guard that is free when `dev` is already the current device (torch.cuda.device() costs ~25 us per use)."""
+    idx = dev.index
+    return _NOOP if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -109,7 +126,7 @@ def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False):
     lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if want_lse else None
     is_bf16 = 1 if q.dtype == torch.bfloat16 else 0
     LL = ctypes.c_longlong
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         rc = lib().gvd_attention_fwd_strided(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
                                              ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                              B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), *(LL(s) for s in strides),
@@ -125,7 +142,7 @@ def _hip_attention_bwd(q, k, v, out, g, lse, heads, frame_major=False):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty_like(lse)
     LL, P = ctypes.c_longlong, ctypes.c_void_p
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         rc = lib().gvd_attention_bwd_strided(P(q.data_ptr()), P(k.data_ptr()), P(v.data_ptr()), P(out.data_ptr()),
                                              P(g.data_ptr()), P(lse.data_ptr()), P(delta.data_ptr()), P(dq.data_ptr()),
                                              P(dk.data_ptr()), P(dv.data_ptr()), B, heads, Nq, Nk, d,
@@ -216,7 +233,7 @@ def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=Fals
     b = _f32_param(bias)
     P, LL = ctypes.c_void_p, ctypes.c_longlong
     bf = 1 if x.dtype == torch.bfloat16 else 0
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         if group is None:
             rc = lib().gvd_group_norm(P(x.data_ptr()), P(y.data_ptr()), P(g.data_ptr()), P(b.data_ptr()), P(stats.data_ptr()),
                                       N, C, LL(S), groups, ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)), bf,
@@ -243,7 +260,7 @@ def _hip_group_norm_bwd(x, gy, gamma32, stats, groups, eps, silu, channels_last,
     scratch = torch.empty(2 * N * groups + N * C, dtype=torch.float64, device=x.device)
     P, LL = ctypes.c_void_p, ctypes.c_longlong
     bf = 1 if x.dtype == torch.bfloat16 else 0
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         if group is None:
             rc = lib().gvd_group_norm_bwd(P(x.data_ptr()), P(gy.data_ptr()), P(gx.data_ptr()), P(gamma32.data_ptr()),
                                           P(stats.data_ptr()), P(scratch.data_ptr()), N, C, LL(S), groups,
@@ -305,7 +322,7 @@ def _hip_layer_norm(x, weight, bias, eps):
     x = x.contiguous()
     C = x.shape[-1]
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib().gvd_layer_norm(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
                                   ctypes.c_void_p(weight.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
                                   ctypes.c_longlong(x.numel() // C), C, ctypes.c_float(eps),
@@ -331,7 +348,7 @@ class _LayerNormFn(torch.autograd.Function):
         C = x.shape[-1]
         gx = torch.empty_like(x)
         P = ctypes.c_void_p
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _check(lib().gvd_layer_norm_bwd(P(x.data_ptr()), P(gy.data_ptr()), P(weight.data_ptr()), P(gx.data_ptr()),
                                             ctypes.c_longlong(x.numel() // C), C, ctypes.c_float(ctx.eps),
                                             1 if x.dtype == torch.bfloat16 else 0, P(_stream())))
@@ -352,7 +369,7 @@ class _GegluFn(torch.autograd.Function):
         C = h.shape[-1] // 2
         gh = torch.empty_like(h)
         P = ctypes.c_void_p
-        with torch.cuda.device(h.device):
+        with _on(h.device):
             _check(lib().gvd_geglu_bwd(P(h.data_ptr()), P(gy.data_ptr()), P(gh.data_ptr()), ctypes.c_longlong(h.numel() // (2 * C)),
                                        C, 1 if h.dtype == torch.bfloat16 else 0, P(_stream())))
         return gh
@@ -392,7 +409,7 @@ def geglu(h):
 def _hip_geglu(h):
     C = h.shape[-1] // 2
     y = torch.empty(h.shape[:-1] + (C,), dtype=h.dtype, device=h.device)
-    with torch.cuda.device(h.device):
+    with _on(h.device):
         rc = lib().gvd_geglu(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(y.data_ptr()),
                              ctypes.c_longlong(h.numel() // (2 * C)), C,
                              1 if h.dtype == torch.bfloat16 else 0, ctypes.c_void_p(_stream()))
@@ -413,7 +430,7 @@ def ddim_step(x, e_cond, e_uncond, noise, *, cfg_scale, guidance_rescale, sqrt_a
         x, e_cond, e_uncond, noise = (t.contiguous() for t in (x, e_cond, e_uncond, noise))
         x_prev, x0 = torch.empty_like(x), torch.empty_like(x)
         ws = torch.empty(8, dtype=torch.float64, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             rc = lib().gvd_ddim_step(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(e_cond.data_ptr()),
                                      ctypes.c_void_p(e_uncond.data_ptr()), ctypes.c_void_p(noise.data_ptr()),
                                      ctypes.c_void_p(x_prev.data_ptr()), ctypes.c_void_p(x0.data_ptr()),
