@@ -1,6 +1,8 @@
 """Scene-grounding guidance loss: masked L2 between one decoded x0 frame and the 3DGS
-render of that frame.  Restates LossGuidance of utils/viewcrafter_wrapper.py:47-165 (the `recon` term;
-SSIM / LPIPS add-ons :150-159 pull in torchvision-VGG and are a 'next' row, N4).
+render of that frame, optionally mixed with a structural term.  Restates LossGuidance of
+utils/viewcrafter_wrapper.py:47-165: the `recon` term (:145-147) and the `ssim_guidance` mix
+0.8 recon + 0.2 sum(1 - ssim_map) (:150-155; the map through the fused SSIM kernels on the GPU).  The LPIPS add-on
+(:157-159) needs torchvision-VGG weights and stays a 'next' row (N4).
 """
 import torch
 import torch.nn.functional as F
@@ -11,8 +13,9 @@ class LossGuidance:
                  ssim_guidance=False, lpips_guidance=False, device="cuda:0", verbose=False, mean_loss=False,
                  scale_guidance_weight=False):
         assert mean_loss is False, "Important to set it to False. "
-        if ssim_guidance or lpips_guidance:
-            raise NotImplementedError("SSIM / LPIPS guidance terms are not part of this build (SURVEY 8f N4)")
+        if lpips_guidance:
+            raise NotImplementedError("the LPIPS guidance term is not part of this build (SURVEY 8f N4)")
+        self.ssim_guidance = bool(ssim_guidance)
         if scale_guidance_weight:
             raise NotImplementedError("scale_guidance_weight needs utils.stepfun.learning_rate_decay (out of scope)")
         self.ddim_steps, self.recur_steps, self.iter_steps = ddim_steps, recur_steps, iter_steps
@@ -42,8 +45,11 @@ class LossGuidance:
             mask = torch.ones_like(D)
         else:
             mask = self.guidance_masks[batch_idx_start:batch_idx_end].expand_as(D)
-        loss = self.w_recon * torch.square(D - self.guidance_images[batch_idx_start:batch_idx_end]) * mask
-        return {"recon": loss.sum()}, mask.sum()
+        G = self.guidance_images[batch_idx_start:batch_idx_end]
+        loss = (self.w_recon * torch.square(D - G) * mask).sum()
+        if self.ssim_guidance:   # viewcrafter_wrapper.py:150-155 with loss_utils.ssim_noavg(:84-118): sum over the map
+            loss = 0.8 * loss + 0.2 * _one_minus_ssim_sum(D.float(), G.float(), mask)
+        return {"recon": loss}, mask.sum()
 
     def update_save_dir(self, train_iter):
         self.current_train_iter = train_iter
@@ -52,3 +58,26 @@ class LossGuidance:
         """The reference writes an mp4 of the decoded x0 at EVERY DDIM step (viewcrafter_wrapper.py:174-192) -- a
         pure host stall on the hot loop.  Kept as a hook: tensors are stashed, not encoded."""
         self.last_pred_x0 = (int(ddim_index), pred_x0)
+
+
+def _one_minus_ssim_sum(x, y, mask):
+    """sum(1 - ssim_map(x*m + (1-m), y*m + (1-m))) over [1, C, H, W].  GPU: the fused SSIM kernels (value = mean of
+    the map, so the sum is numel * (1 - mean)); CPU tensors (tests under ops.use_reference_math) take the explicit
+    five-convolution form of loss_utils._ssim_noavg."""
+    xm, ym = x * mask + (1 - mask), y * mask + (1 - mask)
+    if x.is_cuda:
+        import fused_loss
+        return x.numel() * (1.0 - fused_loss.ssim(xm, ym.detach()))
+    from . import ops
+    if not ops._REFERENCE_MATH:
+        raise RuntimeError("LossGuidance(ssim_guidance=True): tensors must live on a ROCm device (this build has no CPU path)")
+    from math import exp
+    g = torch.tensor([exp(-(i - 5) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)], dtype=torch.float32)
+    g = g / g.sum()
+    C = x.shape[1]
+    w = (g[:, None] @ g[None, :])[None, None].expand(C, 1, 11, 11).contiguous().to(x)
+    conv = lambda t: F.conv2d(t, w, padding=5, groups=C)
+    mu1, mu2 = conv(xm), conv(ym)
+    s1, s2, s12 = conv(xm * xm) - mu1 * mu1, conv(ym * ym) - mu2 * mu2, conv(xm * ym) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+    return (1.0 - m).sum()

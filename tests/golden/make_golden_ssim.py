@@ -33,5 +33,16 @@ for tag, shp in cases.items():
         out[f"{tag}_l1_masked"] = ref.l1_loss_mask(x.detach(), y, mask).numpy()
     else:
         out[f"{tag}_ssim_per_batch"] = ref.ssim(x.detach(), y, size_average=False).numpy()
+# LossGuidance with ssim_guidance (utils/viewcrafter_wrapper.py:145-155), from the reference's ssim_noavg
+x = (torch.rand((3, 1, 24, 40), generator=g) * 2 - 1).requires_grad_(True)       # decoded frame [3,1,H,W] in [-1,1]
+G_img = torch.rand((1, 3, 24, 40), generator=g)
+mask = (torch.rand((1, 1, 24, 40), generator=g) > 0.35).float()
+D = ((x.permute(1, 0, 2, 3) + 1.) / 2.).clamp(0, 1)
+gm = mask.expand_as(D)
+recon = (0.5 * torch.square(D - G_img) * gm).sum()
+loss = 0.8 * recon + 0.2 * (1.0 - ref.ssim_noavg(D.float(), G_img.float(), mask=gm)).sum()
+(gx,) = torch.autograd.grad(loss, x)
+out["lg_x"], out["lg_G"], out["lg_mask"] = x.detach().numpy(), G_img.numpy(), mask.numpy()
+out["lg_loss"], out["lg_grad"], out["lg_numel"] = loss.detach().numpy(), gx.numpy(), gm.sum().numpy()
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ssim_ref.npz"), **out)
 print({k: v.shape for k, v in out.items() if "ssim" in k})

@@ -140,3 +140,34 @@ def test_fused_ssim_randomized_sizes_against_the_oracle(seed):
     vo, go = so.ssim(x, y)
     assert abs(float(v) - float(vo)) < 3e-6, (shp, float(v), float(vo))
     assert np.abs(g.cpu().numpy() - go).max() < 1e-4 * max(np.abs(go).max(), 1e-12), shp
+
+
+def _loss_guidance_case(device):
+    from lvdm_amd.guidance import LossGuidance
+    lg = LossGuidance(ddim_steps=50, recur_steps=1, ssim_guidance=True, device=str(device))
+    lg.set_hw(24, 40)
+    lg.set_guidance_images(torch.tensor(G["lg_G"], device=device))
+    lg.set_guidance_masks(torch.tensor(G["lg_mask"], device=device))
+    x = torch.tensor(G["lg_x"], device=device).requires_grad_(True)
+    loss_dict, numel = lg(x, 10, 0, 1)
+    (gx,) = torch.autograd.grad(loss_dict["recon"], x)
+    assert abs(float(numel) - float(G["lg_numel"])) < 0.5
+    assert abs(float(loss_dict["recon"]) - float(G["lg_loss"])) < 2e-5 * abs(float(G["lg_loss"]))
+    ref = G["lg_grad"]
+    assert np.abs(gx.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_loss_guidance_with_ssim_term_matches_the_reference_form_cpu():
+    """LossGuidance(ssim_guidance=True) (viewcrafter_wrapper.py:145-155) against the value / gradient the reference's
+    ssim_noavg gives (golden), explicit-math path."""
+    from lvdm_amd import ops
+    ops.use_reference_math(True)
+    try:
+        _loss_guidance_case(torch.device("cpu"))
+    finally:
+        ops.use_reference_math(False)
+
+
+@pytest.mark.gpu
+def test_loss_guidance_with_ssim_term_matches_the_reference_form_on_device():
+    _loss_guidance_case(torch.device("cuda:0"))
