@@ -206,16 +206,18 @@ def main():
         roofline = None
         if dom:
             achieved = alg_bytes[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            traffic = None
+            traffic = valu_busy = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(dom)
+                    pj = json.load(open(pmc))
+                    traffic = pj.get(dom)
+                    valu_busy = pj.get("_valu_busy", {}).get(dom)   # the blend kernels are VALU-bound, not HBM-bound
                 except Exception:
                     traffic = None
             roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                            avg_us=round(kern[dom]["avg_us"], 2), alg_bytes=int(alg_bytes[dom]))
+                            avg_us=round(kern[dom]["avg_us"], 2), alg_bytes=int(alg_bytes[dom]), valu_busy=valu_busy)
 
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1:
