@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gvd_raster.h"
@@ -84,6 +86,55 @@ volatile uint32_t* host_mirror()
     }
     return p;
 }
+
+// ---- speculative stage 2 (exact API, no idle gap after the read-back) --------------------------------------------
+// gvd_raster_forward must return the exact num_rendered, which only exists after stage 1 ran on the device.  Waiting
+// for it before sizing the binning chunk leaves the GPU idle while the host wakes up, calls the allocator and queues
+// stage 2 (30-80 us per render, host dependent).  Instead the binning chunk is sized from the largest num_rendered seen
+// for the same (P, width, height) (+12.5 %), stage 2 is queued right behind stage 1 with that capacity, and only then
+// does the host wait -- for stage 1 alone, through an event.  If the guess was too small (or the longest tile list
+// needs a bigger sort class than guessed) everything is simply run again the exact way; the kernels are overflow-safe.
+// The capacity a binning chunk was laid out for is remembered per chunk address so that backward (which is handed the
+// exact num_rendered) finds the same offsets.  GVD_RASTER_SPECULATE=0 turns it off.
+struct SpecHint { int P, W, H; uint32_t r_max, list_max; };
+std::mutex g_spec_mu;
+std::vector<SpecHint> g_hints;
+std::vector<std::pair<const void*, uint32_t>> g_chunk_cap;   // aligned binning chunk -> capacity of its layout
+
+bool spec_enabled()
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GVD_RASTER_SPECULATE"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+bool spec_lookup(int P, int W, int H, SpecHint* out)
+{
+    std::lock_guard<std::mutex> lk(g_spec_mu);
+    for (const SpecHint& h : g_hints) if (h.P == P && h.W == W && h.H == H) { *out = h; return true; }
+    return false;
+}
+void spec_update(int P, int W, int H, uint32_t R, uint32_t max_list)
+{
+    std::lock_guard<std::mutex> lk(g_spec_mu);
+    for (SpecHint& h : g_hints)
+        if (h.P == P && h.W == W && h.H == H) { if (R > h.r_max) h.r_max = R; if (max_list > h.list_max) h.list_max = max_list; return; }
+    if (g_hints.size() >= 16) g_hints.erase(g_hints.begin());
+    g_hints.push_back(SpecHint{ P, W, H, R, max_list });
+}
+void chunk_cap_set(const void* bin, uint32_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_spec_mu);
+    for (auto& e : g_chunk_cap) if (e.first == bin) { e.second = cap; return; }
+    if (g_chunk_cap.size() >= 64) g_chunk_cap.erase(g_chunk_cap.begin());
+    g_chunk_cap.emplace_back(bin, cap);
+}
+uint32_t chunk_cap_get(const void* bin, uint32_t R)
+{
+    std::lock_guard<std::mutex> lk(g_spec_mu);
+    for (const auto& e : g_chunk_cap) if (e.first == bin && e.second >= R) return e.second;
+    return R;
+}
+inline int sort_class_of(uint32_t max_list) { return max_list > 16384 ? 2 : (max_list > 2048 ? 1 : 0); }
 
 inline char* align_up(char* p) { return (char*)(((uintptr_t)p + gvd::kAlign - 1) & ~(uintptr_t)(gvd::kAlign - 1)); }
 
@@ -235,6 +286,11 @@ void gvd_raster_chunk_layout(int P, int width, int height, uint32_t num_rendered
     o->point_list_keys = L.keys; o->point_list = L.point_list; o->bucket = L.bucket;
 }
 
+uint32_t gvd_raster_chunk_capacity(const void* binning_chunk, uint32_t num_rendered)
+{
+    return chunk_cap_get(align_up((char*)binning_chunk), num_rendered);
+}
+
 int gvd_raster_forward(
     gvd_alloc_fn geometry_alloc, void* geometry_user, gvd_alloc_fn binning_alloc, void* binning_user,
     gvd_alloc_fn image_alloc, void* image_user,
@@ -264,6 +320,33 @@ int gvd_raster_forward(
     img = align_up(img);
     volatile uint32_t* mirror = host_mirror();
     if (!mirror) return fail(GVD_ERR_HIP, "hipHostMalloc(mirror) failed");
+    SpecHint hint;
+    if (spec_enabled() && spec_lookup(P, width, height, &hint) && hint.r_max > 0 && hint.r_max < 0x60000000u) {
+        static thread_local hipEvent_t ev = nullptr;
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+        if (ev) {
+            const uint32_t cap = hint.r_max + hint.r_max / 8 + 4096;
+            const int class_spec = sort_class_of(hint.list_max + hint.list_max / 4);
+            gvd::Layout Ls = gvd::make_layout(P, width, height, cap);
+            char* bin_s = binning_alloc(binning_user, Ls.bin_bytes);
+            if (!bin_s) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
+            bin_s = align_up(bin_s);
+            rc = forward_stage1(in, Ls, geom, img, cap, nullptr, mirror, stream);
+            if (rc != GVD_OK) return rc;
+            HIP_TRY(hipEventRecord(ev, stream));
+            rc = forward_stage2(in, Ls, geom, bin_s, img, cap, class_spec, stream);
+            if (rc != GVD_OK) return rc;
+            HIP_TRY(hipEventSynchronize(ev));   // stage 1 only: stage 2 keeps running while the host returns
+            const uint32_t Rs = mirror[0], max_list_s = mirror[1];
+            if (Rs > 0x7fffffffu) return fail(GVD_ERR_OVERFLOW, "num_rendered exceeds int32");
+            spec_update(P, width, height, Rs, max_list_s);
+            if (Rs <= cap && sort_class_of(max_list_s) <= class_spec) {
+                chunk_cap_set(bin_s, cap);
+                return (int)Rs;
+            }
+            // guessed too small: fall through and run the exact path (stage 1 again, with no capacity limit)
+        }
+    }
     rc = forward_stage1(in, L, geom, img, 0xffffffffu, nullptr, mirror, stream);
     if (rc != GVD_OK) return rc;
     // the one host sync of the forward (reference: cudaMemcpy at rasterizer_impl.cu:282)
@@ -271,11 +354,13 @@ int gvd_raster_forward(
     const uint32_t R = mirror[0];
     const uint32_t max_list = mirror[1];
     if (R > 0x7fffffffu) return fail(GVD_ERR_OVERFLOW, "num_rendered exceeds int32");
+    spec_update(P, width, height, R, max_list);
     L = gvd::make_layout(P, width, height, R);
     char* bin = binning_alloc(binning_user, L.bin_bytes);
     if (!bin) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
     bin = align_up(bin);
-    const int max_class = max_list > 16384 ? 2 : (max_list > 2048 ? 1 : 0);
+    chunk_cap_set(bin, R);
+    const int max_class = sort_class_of(max_list);
     rc = forward_stage2(in, L, geom, bin, img, R, max_class, stream);
     if (rc != GVD_OK) return rc;
     return (int)R;
@@ -330,15 +415,16 @@ int gvd_raster_backward_conf(
     if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
         (M > 0 && !dL_dsh))
         return fail(GVD_ERR_INVALID, "null gradient output");
-    const Layout L = make_layout(P, width, height, (uint32_t)R);
     char* geom = align_up(geom_buffer);
     char* bin = align_up(binning_buffer);
     char* img = align_up(image_buffer);
+    const uint32_t cap = chunk_cap_get(bin, (uint32_t)R);   // layout capacity of this chunk (== R unless stage 2 ran speculatively)
+    const Layout L = make_layout(P, width, height, cap);
     if (!radii) radii = (const int*)(geom + L.internal_radii);
     float* partials = (float*)(bin + L.partials);
-    HIP_TRY(hipMemsetAsync(partials, 0, (size_t)(R > 0 ? R : 1) * kPartialStride * 4, stream));
+    HIP_TRY(hipMemsetAsync(partials, 0, (size_t)(cap > 0 ? cap : 1) * kPartialStride * 4, stream));
     RenderBwdArgs ra{};
-    ra.W = width; ra.H = height; ra.gx = L.gx; ra.gy = L.gy; ra.capacity = (uint32_t)R;
+    ra.W = width; ra.H = height; ra.gx = L.gx; ra.gy = L.gy; ra.capacity = cap;
     ra.ranges = (const uint32_t*)(img + L.ranges); ra.point_list = (const uint32_t*)(bin + L.point_list);
     ra.tile_order = (const uint32_t*)(img + L.tile_order);
     ra.n_contrib = (const uint32_t*)(img + L.n_contrib); ra.point_offsets = (const uint32_t*)(geom + L.point_offsets);

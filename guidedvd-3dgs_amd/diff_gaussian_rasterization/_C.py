@@ -265,7 +265,11 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 def chunk_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):
     """Typed views of the internal scratch arrays (tests / debugging only)."""
     lay = _ChunkLayout()
-    lib().gvd_raster_chunk_layout(P, W, H, R, ctypes.byref(lay))
+    L = lib()
+    L.gvd_raster_chunk_capacity.restype = ctypes.c_uint32
+    L.gvd_raster_chunk_capacity.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    cap = L.gvd_raster_chunk_capacity(binningBuffer.data_ptr(), int(R)) if binningBuffer.numel() else int(R)
+    L.gvd_raster_chunk_layout(P, W, H, cap, ctypes.byref(lay))
 
     def view(buf, off, nbytes, dtype):
         base = buf.data_ptr()

@@ -22,8 +22,9 @@
  * (documented in DESIGN.md; inspectable through gvd_raster_chunk_layout for tests).
  *
  * Threading / streams: every launch goes to `stream` (the reference used the legacy
- * default stream).  forward performs ONE host<->device sync to learn num_rendered for
- * sizing the binning chunk (the reference's cudaMemcpy at rasterizer_impl.cu:282),
+ * default stream).  forward performs ONE host<->device sync to learn num_rendered
+ * (the reference's cudaMemcpy at rasterizer_impl.cu:282; from the second render of a given
+ * (P, width, height) on, stage 2 is queued speculatively BEFORE that wait, see capi.hip),
  * unless the caller passes a capacity through gvd_raster_forward_capped (no sync).
  * Not re-entrant on one stream from several host threads.
  *
@@ -80,6 +81,12 @@ int gvd_raster_forward(
     int* radii,
     int debug,
     void* stream);
+
+/* Capacity the binning chunk `binning_chunk` (as returned by the allocator callback) was laid out for by the forward
+ * that produced it: num_rendered itself, or the larger speculative capacity when stage 2 was queued before the
+ * read-back (see capi.hip, GVD_RASTER_SPECULATE).  gvd_raster_backward looks this up itself; tests that inspect the
+ * internal arrays pass it to gvd_raster_chunk_layout instead of num_rendered. */
+uint32_t gvd_raster_chunk_capacity(const void* binning_chunk, uint32_t num_rendered);
 
 /* Sync-free variant (MI355X addition; no reference counterpart): the caller supplies the
  * binning chunk up front, sized gvd_raster_binning_bytes(capacity, ...).  num_rendered stays

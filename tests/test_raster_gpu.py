@@ -337,3 +337,21 @@ def test_operator_sync_free_mode_matches_and_reports_overflow_late():
     finally:
         _C._PENDING.clear()
         _C.set_instance_capacity(0)
+
+
+def test_speculative_stage2_misprediction_falls_back_exactly():
+    """Same (P, W, H) three times: small splats (first call: exact path, sets the hint), then 3x larger splats (the
+    speculative capacity from the hint is too small -> the forward re-runs the exact path), then small again
+    (speculation succeeds with a now generous capacity).  Every result must match the oracle bit for bit."""
+    base = _tiny(41, P=400, W=96, H=80)
+    cam = base["cameras"][0]
+    grads = _grads(80, 96, 5)
+    Rs = []
+    for mult in (0.5, 3.0, 0.5, 3.0):
+        sc = dict(base)
+        sc["scales"] = (base["scales"] * mult).astype(np.float32)
+        st_o, g_o = run_oracle(sc, cam, grads)
+        st_h, g_h = run_hip(sc, cam, grads)
+        _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3)
+        Rs.append(int(st_o["R"]))
+    assert Rs[1] > 1.5 * Rs[0], Rs   # the second render really overflows the speculative capacity
