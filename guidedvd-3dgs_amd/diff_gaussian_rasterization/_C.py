@@ -11,6 +11,7 @@ There is NO CPU fallback: tensors must live on a ROCm device and the HIP library
 """
 import ctypes
 import os
+import threading
 
 import torch  # must be imported before the .so so that ONE libamdhip64 (torch's) serves both
 
@@ -151,6 +152,21 @@ def _drain_status(block=False):
                                f"({_CAPACITY}); raise it with set_instance_capacity() / GVD_RASTER_CAPACITY")
 
 
+_EMPTY = torch.empty(0, dtype=torch.uint8)
+_TLS = threading.local()
+
+
+def _chunks(dev):
+    """Three allocator-callback targets per (thread, device), created once."""
+    cache = getattr(_TLS, "chunks", None)
+    if cache is None:
+        cache = _TLS.chunks = {}
+    c = cache.get(dev)
+    if c is None:
+        c = cache[dev] = (_Chunk(dev), _Chunk(dev), _Chunk(dev))
+    return c
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug):
@@ -192,7 +208,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             ev.record()
             _PENDING.append((ev, host))
             return _CAPACITY, out_color, out_depth, out_alpha, radii, geom_t, bin_t, img_t
-        geom, binning, img = _Chunk(dev), _Chunk(dev), _Chunk(dev)
+        geom, binning, img = _chunks(dev)   # allocator callback targets, reused (building a ctypes callback costs ~5 us)
         rc = L.gvd_raster_forward(geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H,
                                   _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot),
                                   _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cam), float(tan_fovx), float(tan_fovy),
@@ -200,7 +216,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                   radii.data_ptr() if P > 0 else None, int(bool(debug)), _stream())
         if rc < 0:
             raise _err(rc)
-    return rc, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor
+    res = (rc, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor)
+    geom.tensor = binning.tensor = img.tensor = _EMPTY   # the chunks now belong to the caller only
+    return res
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
