@@ -9,6 +9,7 @@
 
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -99,7 +100,8 @@ volatile uint32_t* host_mirror()
 struct SpecHint { int P, W, H; uint32_t r_max, list_max; };
 std::mutex g_spec_mu;
 std::vector<SpecHint> g_hints;
-std::vector<std::pair<const void*, uint32_t>> g_chunk_cap;   // aligned binning chunk -> capacity of its layout
+std::unordered_map<const void*, uint32_t> g_chunk_cap;   // aligned binning chunk laid out SPECULATIVELY -> its capacity
+constexpr size_t kMaxSpecChunks = 1u << 16;               // beyond this many live entries speculation pauses
 
 bool spec_enabled()
 {
@@ -121,18 +123,29 @@ void spec_update(int P, int W, int H, uint32_t R, uint32_t max_list)
     if (g_hints.size() >= 16) g_hints.erase(g_hints.begin());
     g_hints.push_back(SpecHint{ P, W, H, R, max_list });
 }
+// Only chunks whose layout capacity differs from the num_rendered handed to backward need an entry; every other
+// forward ERASES the entry of the address it is about to use (the allocator may hand out the address of a dead
+// speculative chunk again).  Entries are never evicted while their chunk can still reach backward.
 void chunk_cap_set(const void* bin, uint32_t cap)
 {
     std::lock_guard<std::mutex> lk(g_spec_mu);
-    for (auto& e : g_chunk_cap) if (e.first == bin) { e.second = cap; return; }
-    if (g_chunk_cap.size() >= 64) g_chunk_cap.erase(g_chunk_cap.begin());
-    g_chunk_cap.emplace_back(bin, cap);
+    g_chunk_cap[bin] = cap;
+}
+void chunk_cap_erase(const void* bin)
+{
+    std::lock_guard<std::mutex> lk(g_spec_mu);
+    g_chunk_cap.erase(bin);
+}
+bool chunk_cap_room()
+{
+    std::lock_guard<std::mutex> lk(g_spec_mu);
+    return g_chunk_cap.size() < kMaxSpecChunks;
 }
 uint32_t chunk_cap_get(const void* bin, uint32_t R)
 {
     std::lock_guard<std::mutex> lk(g_spec_mu);
-    for (const auto& e : g_chunk_cap) if (e.first == bin && e.second >= R) return e.second;
-    return R;
+    const auto it = g_chunk_cap.find(bin);
+    return (it != g_chunk_cap.end() && it->second >= R) ? it->second : R;
 }
 inline int sort_class_of(uint32_t max_list) { return max_list > 16384 ? 2 : (max_list > 2048 ? 1 : 0); }
 
@@ -321,7 +334,7 @@ int gvd_raster_forward(
     volatile uint32_t* mirror = host_mirror();
     if (!mirror) return fail(GVD_ERR_HIP, "hipHostMalloc(mirror) failed");
     SpecHint hint;
-    if (spec_enabled() && spec_lookup(P, width, height, &hint) && hint.r_max > 0 && hint.r_max < 0x60000000u) {
+    if (spec_enabled() && chunk_cap_room() && spec_lookup(P, width, height, &hint) && hint.r_max > 0 && hint.r_max < 0x60000000u) {
         static thread_local hipEvent_t ev = nullptr;
         if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
         if (ev) {
@@ -344,6 +357,7 @@ int gvd_raster_forward(
                 chunk_cap_set(bin_s, cap);
                 return (int)Rs;
             }
+            chunk_cap_erase(bin_s);
             // guessed too small: fall through and run the exact path (stage 1 again, with no capacity limit)
         }
     }
@@ -359,7 +373,7 @@ int gvd_raster_forward(
     char* bin = binning_alloc(binning_user, L.bin_bytes);
     if (!bin) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
     bin = align_up(bin);
-    chunk_cap_set(bin, R);
+    chunk_cap_erase(bin);   // exact layout: backward's num_rendered describes it
     const int max_class = sort_class_of(max_list);
     rc = forward_stage2(in, L, geom, bin, img, R, max_class, stream);
     if (rc != GVD_OK) return rc;
@@ -390,6 +404,7 @@ int gvd_raster_forward_capped(
     char* geom = align_up(geometry_chunk);
     char* img = align_up(image_chunk);
     char* bin = align_up(binning_chunk);
+    chunk_cap_erase(bin);   // the caller passes `capacity` to backward; drop a dead speculative chunk's entry for this address
     rc = forward_stage1(in, L, geom, img, capacity, d_status, nullptr, stream);
     if (rc != GVD_OK) return rc;
     return forward_stage2(in, L, geom, bin, img, capacity, 2, stream);

@@ -87,7 +87,14 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw hipStream_t of torch's current stream on the current device (the private fast path costs ~0.3 us, the public
+    torch.cuda.current_stream() object ~9 us)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -35,6 +35,15 @@ def _on(dev):
     return _NOOP if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(dev)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream():
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -92,7 +101,7 @@ class _SSIM(torch.autograd.Function):
         with _on(x.device):
             _check(L.gvd_ssim_forward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, planes, H, W, P(partials.data_ptr()),
                                       P(dmaps.data_ptr() if need_grad else None), P(None),
-                                      P(torch.cuda.current_stream().cuda_stream)))
+                                      P(_stream())))
         per_plane = partials.view(planes, -1).sum(1)          # fixed summation order: reproducible
         ctx.per_batch, ctx.shape = per_batch, (N, C, H, W)
         if need_grad:
@@ -114,7 +123,7 @@ class _SSIM(torch.autograd.Function):
         P = ctypes.c_void_p
         with _on(x.device):
             _check(lib().gvd_ssim_backward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, P(dmaps.data_ptr()), P(scale.data_ptr()),
-                                           planes, H, W, P(d.data_ptr()), P(torch.cuda.current_stream().cuda_stream)))
+                                           planes, H, W, P(d.data_ptr()), P(_stream())))
         return d, None, None
 
 
@@ -155,7 +164,7 @@ class _Photometric(torch.autograd.Function):
         with _on(x.device):
             _check(L.gvd_photometric_forward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, planes, H, W, ctypes.c_float(lambda_dssim),
                                              P(partials.data_ptr()), P(dmaps.data_ptr() if need_grad else None),
-                                             P(out3.data_ptr()), P(torch.cuda.current_stream().cuda_stream)))
+                                             P(out3.data_ptr()), P(_stream())))
         ctx.cfg = (planes, H, W, float(lambda_dssim), image.shape)
         if need_grad:
             ctx.save_for_backward(x, y, dmaps)
@@ -172,7 +181,7 @@ class _Photometric(torch.autograd.Function):
         with _on(x.device):
             _check(lib().gvd_photometric_backward(P(x.data_ptr()), P(y.data_ptr()), _GAUSS11, P(dmaps.data_ptr()), P(g.data_ptr()),
                                                   planes, H, W, ctypes.c_float(lam), P(d.data_ptr()),
-                                                  P(torch.cuda.current_stream().cuda_stream)))
+                                                  P(_stream())))
         return d.view(shape), None, None
 
 

@@ -31,6 +31,15 @@ def _on(dev):
     return _NOOP if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(dev)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream():
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -65,7 +74,7 @@ def distCUDA2(points):
     base = (ws.data_ptr() + 255) & ~255
     with _on(pts.device):
         rc = L.gvd_knn_mean_dist(pts.data_ptr(), P, means.data_ptr(), nearest.data_ptr(), base, nbytes,
-                                 torch.cuda.current_stream().cuda_stream)
+                                 _stream())
     if rc != 0:
         raise RuntimeError(f"gvd_knn error {rc}: {L.gvd_knn_last_error().decode()}")
     return means, nearest
