@@ -355,3 +355,39 @@ def test_speculative_stage2_misprediction_falls_back_exactly():
         _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3)
         Rs.append(int(st_o["R"]))
     assert Rs[1] > 1.5 * Rs[0], Rs   # the second render really overflows the speculative capacity
+
+
+def test_many_outstanding_speculative_forwards_then_backward():
+    """80 renders of the same size are kept alive (all but the first laid out speculatively, every one in its own
+    binning chunk) and differentiated afterwards in reverse order: each gradient must equal the one obtained from a
+    render that is differentiated immediately.  Guards the per-chunk capacity bookkeeping of the speculative stage 2."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = syn.scene_c1()
+    cam = sc["cameras"][0]
+    t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev, requires_grad=rg)
+    P = sc["means3D"].shape[0]
+    base = {k: t(sc[k]) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+    s = GaussianRasterizationSettings(image_height=128, image_width=128, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(sc["bg"]),
+                                      scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=3,
+                                      campos=t(cam["campos"]), prefiltered=False, debug=False, confidence=torch.ones((P, 1), device=dev))
+    gC = torch.randn(3, 128, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+
+    def render(k):
+        prm = {n: v.clone().requires_grad_(True) for n, v in base.items()}
+        with torch.no_grad():
+            prm["scales"] *= (1.0 + 0.004 * k)      # a slightly different num_rendered every time
+        m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+        color, _, _, _ = GaussianRasterizer(s)(means3D=prm["means3D"], means2D=m2, opacities=prm["opacities"], shs=prm["shs"],
+                                               scales=prm["scales"], rotations=prm["rotations"])
+        return color, prm
+
+    held = [render(k) for k in range(80)]
+    for k in reversed(range(80)):
+        color, prm = held[k]
+        color.backward(gC)
+    for k in (0, 1, 37, 79):
+        color, prm = render(k)
+        color.backward(gC)
+        for n in prm:
+            assert torch.equal(prm[n].grad, held[k][1][n].grad), (k, n)
