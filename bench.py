@@ -219,6 +219,43 @@ def main():
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                             avg_us=round(kern[dom]["avg_us"], 2), alg_bytes=int(alg_bytes[dom]), valu_busy=valu_busy)
 
+        # SURVEY 8(d) asks for two more points on the same scene: SH degree 0, and all three pixel gradients non-zero
+        # (colour + depth + alpha).  Short side runs (not the headline value), single rank.
+        variants = None
+        if world == 1 and loss_fn is None:
+            gD = torch.randn((1, H, W), device=dev, generator=gen) / (H * W)
+            gA = torch.randn((1, H, W), device=dev, generator=gen) / (H * W)
+
+            def timed(fn, n=60):
+                for i in range(10):
+                    fn(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(n):
+                    fn(10 + i)
+                torch.cuda.synchronize()
+                return round(n / (time.perf_counter() - t1), 1)
+
+            def step_all(i):
+                s = cams[i % len(cams)]
+                color, radii, depth, alpha = GaussianRasterizer(s)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
+                                                                   scales=scales, rotations=rots)
+                for p_ in params:
+                    p_.grad = None
+                torch.autograd.backward([color, depth, alpha], [gC, gD, gA])
+
+            cams0 = [c._replace(sh_degree=0) for c in cams]
+
+            def step_d0(i):
+                s = cams0[i % len(cams0)]
+                color, radii, depth, alpha = GaussianRasterizer(s)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
+                                                                   scales=scales, rotations=rots)
+                for p_ in params:
+                    p_.grad = None
+                torch.autograd.backward([color], [gC])
+
+            variants = {"all_three_pixel_gradients_iters_per_s": timed(step_all), "sh_degree_0_iters_per_s": timed(step_d0)}
+
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1:
             cpu_baseline = cpu_leg(sc, args, np)
@@ -237,6 +274,7 @@ def main():
                        "parallelism": f"per-camera shards x{world}"},
             "roofline": roofline,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+            "variants": variants,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
