@@ -86,22 +86,32 @@ def frame_parallel(shard):
         _ACTIVE = prev
 
 
+def _a2a(src, n_out, out_splits, in_splits, group):
+    """all_to_all_single; a backend without a device all-to-all (gloo, used to run two ranks on one GPU in the tests)
+    gets the exchange staged through host memory -- RCCL takes the device tensors directly."""
+    src = src.contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        host = src.cpu()
+        out = host.new_empty(n_out)
+        dist.all_to_all_single(out, host, out_splits, in_splits, group=group)
+        return out.to(src.device)
+    out = src.new_empty(n_out)
+    dist.all_to_all_single(out, src, out_splits, in_splits, group=group)
+    return out
+
+
 class _AllToAll(torch.autograd.Function):
     """all_to_all_single with explicit split sizes; the backward is the transposed exchange."""
 
     @staticmethod
     def forward(ctx, flat, in_splits, out_splits, group):
         ctx.cfg = (in_splits, out_splits, group)
-        out = flat.new_empty(sum(out_splits))
-        dist.all_to_all_single(out, flat.contiguous(), out_splits, in_splits, group=group)
-        return out
+        return _a2a(flat, sum(out_splits), out_splits, in_splits, group)
 
     @staticmethod
     def backward(ctx, g):
         in_splits, out_splits, group = ctx.cfg
-        gi = g.new_empty(sum(in_splits))
-        dist.all_to_all_single(gi, g.contiguous(), in_splits, out_splits, group=group)
-        return gi, None, None, None
+        return _a2a(g, sum(in_splits), in_splits, out_splits, group), None, None, None
 
 
 def frames_to_pixels(tok, shard):
