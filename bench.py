@@ -66,8 +66,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank = local_rank % torch.cuda.device_count()   # (several ranks per GPU only in the gloo dry run below)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        _init_dist(dist, torch, local_rank)
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -283,6 +284,16 @@ def main():
         dist.destroy_process_group()
 
 
+def _init_dist(dist, torch, local_rank):
+    """One rank per GPU over RCCL (backend "nccl").  GVD_DIST_BACKEND=gloo is a dry-run aid: it lets the multi-rank control
+    flow (barriers, max-reduce, rank-0 reporting) run with several ranks on ONE GPU, where RCCL refuses duplicate devices."""
+    backend = os.environ.get("GVD_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+
+
 def ddim_main(args):
     """BASELINE configs[2]: ViewCrafter 25-frame DDIM (unguided: 2 U-Net forwards + fused update per step),
     random-init U-Net with the zero-init modules re-randomised (SURVEY 7 'random-init U-Net is degenerate'),
@@ -295,12 +306,13 @@ def ddim_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = local_rank % torch.cuda.device_count()
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     if world > 1:  # CFG pair x frame shards, one rank per GPU over RCCL (lvdm_amd/parallel.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        _init_dist(dist, torch, local_rank)
     torch.backends.cudnn.benchmark = os.environ.get("GVD_CONV_FIND", "1") == "1"  # let MIOpen time its NHWC solvers once per shape
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from lvdm_amd import ops
