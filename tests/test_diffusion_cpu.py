@@ -289,3 +289,29 @@ def test_vae_encoder_and_posterior_match_reference():
     np.testing.assert_allclose(post.mean.numpy(), R["mean"], rtol=1e-4, atol=1e-5 * np.abs(R["mean"]).max())
     np.testing.assert_allclose(post.std.numpy(), R["std"], rtol=1e-4)
     np.testing.assert_allclose(z.numpy(), R["z"], rtol=1e-4, atol=1e-5 * np.abs(R["z"]).max())
+
+
+def test_resampler_and_image_proj_match_reference():
+    """SURVEY 8f N2 (image-conditioning projector): lvdm_amd.resampler against the reference's Resampler / ImageProjModel
+    (tests/golden/make_golden_resampler.py), forward and input gradient; same state-dict keys."""
+    from lvdm_amd import ops
+    from lvdm_amd.resampler import ImageProjModel, Resampler
+    R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resampler_ref.npz"))
+    cfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=96, output_dim=80, ff_mult=4, video_length=3)
+    proj = dict(cross_attention_dim=64, clip_embeddings_dim=48, clip_extra_context_tokens=4)
+    ops.use_reference_math(True)
+    try:
+        rs = fill_by_name(Resampler(**cfg), std=0.08).eval()
+        assert sorted(rs.state_dict().keys()) == list(R["keys"])
+        x = torch.tensor(R["x"]).requires_grad_(True)
+        y = rs(x)
+        (gx,) = torch.autograd.grad((y * torch.tensor(R["probe"])).sum(), x)
+        pm = fill_by_name(ImageProjModel(**proj), std=0.1).eval()
+        assert sorted(pm.state_dict().keys()) == list(R["proj_keys"])
+        with torch.no_grad():
+            t = pm(torch.tensor(R["e"]))
+    finally:
+        ops.use_reference_math(False)
+    np.testing.assert_allclose(y.detach().numpy(), R["y"], rtol=1e-4, atol=1e-5 * np.abs(R["y"]).max())
+    np.testing.assert_allclose(gx.numpy(), R["gx"], rtol=1e-4, atol=1e-5 * np.abs(R["gx"]).max())
+    np.testing.assert_allclose(t.numpy(), R["t"], rtol=1e-4, atol=1e-5 * np.abs(R["t"]).max())

@@ -514,3 +514,47 @@ def test_norm_kernels_randomized_shapes(seed):
     (rh,) = torch.autograd.grad(ygr, hf, gl.float())
     assert float((yg.float() - ygr).abs().max()) < tol * max(1.0, float(ygr.abs().max()))
     assert float((gh.float() - rh).abs().max()) < tol * max(float(rh.abs().max()), 1e-6)
+
+
+def test_resampler_on_device_golden_and_fp16_kernels():
+    """the image-conditioning projector.  fp32 on the device against the reference golden (forward and
+    input gradient); then the ViewCrafter shape (257 CLIP tokens -> 16 frames x 16 queries, 12 heads x 64) in fp16, where
+    attention and LayerNorm are the HIP kernels, against the same module in fp32."""
+    from lvdm_amd import ops
+    from lvdm_amd.resampler import Resampler
+    R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resampler_ref.npz"))
+    cfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=96, output_dim=80, ff_mult=4, video_length=3)
+    rs = fill_by_name(Resampler(**cfg), std=0.08).eval().to(DEV)
+    x = torch.tensor(R["x"], device=DEV, requires_grad=True)
+    y = rs(x)
+    (gx,) = torch.autograd.grad((y * torch.tensor(R["probe"], device=DEV)).sum(), x)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), R["y"], rtol=2e-4, atol=2e-4 * np.abs(R["y"]).max())
+    np.testing.assert_allclose(gx.cpu().numpy(), R["gx"], rtol=2e-4, atol=2e-4 * np.abs(R["gx"]).max())
+
+    big = dict(dim=1024, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=1024, ff_mult=4,
+               video_length=16)
+    rs = fill_by_name(Resampler(**big), std=0.02).eval().to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    tokens = torch.randn(2, 257, 1280, device=DEV, generator=g)
+    calls = {"attn": 0, "ln": 0}
+    orig_a, orig_l = ops._hip_attention_fwd, ops._hip_layer_norm
+
+    def count_a(*a, **k):
+        calls["attn"] += 1
+        return orig_a(*a, **k)
+
+    def count_l(*a, **k):
+        calls["ln"] += 1
+        return orig_l(*a, **k)
+
+    with torch.no_grad():
+        y32 = rs(tokens)
+        half = rs.half()
+        ops._hip_attention_fwd, ops._hip_layer_norm = count_a, count_l
+        try:
+            y16 = half(tokens.half())
+        finally:
+            ops._hip_attention_fwd, ops._hip_layer_norm = orig_a, orig_l
+    assert y16.shape == (2, 256, 1024) and calls["attn"] == 4 and calls["ln"] == 4 * 3 + 1, calls
+    err = float((y16.float() - y32).abs().max()) / float(y32.abs().max())
+    assert err < 2e-2, err
