@@ -409,18 +409,19 @@ __global__ void __launch_bounds__(CLASS == 0 ? 256 : 1024) k_sort_tiles(SortArgs
 // k_render_fwd: one workgroup (4 waves) per 16x16 tile; wave w owns the 16x4 pixel strip
 // rows 4w..4w+3 (x fastest, so output stores are 64-byte row segments).
 // Per batch of 256 list entries: each thread fetches one entry (id -> xy, conic/opacity, rgb+depth),
-// runs the conservative tile test, and the survivors are compacted into LDS with a wave ballot +
-// prefix (order preserved, original list position kept for n_contrib).  Every pixel then walks the
-// compacted batch from LDS (broadcast reads) with the reference's exact per-pixel sequence
-// (forward.cu:329-368).
+// runs the conservative test against each of the four strips, and the survivors are compacted into one
+// LDS list PER STRIP with wave ballots + prefixes (order preserved, original list position kept for
+// n_contrib): a wave only walks the entries that can reach its own 64 pixels (about two thirds of the
+// tile's survivors on the C2 scene).  Every pixel then walks its strip's batch from LDS (broadcast reads)
+// with the reference's exact per-pixel sequence (forward.cu:329-368).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
 {
-    __shared__ float2 s_xy[256];
-    __shared__ float4 s_co[256];
-    __shared__ float4 s_cd[256];
-    __shared__ uint32_t s_pos[256];
-    __shared__ uint32_t s_wcount[4];
+    __shared__ float2 s_xy4[4][256];   // one compacted list per strip (= per wave)
+    __shared__ float4 s_co4[4][256];
+    __shared__ float4 s_cd4[4][256];
+    __shared__ uint32_t s_pos4[4][256];
+    __shared__ uint4 s_wcount[4];
 
     const int tile = (int)a.tile_order[blockIdx.x];
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -443,9 +444,9 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     for (uint32_t b = r0; b < r1; b += 256) {
         const int num_done = __syncthreads_count(T == 0.0f);
         if (num_done == 256) break;
-        // ---- stage + cull + compact ----
+        // ---- stage + cull per strip + compact into the four strip lists ----
         const uint32_t e = b + tid;
-        bool keep = false;
+        uint32_t smask = 0;
         float2 xy;
         float4 co, cd;
         if (e < r1) {
@@ -453,25 +454,36 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
             xy = reinterpret_cast<const float2*>(a.means2D)[id];
             co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
             cd = reinterpret_cast<const float4*>(a.rgbd)[id];
-            keep = tile_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
+            smask = strip_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wcount[w] = (uint32_t)__popcll(m);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long m0 = __ballot(smask & 1u), m1 = __ballot(smask & 2u), m2 = __ballot(smask & 4u),
+                                 m3 = __ballot(smask & 8u);
+        if (lane == 0) s_wcount[w] = make_uint4((uint32_t)__popcll(m0), (uint32_t)__popcll(m1), (uint32_t)__popcll(m2), (uint32_t)__popcll(m3));
         __syncthreads();
-        uint32_t wbase = 0, n = 0;
+        uint4 base = make_uint4(0, 0, 0, 0), tot = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t c = s_wcount[i];
-            if (i < w) wbase += c;
-            n += c;
+            const uint4 c = s_wcount[i];
+            if (i < w) { base.x += c.x; base.y += c.y; base.z += c.z; base.w += c.w; }
+            tot.x += c.x; tot.y += c.y; tot.z += c.z; tot.w += c.w;
         }
-        if (keep) {
-            const uint32_t slot = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            s_xy[slot] = xy;
-            s_co[slot] = co;
-            s_cd[slot] = cd;
-            s_pos[slot] = e - r0 + 1;  // value of `contributor` when this entry is visited
+        const uint32_t pos_e = e - r0 + 1;  // value of `contributor` when this entry is visited
+#define GVD_PUT(S, M, B)                                                                          \
+        if (smask & (1u << S)) {                                                                  \
+            const uint32_t slot = (B) + (uint32_t)__popcll((M) & below);                          \
+            s_xy4[S][slot] = xy; s_co4[S][slot] = co; s_cd4[S][slot] = cd; s_pos4[S][slot] = pos_e; \
         }
+        GVD_PUT(0, m0, base.x)
+        GVD_PUT(1, m1, base.y)
+        GVD_PUT(2, m2, base.z)
+        GVD_PUT(3, m3, base.w)
+#undef GVD_PUT
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w == 0 ? tot.x : w == 1 ? tot.y : w == 2 ? tot.z : tot.w));
+        const float2* s_xy = s_xy4[w];
+        const float4* s_co = s_co4[w];
+        const float4* s_cd = s_cd4[w];
+        const uint32_t* s_pos = s_pos4[w];
         __syncthreads();
         // ---- blend ----
         // Branch-free, 4 entries per trip: the per-entry geometry (power, exp, alpha) of the 4 entries

@@ -189,20 +189,20 @@ __device__ __forceinline__ float gauss_power(float conA, float conB, float conC,
     return fmaf(-0.5f, fmaf(conA * dx, dx, (conC * dy) * dy), -((conB * dx) * dy));
 }
 
-// Conservative tile-level test: can this Gaussian reach alpha >= 1/255 at ANY pixel centre of the
-// 16x16 tile whose first pixel is (x0,y0)?  Used to drop list entries at LDS staging time; never
+// Conservative rectangle-level test: can this Gaussian reach alpha >= 1/255 at ANY pixel centre of the
+// rectangle [x0, x0+xs] x [y0, y0+ys]?  Used to drop list entries at LDS staging time; never
 // changes results (entries it drops are exactly those forward.cu:347-349 / backward.cu:505-507 skip
-// at every pixel).  Exact minimum of the quadratic form over the tile rectangle, plus a rounding
+// at every pixel of the rectangle).  Exact minimum of the quadratic form over the rectangle, plus a rounding
 // margin >> the fp32 evaluation error of gauss_power (DESIGN.md "tile culling").
-__device__ __forceinline__ bool tile_may_contribute(float mx, float my, float conA, float conB, float conC,
-                                                    float opacity, float x0, float y0)
+__device__ __forceinline__ bool rect_may_contribute(float mx, float my, float conA, float conB, float conC,
+                                                    float opacity, float x0, float y0, float xs, float ys)
 {
     if (!(opacity >= (1.0f / 255.0f))) return false;         // alpha <= opacity * 1
     // the closed-form minimum below needs a positive-definite conic; otherwise keep the entry
     if (!(conA > 0.0f && conC > 0.0f && conA * conC - conB * conB > 0.0f)) return true;
     const float tau = __logf(255.0f * opacity);              // need q <= tau
-    const float ax = x0 - mx, bx = (x0 + 15.0f) - mx;        // pixel - mean, over the tile
-    const float ay = y0 - my, by = (y0 + 15.0f) - my;
+    const float ax = x0 - mx, bx = (x0 + xs) - mx;           // pixel - mean, over the rectangle
+    const float ay = y0 - my, by = (y0 + ys) - my;
     const float cx = fminf(fmaxf(0.0f, ax), bx);
     const float cy = fminf(fmaxf(0.0f, ay), by);
     float qmin;
@@ -224,6 +224,25 @@ __device__ __forceinline__ bool tile_may_contribute(float mx, float my, float co
     const float margin = 1.0e-5f * mag + 1.0e-5f * fabsf(tau) + 1.0e-4f;
     // NaN-safe: any NaN in qmin keeps the entry.
     return !(qmin > tau + margin);
+}
+
+// The 16x16 tile whose first pixel is (x0, y0).
+__device__ __forceinline__ bool tile_may_contribute(float mx, float my, float conA, float conB, float conC,
+                                                    float opacity, float x0, float y0)
+{
+    return rect_may_contribute(mx, my, conA, conB, conC, opacity, x0, y0, 15.0f, 15.0f);
+}
+
+// Bit s set: the Gaussian may contribute to the 16x4 pixel strip (rows 4s..4s+3 of the tile) that wave s of a
+// blend workgroup owns.  The union of the four strips is the tile.
+__device__ __forceinline__ uint32_t strip_mask(float mx, float my, float conA, float conB, float conC,
+                                               float opacity, float x0, float y0)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        m |= rect_may_contribute(mx, my, conA, conB, conC, opacity, x0, y0 + 4.0f * (float)s, 15.0f, 3.0f) ? (1u << s) : 0u;
+    return m;
 }
 
 // Sum of 10 per-lane values over the 64 lanes of a wave, 36 instructions in one hand-scheduled block:
