@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const int px = tx * 16 + (lane & 15);
-    const int py = ty * 16 + w * 4 + (lane >> 4);
+    const int px = tx * 16 + (w & 1) * 8 + (lane & 7);      // wave w owns the 8x8 quadrant (w & 1, w >> 1): the per-wave
+    const int py = ty * 16 + (w >> 1) * 8 + (lane >> 3);    // skip of entries that reach none of its pixels fires more often
     const bool inside = px < a.W && py < a.H;
     const float pixfx = (float)px, pixfy = (float)py;
     const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);

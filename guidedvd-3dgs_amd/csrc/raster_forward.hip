@@ -427,8 +427,8 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const int px = tx * 16 + (lane & 15);
-    const int py = ty * 16 + w * 4 + (lane >> 4);
+    const int px = tx * 16 + (w & 1) * 8 + (lane & 7);      // wave w owns the 8x8 quadrant (w & 1, w >> 1)
+    const int py = ty * 16 + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pixfx = (float)px, pixfy = (float)py;
     const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
             xy = reinterpret_cast<const float2*>(a.means2D)[id];
             co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
             cd = reinterpret_cast<const float4*>(a.rgbd)[id];
-            smask = strip_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
+            smask = quad_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         const unsigned long long m0 = __ballot(smask & 1u), m1 = __ballot(smask & 2u), m2 = __ballot(smask & 4u),
@@ -506,11 +506,12 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
             const float test_T = T * (1.f - alpha);                                               \
             const bool go = !(test_T < 0.0001f);        /* false when stopping now or already stopped (T == 0) */ \
             const float Tc = go ? T : 0.0f;                                                       \
-            C0 = fmaf((CD).x * alpha, Tc, C0);                                                    \
-            C1 = fmaf((CD).y * alpha, Tc, C1);                                                    \
-            C2 = fmaf((CD).z * alpha, Tc, C2);                                                    \
+            const float wgt = alpha * Tc;               /* blend weight formed once: c * (alpha * T), not (c * alpha) * T */ \
+            C0 = fmaf((CD).x, wgt, C0);                                                           \
+            C1 = fmaf((CD).y, wgt, C1);                                                           \
+            C2 = fmaf((CD).z, wgt, C2);                                                           \
             weight = fmaf(alpha, Tc, weight);                                                     \
-            D = fmaf((CD).w * alpha, Tc, D);                                                      \
+            D = fmaf((CD).w, wgt, D);                                                             \
             T_keep = go ? test_T : T_keep;                                                        \
             T = go ? test_T : 0.0f;                                                               \
             last_contributor = (go && hit) ? (POS) : last_contributor;                            \

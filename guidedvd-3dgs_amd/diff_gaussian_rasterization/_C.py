@@ -228,6 +228,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return res
 
 
+KEEP_BACKWARD_INTERNALS = False
+LAST_BACKWARD_INTERNALS = {}
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
                                  sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug,
@@ -267,6 +271,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                        dL_dscales.data_ptr(), dL_drotations.data_ptr(), _ptr(conf), int(bool(debug)), _stream())
             if rc < 0:
                 raise _err(rc)
+    if KEEP_BACKWARD_INTERNALS:   # parity tests: the per-Gaussian sums the reference keeps internal (rasterize_points.cu:172-176)
+        LAST_BACKWARD_INTERNALS.update(dL_dconic=dL_dconic, dL_ddepths=dL_ddepths)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -127,6 +127,19 @@ def backward(st, dL_dcolor, dL_ddepth, dL_dalpha):
                            _p(st["alpha"]), _p(st["n_contrib"]), _p(dL_dcolor), _p(dL_ddepth), _p(dL_dalpha),
                            _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]),
                            _p(g["dL_dcolors"]), _p(g["dL_ddepths"]))
+    derived_from_sums(st, g)
+    return g
+
+
+def derived_from_sums(st, g):
+    """Second half of the backward (backward.cu:144-412: cov2D, projection, SH, cov3D) from the per-Gaussian sums
+    g[dL_dmeans2D, dL_dconic, dL_dcolors, dL_ddepths]; fills the derived gradients into g.  Separate so that tests can
+    run the chain on another implementation's sums."""
+    L = lib()
+    P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
+    i = st["_in"]
+    for k in ("dL_dmeans2D", "dL_dconic", "dL_dcolors", "dL_ddepths"):
+        g[k] = np.ascontiguousarray(g[k], np.float32)
     g["dL_dmeans3D"] = np.zeros((P, 3), np.float32)
     g["dL_dcov3D"] = np.zeros((P, 6), np.float32)
     g["dL_dsh"] = np.zeros((P, M, 3), np.float32)

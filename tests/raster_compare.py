@@ -62,11 +62,15 @@ def run_hip(sc, cam, grads=None, colors_precomp=None, cov3D_precomp=None, device
         gC, gD, gA = (t(x) for x in grads)
         if alpha_override is not None:  # isolate the backward kernels from forward rounding differences
             alpha = t(alpha_override).reshape(1, H, W)
+        _C.KEEP_BACKWARD_INTERNALS = True
         res = _C.rasterize_gaussians_backward(bg, m3, radii, col, scales, rots, 1.0, cov, vm, pm, cam["tanfovx"],
                                               cam["tanfovy"], gC.reshape(3, H, W), gD.reshape(1, H, W), gA.reshape(1, H, W),
                                               sh, sc["sh_degree"], cp, gb, R, bb, ib, alpha, debug)
         names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
         g = {n: x.cpu().numpy() for n, x in zip(names, res)}
+        _C.KEEP_BACKWARD_INTERNALS = False
+        g["dL_dconic"] = _C.LAST_BACKWARD_INTERNALS.pop("dL_dconic").reshape(-1, 4).cpu().numpy()
+        g["dL_ddepths"] = _C.LAST_BACKWARD_INTERNALS.pop("dL_ddepths").cpu().numpy()
     return st, g
 
 

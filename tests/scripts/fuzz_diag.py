@@ -4,7 +4,7 @@ for p in (ROOT, os.path.join(ROOT, "guidedvd-3dgs_amd"), os.path.join(ROOT, "tes
 import numpy as np
 from raster_compare import run_hip, run_oracle, rel_to_max
 from test_raster_fuzz_gpu import _scene
-for seed in (1, 2, 4, 10):
+for seed in [int(a) for a in sys.argv[1:]] or (1, 2, 4, 10):
     sc, cam, grads = _scene(seed)
     st_o, g_o = run_oracle(sc, cam, grads)
     _, g = run_hip(sc, cam, grads, alpha_override=st_o["alpha"])
