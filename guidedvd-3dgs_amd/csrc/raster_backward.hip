@@ -30,6 +30,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     __shared__ uint32_t s_ord[256];
     __shared__ float s_part[4][256][kNV];
     __shared__ uint32_t s_wcount[4];
+    __shared__ uint4 s_wcount4[4];
+    __shared__ __attribute__((aligned(4))) uint16_t s_list[4][260];  // per quadrant (= wave): slots of the entries that can reach it
     __shared__ uint32_t s_max;
 
     const int tile = (int)a.tile_order[blockIdx.x];
@@ -88,7 +90,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 
     for (uint32_t bdone = 0; bdone < tile_max; bdone += 256) {
         // ---- stage (descending list order) + cull + compact ----
-        bool keep = false;
+        uint32_t smask = 0;
         float2 xy;
         float4 co, cd;
         uint32_t id = 0, ord = 0;
@@ -98,30 +100,46 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             xy = reinterpret_cast<const float2*>(a.means2D)[id];
             co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
             cd = reinterpret_cast<const float4*>(a.rgbd)[id];
-            keep = tile_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
+            smask = quad_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
         }
+        const bool keep = smask != 0;
         {
             float4* z = reinterpret_cast<float4*>(&s_part[0][0][0]);
 #pragma unroll
             for (int i = 0; i < (4 * 256 * kNV / 4) / 256; i++) z[i * 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const unsigned long long below = (1ull << lane) - 1ull;
         const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wcount[w] = (uint32_t)__popcll(m);
+        const unsigned long long m0 = __ballot(smask & 1u), m1 = __ballot(smask & 2u), m2 = __ballot(smask & 4u),
+                                 m3 = __ballot(smask & 8u);
+        if (lane == 0) {
+            s_wcount[w] = (uint32_t)__popcll(m);
+            s_wcount4[w] = make_uint4((uint32_t)__popcll(m0), (uint32_t)__popcll(m1), (uint32_t)__popcll(m2), (uint32_t)__popcll(m3));
+        }
         __syncthreads();
-        uint32_t wbase = 0, n = 0;
+        uint32_t wbase = 0;
+        uint4 base = make_uint4(0, 0, 0, 0), tot = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t c = s_wcount[i];
-            if (i < w) wbase += c;
-            n += c;
+            const uint4 c4 = s_wcount4[i];
+            if (i < w) { wbase += c; base.x += c4.x; base.y += c4.y; base.z += c4.z; base.w += c4.w; }
+            tot.x += c4.x; tot.y += c4.y; tot.z += c4.z; tot.w += c4.w;
         }
-        const uint32_t slot = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t slot = wbase + (uint32_t)__popcll(m & below);
         if (keep) {
             s_xy[slot] = xy;
             s_co[slot] = co;
             s_cd[slot] = cd;
             s_ord[slot] = ord;
+            if (smask & 1u) s_list[0][base.x + (uint32_t)__popcll(m0 & below)] = (uint16_t)slot;
+            if (smask & 2u) s_list[1][base.y + (uint32_t)__popcll(m1 & below)] = (uint16_t)slot;
+            if (smask & 4u) s_list[2][base.z + (uint32_t)__popcll(m2 & below)] = (uint16_t)slot;
+            if (smask & 8u) s_list[3][base.w + (uint32_t)__popcll(m3 & below)] = (uint16_t)slot;
         }
+        // entries of the batch that can reach this wave's quadrant, walked in list order
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w == 0 ? tot.x : w == 1 ? tot.y : w == 2 ? tot.z : tot.w));
+        const uint32_t* my_list = reinterpret_cast<const uint32_t*>(s_list[w]);  // two 16-bit slots per word
         __syncthreads();
 
         // ---- per-pixel gradient terms, wave-reduced per Gaussian ----
@@ -136,20 +154,20 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 // doubled the dL_dscales error and was rejected.
 #define GVD_BWD_RCP(D) ([&] { const float r0_ = __builtin_amdgcn_rcpf(D); return fmaf(fmaf(-(D), r0_, 1.0f), r0_, r0_); }())
 #define GVD_BWD_GEOM(J, DX, DY, G, ALPHA, ACT)                                                    \
-        const float2 gxy##J = s_xy[j + J];                                                        \
-        const float4 con##J = s_co[j + J];                                                        \
+        const float2 gxy##J = s_xy[sl##J];                                                        \
+        const float4 con##J = s_co[sl##J];                                                        \
         const float DX = gxy##J.x - pixfx, DY = gxy##J.y - pixfy;                                 \
         const float pw##J = gauss_power(con##J.x, con##J.y, con##J.z, DX, DY);                    \
         const float G = __expf(pw##J);                                                            \
         const float ALPHA = fminf(0.99f, con##J.w * G);                                           \
-        const bool ACT = (s_ord[j + J] < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);
+        const bool ACT = (s_ord[sl##J] < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);
 // Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the value the next
 // active entry would have formed (pushing (last_alpha=0, .) is the identity: fmaf(1, acc, 0*c) == acc
 // bit-exactly) and all ten terms are exactly 0 -- no per-variable selects needed.
 #define GVD_BWD_TERMS(J, DX, DY, G, ALPHA, ACT, V)                                                \
         float V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9;                         \
         {                                                                                         \
-            const float4 c = s_cd[j + J];                                                         \
+            const float4 c = s_cd[sl##J];                                                         \
             const float am = ACT ? ALPHA : 0.f;                                                   \
             const float gm = ACT ? G : 0.f;                                                       \
             const float one_m_a = 1.f - am;                                                       \
@@ -193,13 +211,16 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 #define GVD_BWD_STORE10(J, V)                                                                     \
         wave_reduce10(V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9);                \
         if ((lane & 31) == 31) {                                                                  \
-            float* o = &s_part[w][j + J][(lane >> 5) * 5];                                        \
+            float* o = &s_part[w][sl##J][(lane >> 5) * 5];                                        \
             o[0] = V##0; o[1] = V##1; o[2] = V##2; o[3] = V##3; o[4] = V##4;                      \
         }
         {
 #pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
             uint32_t j = 0;
+            uint32_t pair = my_list[0];   // slots of entries j, j+1 (prefetched one trip ahead; the list is padded)
             for (; j + 2 <= n; j += 2) {
+                const uint32_t sl0 = pair & 0xffffu, sl1 = pair >> 16;
+                pair = my_list[(j >> 1) + 1];
                 GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
                 GVD_BWD_GEOM(1, dx1, dy1, G1, alpha1, act1)
                 const bool any0 = __any(act0), any1 = __any(act1);
@@ -208,7 +229,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                     GVD_BWD_TERMS(1, dx1, dy1, G1, alpha1, act1, q)
                     wave_reduce20(p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, q0, q1, q2, q3, q4, q5, q6, q7, q8, q9);
                     if ((lane & 15) == 15) {  // row 0: A[0..4], row 1: B[0..4], row 2: A[5..9], row 3: B[5..9]
-                        float* o = &s_part[w][j + ((lane >> 4) & 1)][(lane >> 5) * 5];
+                        float* o = &s_part[w][(lane & 16) ? sl1 : sl0][(lane >> 5) * 5];
                         o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3; o[4] = p4;
                     }
                 } else if (any0) {
@@ -220,6 +241,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                 }
             }
             if (j < n) {
+                const uint32_t sl0 = pair & 0xffffu;
                 GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
                 if (__any(act0)) {
                     GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
