@@ -233,14 +233,16 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     SortArgs so{};
     so.capacity = capacity; so.ranges = (const uint32_t*)(img + L.ranges); so.bucket = (uint64_t*)(bin + L.bucket);
     so.point_list = (uint32_t*)(bin + L.point_list); so.keys = (uint64_t*)(bin + L.keys);
-    {
+    static const bool fused_sort = !(getenv("GVD_RASTER_FUSED_SORT") && atoi(getenv("GVD_RASTER_FUSED_SORT")) == 0);
+    if (!fused_sort || max_class >= 1) {
         ProfScope ps("sort_tiles", stream);
-        launch_sort_tiles(so, L.T, max_class, stream);
+        launch_sort_tiles(so, L.T, max_class, !fused_sort, stream);
     }
     AFTER_LAUNCH("sort_tiles");
     RenderArgs ra{};
     ra.W = in.width; ra.H = in.height; ra.gx = L.gx; ra.gy = L.gy; ra.capacity = capacity;
-    ra.ranges = (const uint32_t*)(img + L.ranges); ra.point_list = (const uint32_t*)(bin + L.point_list);
+    ra.fused_sort = fused_sort ? 1 : 0; ra.bucket = so.bucket; ra.keys = so.keys;
+    ra.ranges = (const uint32_t*)(img + L.ranges); ra.point_list = (uint32_t*)(bin + L.point_list);
     ra.means2D = (const float*)(geom + L.means2D); ra.conic_opacity = (const float*)(geom + L.conic_opacity);
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = in.background;
     ra.out_color = in.out_color; ra.out_depth = in.out_depth; ra.out_alpha = in.out_alpha;

@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     __shared__ uint4 s_wcount4[4];
     __shared__ __attribute__((aligned(4))) uint16_t s_list[4][260];  // per quadrant (= wave): slots of the entries that can reach it
     __shared__ uint32_t s_max;
+    __shared__ uint32_t s_qmax[4];
 
     const int tile = (int)a.tile_order[blockIdx.x];
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -76,9 +77,13 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         uint32_t m = last_contributor;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-        if (lane == 0 && m) atomicMax(&s_max, m);
+        if (lane == 0) {
+            s_qmax[w] = m;   // entries at or behind this position contribute to no pixel of quadrant w
+            if (m) atomicMax(&s_max, m);
+        }
     }
     __syncthreads();
+    const uint32_t qmax0 = s_qmax[0], qmax1 = s_qmax[1], qmax2 = s_qmax[2], qmax3 = s_qmax[3];
     const uint32_t tile_max = min(s_max, r1 - r0);
     if (tile_max == 0) return;
 
@@ -101,6 +106,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
             cd = reinterpret_cast<const float4*>(a.rgbd)[id];
             smask = quad_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
+            smask &= (ord < qmax0 ? 1u : 0u) | (ord < qmax1 ? 2u : 0u) | (ord < qmax2 ? 4u : 0u) | (ord < qmax3 ? 8u : 0u);
         }
         const bool keep = smask != 0;
         {

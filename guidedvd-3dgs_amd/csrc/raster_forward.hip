@@ -149,15 +149,18 @@ __global__ void __launch_bounds__(256) k_preprocess(PreprocessArgs a)
 
 // ------------------------------------------------------------------------------------------------
 // k_colscan: hist[b][t] -> exclusive prefix over b (in place); tile_count[t] = column total.
-// Block = 1024 threads = 16 b-segments x 64 tiles; grid = ceil(T/64).
+// Block = 1024 threads = kColSegs b-segments x kColTiles tiles; grid = ceil(T / kColTiles).  The kernel is a chain of
+// dependent global round trips (sum pass, then rewrite pass), so the column is cut into many short segments: 64
+// segments of ceil(B/64) rows need 2 + 2 trips of 8 loads in flight for B = 782 where 16 segments needed 7 + 7.
 // ------------------------------------------------------------------------------------------------
+constexpr int kColTiles = 16, kColSegs = 1024 / kColTiles;
 __global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_count, int B, int T)
 {
-    __shared__ uint32_t s_seg[16][64];
-    const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + tl;
-    const int per = (B + 15) / 16;
-    const int b0 = seg * per, b1 = min(B, b0 + per);
+    __shared__ uint32_t s_seg[kColSegs][kColTiles];
+    const int tl = threadIdx.x % kColTiles, seg = threadIdx.x / kColTiles;
+    const int t = blockIdx.x * kColTiles + tl;
+    const int per = (B + kColSegs - 1) / kColSegs;
+    const int b0 = min(B, seg * per), b1 = min(B, b0 + per);
     constexpr int U = 8;  // loads in flight per lane (the loop is latency-, not bandwidth-bound)
     uint32_t sum = 0;
     if (t < T) {
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, u
                 run += v[u];
             }
         }
-        if (seg == 15) tile_count[t] = run;  // per*16 >= B so the last segment ends at B
+        if (seg == kColSegs - 1) tile_count[t] = run;  // the last segment's running total is the column total
     }
 }
 
@@ -228,18 +231,36 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
     if (tid < 256) s_bins[tid] = 0;
     __syncthreads();
     // ---- tiles ----
+    // Every global value this block needs is fetched once, up front and together (one round trip; the kernel is a single
+    // workgroup, so each dependent trip to memory is ~1 us of GPU idle time); up to kKeep tile counts per thread stay in
+    // registers, larger images re-read them (L2 hits).
+    constexpr int kKeep = 4;
     const int per = (a.T + 1023) / 1024;
     const int t0 = tid * per, t1 = min(a.T, t0 + per);
+    const int perb = (a.B + 1023) / 1024;
+    const int b0 = tid * perb, b1 = min(a.B, b0 + perb);
+    uint32_t kept[kKeep];
+#pragma unroll
+    for (int i = 0; i < kKeep; i++) kept[i] = (t0 + i < t1) ? a.tile_count[t0 + i] : 0u;
+    uint32_t lb = 0, first_bt = 0;
+    for (int b = b0; b < b1; b++) {
+        const uint32_t x = a.block_total[b];
+        if (b == b0) first_bt = x;
+        lb += x;
+    }
+#define GVD_TILE_COUNT(T_, I_) ((I_) < kKeep ? kept[(I_) < kKeep ? (I_) : 0] : a.tile_count[T_])
     uint32_t local = 0, lmax = 0;
-    for (int t = t0; t < t1; t++) {
-        const uint32_t c = a.tile_count[t];
+#pragma unroll 4
+    for (int t = t0, i = 0; t < t1; t++, i++) {
+        const uint32_t c = GVD_TILE_COUNT(t, i);
         local += c;
         lmax = max(lmax, c);
     }
     uint32_t total;
     uint32_t run = block_excl_scan_1024(local, s_w, &total);
-    for (int t = t0; t < t1; t++) {
-        const uint32_t c = a.tile_count[t];
+#pragma unroll 4
+    for (int t = t0, i = 0; t < t1; t++, i++) {
+        const uint32_t c = GVD_TILE_COUNT(t, i);
         // untouched tiles stay (0,0) like the reference's memset (rasterizer_impl.cu:311)
         a.ranges[2 * t] = c ? run : 0u;
         a.ranges[2 * t + 1] = c ? run + c : 0u;
@@ -257,21 +278,19 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
         const uint32_t excl = block_excl_scan_1024(mine, s_w, &tb);
         if (tid < 256) s_bins[tid] = excl;
         __syncthreads();
-        for (int t = t0; t < t1; t++) {
-            const uint32_t pos = atomicAdd(&s_bins[cost_bucket(a.tile_count[t])], 1u);
+#pragma unroll 4
+        for (int t = t0, i = 0; t < t1; t++, i++) {
+            const uint32_t pos = atomicAdd(&s_bins[cost_bucket(GVD_TILE_COUNT(t, i))], 1u);
             a.tile_order[pos] = (uint32_t)t;
         }
     }
+#undef GVD_TILE_COUNT
     // ---- per-block instance bases (exclusive scan of block_total) ----
-    const int perb = (a.B + 1023) / 1024;
-    const int b0 = tid * perb, b1 = min(a.B, b0 + perb);
-    uint32_t lb = 0;
-    for (int b = b0; b < b1; b++) lb += a.block_total[b];
     uint32_t totb;
     uint32_t runb = block_excl_scan_1024(lb, s_w, &totb);
     for (int b = b0; b < b1; b++) {
         a.chunk_base[b] = runb;
-        runb += a.block_total[b];
+        runb += (b == b0) ? first_bt : a.block_total[b];
     }
     __syncthreads();
     if (tid == 0) {
@@ -437,6 +456,26 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;  // overflowed forward: render background, status already flagged
 
+    // ---- fused per-tile sort (the k_sort_tiles<0> work, done by the workgroup that consumes the list) ----
+    // A separate sort launch lasts as long as its longest list (a chain of ~60 barrier-separated LDS stages) while most
+    // of the GPU idles; here that chain overlaps with the other tiles' blending.
+    extern __shared__ uint64_t s_sorted[];   // kFusedSortMax entries (+ the occupancy pad)
+    const bool sorted_here = a.fused_sort && (r1 - r0) <= kFusedSortMax;
+    if (sorted_here && r1 > r0) {
+        const uint32_t n = r1 - r0;
+        uint64_t* g = a.bucket + r0;
+        for (uint32_t i = tid; i < n; i += 256) s_sorted[i] = g[i];
+        __syncthreads();
+        bitonic_sort_u64<256>(s_sorted, n);
+        const uint64_t thi = ((uint64_t)(uint32_t)tile) << 32;
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint64_t e = s_sorted[i];
+            g[i] = e;
+            a.point_list[r0 + i] = (uint32_t)e;
+            a.keys[r0 + i] = thi | (e >> 32);
+        }
+    }
+
     float T = inside ? 1.0f : 0.0f, T_keep = 1.0f;   // live transmittance (0 = pixel finished) / value kept for the background
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
@@ -450,7 +489,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         float2 xy;
         float4 co, cd;
         if (e < r1) {
-            const uint32_t id = a.point_list[e];
+            const uint32_t id = sorted_here ? (uint32_t)s_sorted[e - r0] : a.point_list[e];
             xy = reinterpret_cast<const float2*>(a.means2D)[id];
             co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
             cd = reinterpret_cast<const float4*>(a.rgbd)[id];
@@ -570,7 +609,7 @@ void launch_preprocess(const PreprocessArgs& a, int blocks, bool lds_hist, hipSt
 }
 void launch_colscan(uint32_t* hist, uint32_t* tile_count, int B, int T, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_colscan, dim3((T + 63) / 64), dim3(1024), 0, s, hist, tile_count, B, T);
+    hipLaunchKernelGGL(k_colscan, dim3((T + kColTiles - 1) / kColTiles), dim3(1024), 0, s, hist, tile_count, B, T);
 }
 void launch_tilescan(const TileScanArgs& a, hipStream_t s)
 {
@@ -581,7 +620,7 @@ void launch_scatter(const ScatterArgs& a, int blocks, bool lds_hist, hipStream_t
     if (lds_hist) hipLaunchKernelGGL(k_scatter<true>, dim3(blocks), dim3(256), (size_t)a.T * 4, s, a);
     else hipLaunchKernelGGL(k_scatter<false>, dim3(blocks), dim3(256), 0, s, a);
 }
-void launch_sort_tiles(const SortArgs& a, int T, int max_class, hipStream_t s)
+void launch_sort_tiles(const SortArgs& a, int T, int max_class, bool short_lists_too, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -589,7 +628,8 @@ void launch_sort_tiles(const SortArgs& a, int T, int max_class, hipStream_t s)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_sort_tiles<0>, dim3(T), dim3(256), 2048 * 8, s, a);
+    // lists of <= kFusedSortMax entries are normally sorted inside k_render_fwd
+    if (short_lists_too) hipLaunchKernelGGL(k_sort_tiles<0>, dim3(T), dim3(256), 2048 * 8, s, a);
     if (max_class >= 1) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(T), dim3(1024), 16384 * 8, s, a);
     if (max_class >= 2) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(T), dim3(1024), 0, s, a);
 }
@@ -603,7 +643,7 @@ void launch_render_fwd(const RenderArgs& a, int T, hipStream_t s)
     // Extra (unused) dynamic LDS caps the resident workgroups per CU so that the hardware dispatcher
     // hands out the LPT-ordered tiles dynamically instead of placing every tile at t=0.
     static const size_t pad = env_bytes("GVD_FWD_LDS_PAD", 0);
-    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), pad, s, a);
+    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), (a.fused_sort ? (size_t)kFusedSortMax * 8 : 0) + pad, s, a);
 }
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
 {

@@ -46,7 +46,11 @@ struct SortArgs {
 struct RenderArgs {
     int W, H, gx, gy;
     uint32_t capacity;
-    const uint32_t *ranges, *point_list, *tile_order;
+    int fused_sort;       // 1: lists of <= kFusedSortMax entries are still unsorted in `bucket`; the tile's workgroup sorts its own
+    uint64_t* bucket;     //    list in LDS first and writes bucket / point_list / keys (what k_sort_tiles<0> would have written)
+    uint64_t* keys;
+    uint32_t* point_list;
+    const uint32_t *ranges, *tile_order;
     const float *means2D, *conic_opacity, *rgbd, *bg;
     float *out_color, *out_depth, *out_alpha;
     uint32_t* n_contrib;
@@ -80,7 +84,8 @@ void launch_preprocess(const PreprocessArgs& a, int blocks, bool lds_hist, hipSt
 void launch_colscan(uint32_t* hist, uint32_t* tile_count, int B, int T, hipStream_t s);
 void launch_tilescan(const TileScanArgs& a, hipStream_t s);
 void launch_scatter(const ScatterArgs& a, int blocks, bool lds_hist, hipStream_t s);
-void launch_sort_tiles(const SortArgs& a, int T, int max_class, hipStream_t s);
+void launch_sort_tiles(const SortArgs& a, int T, int max_class, bool short_lists_too, hipStream_t s);
+constexpr uint32_t kFusedSortMax = 2048;  // longest list a blend workgroup sorts itself (16 KiB of LDS)
 void launch_render_fwd(const RenderArgs& a, int T, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s);
