@@ -195,7 +195,7 @@ int forward_stage1(const FwdIn& in, const gvd::Layout& L, char* geom, char* img,
     }
     AFTER_LAUNCH("colscan");
     TileScanArgs ta{};
-    ta.T = L.T; ta.B = L.bin_blocks; ta.capacity = capacity;
+    ta.T = L.T; ta.B = L.bin_blocks; ta.gx = L.gx; ta.capacity = capacity;
     ta.tile_count = tile_count; ta.block_total = (uint32_t*)(geom + L.block_total);
     ta.ranges = (uint32_t*)(img + L.ranges);
     ta.cursor = L.lds_hist ? nullptr : (uint32_t*)(geom + L.cursor);
@@ -298,7 +298,7 @@ void gvd_raster_chunk_layout(int P, int width, int height, uint32_t num_rendered
     o->cov3D = L.cov3D; o->clamped = L.clamped; o->internal_radii = L.internal_radii;
     o->tiles_touched = L.tiles_touched; o->point_offsets = L.point_offsets; o->scalars = L.scalars;
     o->ranges = L.ranges; o->n_contrib = L.n_contrib;
-    o->point_list_keys = L.keys; o->point_list = L.point_list; o->bucket = L.bucket;
+    o->point_list_keys = L.keys; o->point_list = L.point_list; o->bucket = L.bucket; o->tile_order = L.tile_order;
 }
 
 uint32_t gvd_raster_chunk_capacity(const void* binning_chunk, uint32_t num_rendered)

@@ -221,14 +221,24 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t c)
     return 255u - k;
 }
 
+// Image region (0..7) of tile t: 2x2-tile blocks (32x32 pixels) dealt to the regions in a skewed round-robin, so that
+// every region is a uniform sample of the image (similar total list length: the blend kernels last as long as their
+// slowest XCD) while the ~5 tiles a Gaussian touches still fall into few regions.
+__device__ __forceinline__ int xcd_region(int t, int gx)
+{
+    const int ty = t / gx, tx = t - ty * gx;
+    return ((tx >> 1) + 3 * (ty >> 1)) & 7;
+}
+
 __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
-    __shared__ uint32_t s_bins[256];
+    __shared__ uint32_t s_bins[8][256];   // per XCD region: tiles per cost bucket, then running output ranks
+    __shared__ uint32_t s_rcount[8];
     const int tid = threadIdx.x;
     if (tid == 0) s_max = 0;
-    if (tid < 256) s_bins[tid] = 0;
+    for (int i = tid; i < 8 * 256; i += 1024) (&s_bins[0][0])[i] = 0;
     __syncthreads();
     // ---- tiles ----
     // Every global value this block needs is fetched once, up front and together (one round trip; the kernel is a single
@@ -266,21 +276,44 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
         a.ranges[2 * t + 1] = c ? run + c : 0u;
         if (a.cursor) a.cursor[t] = run;
         run += c;
-        atomicAdd(&s_bins[cost_bucket(c)], 1u);
+        atomicAdd(&s_bins[xcd_region(t, a.gx)][cost_bucket(c)], 1u);
     }
     if (lmax) atomicMax(&s_max, lmax);
-    // ---- tile_order: tiles in (coarsely) descending list length, so that the blend kernels'
-    //      workgroups are dispatched longest-first (LPT) and the tail of the launch is short ----
+    // ---- tile_order: the blend kernels' workgroup b works on tile_order[b].  Two goals:
+    //   * longest lists first (LPT), so that the tail of the launch is short;
+    //   * XCD locality: block b is observed to run on XCD b % 8 and every XCD has its own L2, so position b gets a
+    //     tile of image region b % 8 (xcd_region): an XCD then pulls mostly its own regions' Gaussians (means2D /
+    //     conic / colour records) through its L2 instead of every XCD pulling all of them.
+    //   Within a region tiles are ranked by a 256-bucket counting sort on the list length; rank r of region x goes to
+    //   position 8 r + x.  The ranks beyond the smallest region's size fill the end of the order. ----
     __syncthreads();
     {
-        uint32_t tb;
-        const uint32_t mine = tid < 256 ? s_bins[tid] : 0u;
-        const uint32_t excl = block_excl_scan_1024(mine, s_w, &tb);
-        if (tid < 256) s_bins[tid] = excl;
+        const int w = tid >> 6, lane = tid & 63;
+        if (w < 8) {   // wave w: exclusive scan of region w's 256 buckets (4 per lane)
+            uint32_t v[4], sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { v[i] = s_bins[w][4 * lane + i]; sum += v[i]; }
+            const uint32_t incl = wave_incl_scan_u32(sum);
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { s_bins[w][4 * lane + i] = run; run += v[i]; }
+            if (lane == 63) s_rcount[w] = incl;
+        }
         __syncthreads();
+        uint32_t cmin = 0xffffffffu;
+#pragma unroll
+        for (int x = 0; x < 8; x++) cmin = min(cmin, s_rcount[x]);
 #pragma unroll 4
         for (int t = t0, i = 0; t < t1; t++, i++) {
-            const uint32_t pos = atomicAdd(&s_bins[cost_bucket(GVD_TILE_COUNT(t, i))], 1u);
+            const int x = xcd_region(t, a.gx);
+            const uint32_t r = atomicAdd(&s_bins[x][cost_bucket(GVD_TILE_COUNT(t, i))], 1u);
+            uint32_t pos;
+            if (r < cmin) {
+                pos = 8u * r + (uint32_t)x;
+            } else {
+                pos = 8u * cmin + (r - cmin);
+                for (int y = 0; y < x; y++) pos += s_rcount[y] - cmin;
+            }
             a.tile_order[pos] = (uint32_t)t;
         }
     }

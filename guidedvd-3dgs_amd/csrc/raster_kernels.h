@@ -16,7 +16,7 @@ struct PreprocessArgs {
 };
 
 struct TileScanArgs {
-    int T, B;
+    int T, B, gx;
     uint32_t capacity;
     const uint32_t* tile_count;
     const uint32_t* block_total;

@@ -28,7 +28,7 @@ _P = ctypes.c_void_p
 class _ChunkLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "depths", "means2D", "conic_opacity", "rgbd", "cov3D", "clamped", "internal_radii", "tiles_touched",
-        "point_offsets", "scalars", "ranges", "n_contrib", "point_list_keys", "point_list", "bucket")]
+        "point_offsets", "scalars", "ranges", "n_contrib", "point_list_keys", "point_list", "bucket", "tile_order")]
 
 
 def lib():
@@ -321,6 +321,7 @@ def chunk_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):
         scalars=view(g, lay.scalars, 32, torch.int32),
         ranges=view(i, lay.ranges, 8 * T, torch.int32).view(T, 2),
         n_contrib=view(i, lay.n_contrib, 4 * W * H, torch.int32).view(H, W),
+        tile_order=view(i, lay.tile_order, 4 * T, torch.int32),
         point_list_keys=view(b, lay.point_list_keys, 8 * R, torch.int64) if R > 0 else None,
         point_list=view(b, lay.point_list, 4 * R, torch.int32) if R > 0 else None,
     )

@@ -233,6 +233,8 @@ typedef struct gvd_chunk_layout {
     size_t point_list_keys; /* u64[R] sorted (tile<<32 | depth bits)     */
     size_t point_list;      /* u32[R] sorted Gaussian ids                */
     size_t bucket;          /* u64[R] per-tile (depth bits<<32 | id), sorted in place */
+    /* image chunk, continued */
+    size_t tile_order;      /* u32[tiles]: tile handled by blend workgroup b (longest lists first, image region b % 8) */
 } gvd_chunk_layout;
 
 void gvd_raster_chunk_layout(int P, int width, int height, uint32_t num_rendered, gvd_chunk_layout* out);

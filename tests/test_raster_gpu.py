@@ -391,3 +391,32 @@ def test_many_outstanding_speculative_forwards_then_backward():
         color.backward(gC)
         for n in prm:
             assert torch.equal(prm[n].grad, held[k][1][n].grad), (k, n)
+
+
+def test_tile_dispatch_order_is_a_permutation_by_image_region():
+    """k_tilescan's tile_order: every tile exactly once; workgroup b (observed on XCD b % 8) gets a tile of image region
+    b % 8, and inside a region the lists come longest first (256 geometric cost buckets)."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    sc = syn.scene_c2(P=20000, W=400, H=272)
+    cam = sc["cameras"][1]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda:0")
+    E = torch.Tensor([])
+    W, H = cam["image_width"], cam["image_height"]
+    out = _C.rasterize_gaussians(t(sc["bg"]), t(sc["means3D"]), E, t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"]), 1.0, E,
+                                 t(cam["viewmatrix"]), t(cam["projmatrix"]), cam["tanfovx"], cam["tanfovy"], H, W, t(sc["shs"]),
+                                 sc["sh_degree"], t(cam["campos"]), False, False)
+    R, gb, bb, ib = out[0], out[5], out[6], out[7]
+    v = _C.chunk_views(sc["means3D"].shape[0], W, H, R, gb, bb, ib)
+    order = v["tile_order"].cpu().numpy().astype(np.int64)
+    ranges = v["ranges"].cpu().numpy().astype(np.int64)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    assert sorted(order.tolist()) == list(range(T))
+    gx = (W + 15) // 16
+    region = ((order % gx) // 2 + 3 * ((order // gx) // 2)) % 8       # 2x2-tile blocks dealt round-robin (xcd_region)
+    full = 8 * int(np.bincount(region, minlength=8).min())
+    assert full >= T - 64 and np.all(region[:full] == np.arange(full) % 8)
+    length = ranges[order, 1] - ranges[order, 0]
+    for x in range(8):                      # per band: non-increasing up to the bucket resolution (1/16 of a power of two)
+        ln = length[:full][x::8].astype(np.float64)
+        assert np.all(ln[1:] <= ln[:-1] * 1.07 + 1.0), x
