@@ -425,6 +425,58 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t* d, uint32_t n)
     }
 }
 
+// Merge sort by ranking, for lists that fit two LDS buffers (<= kFusedSortMax): every thread first sorts 8 consecutive
+// entries in registers (19-comparator network), then log2(n/8) passes merge neighbouring runs of width w: an entry's
+// output slot is its index in its own run plus the number of smaller entries in the partner run, found by a binary
+// search (keys are unique, so no tie rule is needed).  A pass is one barrier and <= log2(w)+1 dependent LDS reads per
+// entry, against log2(w)+1 barrier-separated compare-exchange stages of the bitonic network: 8 barriers instead of 66
+// for 2048 entries, and the chain of dependent LDS round trips is ~5x shorter -- this chain, on the longest list, is
+// what the sort costs (most workgroups have long finished).  Returns the buffer holding the sorted list; ends with a
+// barrier.  Entries at index >= n do not exist (runs are simply shorter at the end).
+template <int NT>
+__device__ __forceinline__ uint64_t* merge_sort_u64(uint64_t* buf0, uint64_t* buf1, uint32_t n)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t base = 8 * tid; base < n; base += 8 * NT) {
+        uint64_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? buf0[base + i] : ~0ull;
+#define GVD_CE(A, B) { const uint64_t x_ = v[A], y_ = v[B]; v[A] = x_ < y_ ? x_ : y_; v[B] = x_ < y_ ? y_ : x_; }
+        GVD_CE(0, 1) GVD_CE(2, 3) GVD_CE(4, 5) GVD_CE(6, 7)
+        GVD_CE(0, 2) GVD_CE(1, 3) GVD_CE(4, 6) GVD_CE(5, 7)
+        GVD_CE(1, 2) GVD_CE(5, 6) GVD_CE(0, 4) GVD_CE(3, 7)
+        GVD_CE(1, 5) GVD_CE(2, 6)
+        GVD_CE(1, 4) GVD_CE(3, 6)
+        GVD_CE(2, 4) GVD_CE(3, 5)
+        GVD_CE(3, 4)
+#undef GVD_CE
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (base + i < n) buf0[base + i] = v[i];
+    }
+    __syncthreads();
+    uint64_t* src = buf0;
+    uint64_t* dst = buf1;
+    for (uint32_t w = 8; w < n; w <<= 1) {
+        // (Advancing a thread's searches in lockstep -- K independent LDS reads per halving step -- was measured slower
+        //  than these early-exit loops: 31 us against 23 us for the separate sort kernel on the C2 scene.)
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint32_t run = i / w, p = i - run * w;
+            const uint32_t other = (run ^ 1u) * w;                       // first entry of the partner run
+            const uint32_t len = other < n ? min(w, n - other) : 0u;      // its length (0: no partner, the run is copied)
+            const uint64_t key = src[i];
+            uint32_t lo = 0, hi = len;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (src[other + mid] < key) lo = mid + 1; else hi = mid;
+            }
+            dst[(run & ~1u) * w + p + lo] = key;
+        }
+        __syncthreads();
+        uint64_t* t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
 template <int CLASS>
 __global__ void __launch_bounds__(CLASS == 0 ? 256 : 1024) k_sort_tiles(SortArgs a)
 {
@@ -447,7 +499,8 @@ __global__ void __launch_bounds__(CLASS == 0 ? 256 : 1024) k_sort_tiles(SortArgs
         for (uint32_t i = threadIdx.x; i < n; i += NT) d[i] = g[i];
         __syncthreads();
     }
-    bitonic_sort_u64<NT>(d, n);
+    if (CLASS == 0) d = merge_sort_u64<NT>(d, d + kFusedSortMax, n);
+    else bitonic_sort_u64<NT>(d, n);
     const uint64_t thi = ((uint64_t)tile) << 32;
     for (uint32_t i = threadIdx.x; i < n; i += NT) {
         const uint64_t e = d[i];
@@ -492,14 +545,15 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     // ---- fused per-tile sort (the k_sort_tiles<0> work, done by the workgroup that consumes the list) ----
     // A separate sort launch lasts as long as its longest list (a chain of ~60 barrier-separated LDS stages) while most
     // of the GPU idles; here that chain overlaps with the other tiles' blending.
-    extern __shared__ uint64_t s_sorted[];   // kFusedSortMax entries (+ the occupancy pad)
+    extern __shared__ uint64_t s_sort_lds[];   // 2 x kFusedSortMax entries (+ the occupancy pad)
+    uint64_t* s_sorted = s_sort_lds;
     const bool sorted_here = a.fused_sort && (r1 - r0) <= kFusedSortMax;
     if (sorted_here && r1 > r0) {
         const uint32_t n = r1 - r0;
         uint64_t* g = a.bucket + r0;
         for (uint32_t i = tid; i < n; i += 256) s_sorted[i] = g[i];
         __syncthreads();
-        bitonic_sort_u64<256>(s_sorted, n);
+        s_sorted = merge_sort_u64<256>(s_sorted, s_sorted + kFusedSortMax, n);
         const uint64_t thi = ((uint64_t)(uint32_t)tile) << 32;
         for (uint32_t i = tid; i < n; i += 256) {
             const uint64_t e = s_sorted[i];
@@ -662,7 +716,7 @@ void launch_sort_tiles(const SortArgs& a, int T, int max_class, bool short_lists
         attr_set = true;
     }
     // lists of <= kFusedSortMax entries are normally sorted inside k_render_fwd
-    if (short_lists_too) hipLaunchKernelGGL(k_sort_tiles<0>, dim3(T), dim3(256), 2048 * 8, s, a);
+    if (short_lists_too) hipLaunchKernelGGL(k_sort_tiles<0>, dim3(T), dim3(256), (size_t)kFusedSortMax * 16, s, a);
     if (max_class >= 1) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(T), dim3(1024), 16384 * 8, s, a);
     if (max_class >= 2) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(T), dim3(1024), 0, s, a);
 }
@@ -676,7 +730,7 @@ void launch_render_fwd(const RenderArgs& a, int T, hipStream_t s)
     // Extra (unused) dynamic LDS caps the resident workgroups per CU so that the hardware dispatcher
     // hands out the LPT-ordered tiles dynamically instead of placing every tile at t=0.
     static const size_t pad = env_bytes("GVD_FWD_LDS_PAD", 0);
-    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), (a.fused_sort ? (size_t)kFusedSortMax * 8 : 0) + pad, s, a);
+    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), (a.fused_sort ? (size_t)kFusedSortMax * 16 : 0) + pad, s, a);
 }
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
 {
