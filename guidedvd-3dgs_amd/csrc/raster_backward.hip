@@ -279,8 +279,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-Gaussian part of the backward.  `dsh` is where this Gaussian's 3*M SH gradients go (global row,
-// or a row of the block's LDS staging tile).
+// Per-Gaussian part of the backward.  The 3*M SH gradients are an outer product, dsh[3k+c] = (w_k * dRGB[c]) * conf.
+// STAGED == false: `dsh` is the Gaussian's global row and is written directly.  STAGED == true (M == 16): `dsh` is the
+// Gaussian's row of the block's LDS tile and receives only the FACTORS (kShW + k: w_k, kShRGB + c: dRGB[c], kShConf,
+// kShCount: number of basis functions of the active degree); k_gather_bwd expands them when it streams the tile out.
+constexpr int kShW = 0, kShRGB = 16, kShConf = 19, kShCount = 20, kShRow = 21;
+template <bool STAGED>
 __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int idx, float* dsh)
 {
     const bool visible = a.radii[idx] > 0 && a.scalars[2] == 0;  // overflowed forward: all-zero gradients
@@ -290,12 +294,23 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
     if (visible) {
         const uint32_t beg = idx ? a.point_offsets[idx - 1] : 0u;
         const uint32_t end = a.point_offsets[idx];
-        for (uint32_t g = beg; g < end; g++) {
-            const float4* rec = reinterpret_cast<const float4*>(a.partials + (size_t)g * kPartialStride);
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
-            s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;
-            s[8] += r2.x; s[9] += r2.y;
+        // four records' loads in flight per trip (the run is a chain of dependent round trips otherwise); the additions
+        // stay in record order, so the sums are bit-identical to the one-at-a-time loop
+        for (uint32_t g = beg; g < end; g += 4) {
+            float4 r[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4* rec = reinterpret_cast<const float4*>(a.partials + (size_t)min(g + j, end - 1) * kPartialStride);
+                r[j][0] = rec[0]; r[j][1] = rec[1]; r[j][2] = rec[2];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (g + j < end) {
+                    s[0] += r[j][0].x; s[1] += r[j][0].y; s[2] += r[j][0].z; s[3] += r[j][0].w;
+                    s[4] += r[j][1].x; s[5] += r[j][1].y; s[6] += r[j][1].z; s[7] += r[j][1].w;
+                    s[8] += r[j][2].x; s[9] += r[j][2].y;
+                }
+            }
         }
     }
     // Optional per-Gaussian confidence (the fork's Python-side scaling, ref __init__.py:147-157, folded
@@ -320,7 +335,8 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
         dm[0] = dm[1] = dm[2] = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; i++) dcov[i] = 0.f;
-        for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
+        if (STAGED) dsh[kShCount] = 0.f;   // zero basis functions: the whole row streams out as +0
+        else for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
         ds[0] = ds[1] = ds[2] = 0.f;
         dq[0] = dq[1] = dq[2] = dq[3] = 0.f;
         return;
@@ -426,7 +442,7 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
         float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
         const int D = a.D;
 #define SHV(k, ch) sh[3 * (k) + (ch)]
-#define DSH(k, wgt) { const float w_ = (wgt); dsh[3 * (k)] = (w_ * dRGB[0]) * conf; dsh[3 * (k) + 1] = (w_ * dRGB[1]) * conf; dsh[3 * (k) + 2] = (w_ * dRGB[2]) * conf; }
+#define DSH(k, wgt) { const float w_ = (wgt); if (STAGED) dsh[kShW + (k)] = w_; else { dsh[3 * (k)] = (w_ * dRGB[0]) * conf; dsh[3 * (k) + 1] = (w_ * dRGB[1]) * conf; dsh[3 * (k) + 2] = (w_ * dRGB[2]) * conf; } }
         DSH(0, SH_C0);
         int written = 1;
         if (D > 0) {
@@ -485,7 +501,13 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
         }
 #undef SHV
 #undef DSH
-        for (int k = written; k < a.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+        if (STAGED) {
+            dsh[kShRGB] = dRGB[0]; dsh[kShRGB + 1] = dRGB[1]; dsh[kShRGB + 2] = dRGB[2];
+            dsh[kShConf] = conf;
+            dsh[kShCount] = (float)written;
+        } else {
+            for (int k = written; k < a.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+        }
         const float ddx = dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2];
         const float ddy = dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2];
         const float ddz = dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2];
@@ -495,7 +517,8 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
         g1 += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
         g2 += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
     } else {
-        for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
+        if (STAGED) dsh[kShCount] = 0.f;
+        else for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
     }
     dm[0] = g0 * conf; dm[1] = g1 * conf; dm[2] = g2 * conf;
 
@@ -547,16 +570,20 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
 }
 
 // dL_dsh is 48 floats (192 B) per Gaussian: written per thread it is a 192-byte-stride scatter (64 cache
-// lines per store instruction).  Instead each thread drops its row into an LDS tile (row stride 49
-// floats: conflict-free) and the block streams the tile out as contiguous float4 (1 KiB per wave store).
-constexpr int kShRow = 49;
-
+// lines per store instruction).  Instead each thread drops the 21 factors of its row into an LDS tile (odd row stride:
+// conflict-free) and the block expands and streams the tile out as contiguous float4 (1 KiB per wave store).  Staging the
+// factors instead of the 48 products keeps the tile at 21 KiB, so the kernel's occupancy is set by its registers (6
+// workgroups per CU) and not by LDS (3 with a 48-float row): the kernel is a stream of dependent global reads and lives on
+// the number of waves in flight.
 __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
 {
     extern __shared__ float s_sh[];  // [256][kShRow] when M == 16 (launch passes the size), else unused
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool stage_sh = (a.M == 16);
-    if (idx < a.P) gather_body(a, idx, stage_sh ? (s_sh + threadIdx.x * kShRow) : (a.dL_dsh + (size_t)idx * a.M * 3));
+    if (idx < a.P) {
+        if (stage_sh) gather_body<true>(a, idx, s_sh + threadIdx.x * kShRow);
+        else gather_body<false>(a, idx, a.dL_dsh + (size_t)idx * a.M * 3);
+    }
     if (stage_sh) {
         __syncthreads();
         const size_t block_base = (size_t)blockIdx.x * 256 * 48;
@@ -566,8 +593,16 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
             const int i = (k * 256 + (int)threadIdx.x) * 4;  // float index inside the block's 256x48 tile
             if (block_base + i < total) {
                 const int g = i / 48, c = i - g * 48;
-                const float* r = s_sh + g * kShRow + c;
-                *reinterpret_cast<float4*>(a.dL_dsh + block_base + i) = make_float4(r[0], r[1], r[2], r[3]);
+                const float* r = s_sh + g * kShRow;
+                const int count = (int)r[kShCount];
+                const float conf = r[kShConf];
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = c + j, kk = e / 3, ch = e - kk * 3;
+                    o[j] = kk < count ? (r[kShW + kk] * r[kShRGB + ch]) * conf : 0.f;   // same product order as the direct form
+                }
+                *reinterpret_cast<float4*>(a.dL_dsh + block_base + i) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
     }
