@@ -567,21 +567,28 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
 
+    // The records of batch b + 256 are fetched while batch b is blended (the gather id -> means2D / conic / colour is
+    // two dependent trips to L2 that would otherwise sit between two blend loops).
+    float2 nxy = make_float2(0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), ncd = make_float4(0.f, 0.f, 0.f, 0.f);
+#define GVD_FETCH(E)                                                                              \
+        if ((E) < r1) {                                                                           \
+            const uint32_t id = sorted_here ? (uint32_t)s_sorted[(E) - r0] : a.point_list[E];     \
+            nxy = reinterpret_cast<const float2*>(a.means2D)[id];                                 \
+            nco = reinterpret_cast<const float4*>(a.conic_opacity)[id];                           \
+            ncd = reinterpret_cast<const float4*>(a.rgbd)[id];                                    \
+        }
+    GVD_FETCH(r0 + tid)
     for (uint32_t b = r0; b < r1; b += 256) {
         const int num_done = __syncthreads_count(T == 0.0f);
         if (num_done == 256) break;
-        // ---- stage + cull per strip + compact into the four strip lists ----
+        // ---- stage + cull per quadrant + compact into the four quadrant lists ----
         const uint32_t e = b + tid;
         uint32_t smask = 0;
-        float2 xy;
-        float4 co, cd;
-        if (e < r1) {
-            const uint32_t id = sorted_here ? (uint32_t)s_sorted[e - r0] : a.point_list[e];
-            xy = reinterpret_cast<const float2*>(a.means2D)[id];
-            co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
-            cd = reinterpret_cast<const float4*>(a.rgbd)[id];
-            smask = quad_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
-        }
+        const float2 xy = nxy;
+        const float4 co = nco, cd = ncd;
+        if (e < r1) smask = quad_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
+        GVD_FETCH(e + 256)
         const unsigned long long below = (1ull << lane) - 1ull;
         const unsigned long long m0 = __ballot(smask & 1u), m1 = __ballot(smask & 2u), m2 = __ballot(smask & 4u),
                                  m3 = __ballot(smask & 8u);
@@ -663,6 +670,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         }
 #undef GVD_BLEND_ONE
     }
+#undef GVD_FETCH
     if (inside) {
         const size_t pid = (size_t)py * a.W + px;
         const size_t HW = (size_t)a.H * a.W;
