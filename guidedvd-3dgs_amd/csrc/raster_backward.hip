@@ -13,6 +13,7 @@
 //                  SH bwd (:20-139) and cov3D bwd (:278-341) in one pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "raster_kernels.h"
 #include "raster_layout.h"
@@ -617,7 +618,9 @@ __global__ void __launch_bounds__(256) k_scale_cov(int n, float* __restrict__ dL
 
 void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(256), 0, s, a);
+    // Extra (unused) dynamic LDS lowers the resident workgroups per CU: occupancy experiments only.
+    static const size_t pad = getenv("GVD_BWD_LDS_PAD") ? (size_t)atol(getenv("GVD_BWD_LDS_PAD")) : 0;
+    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(256), pad, s, a);
 }
 void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)
 {
