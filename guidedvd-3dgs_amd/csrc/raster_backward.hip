@@ -23,6 +23,10 @@ namespace gvd {
 
 constexpr int kNV = 10;  // reduced values per (Gaussian, tile)
 
+// DA: the caller supplied a gradient for the depth and / or the alpha image.  The usual training step differentiates the
+// colour image only (both pointers NULL); every depth / alpha term is then exactly zero and DA == false leaves those
+// recurrences and products out (about 9 of the ~80 instructions per entry; the depth gradient is written as +0).
+template <bool DA>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 {
     __shared__ float2 s_xy[256];
@@ -66,8 +70,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         dLp0 = a.dL_dpix[pid];
         dLp1 = a.dL_dpix[HW + pid];
         dLp2 = a.dL_dpix[2 * HW + pid];
-        if (a.dL_dpix_depth) dLd = a.dL_dpix_depth[pid];  // NULL == all-zero gradient
-        if (a.dL_dalphas) dLa = a.dL_dalphas[pid];
+        if (DA && a.dL_dpix_depth) dLd = a.dL_dpix_depth[pid];  // NULL == all-zero gradient
+        if (DA && a.dL_dalphas) dLa = a.dL_dalphas[pid];
     }
     float bg_dot = 0.f;  // backward.cu:575-577 accumulation order
     bg_dot += a.bg[0] * dLp0;
@@ -185,13 +189,17 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             acc0 = fmaf(oml, acc0, last_alpha * lc0);                                             \
             acc1 = fmaf(oml, acc1, last_alpha * lc1);                                             \
             acc2 = fmaf(oml, acc2, last_alpha * lc2);                                             \
-            acc_d = fmaf(oml, acc_d, last_alpha * last_depth);                                    \
-            acc_a = fmaf(oml, acc_a, last_alpha);                                                 \
+            if (DA) {                                                                             \
+                acc_d = fmaf(oml, acc_d, last_alpha * last_depth);                                \
+                acc_a = fmaf(oml, acc_a, last_alpha);                                             \
+            }                                                                                     \
             float dL_dopa = (c.x - acc0) * dLp0;                                                  \
             dL_dopa = fmaf(c.y - acc1, dLp1, dL_dopa);                                            \
             dL_dopa = fmaf(c.z - acc2, dLp2, dL_dopa);                                            \
-            dL_dopa = fmaf(c.w - acc_d, dLd, dL_dopa);                                            \
-            dL_dopa = fmaf(1.f - acc_a, dLa, dL_dopa);                                            \
+            if (DA) {                                                                             \
+                dL_dopa = fmaf(c.w - acc_d, dLd, dL_dopa);                                        \
+                dL_dopa = fmaf(1.f - acc_a, dLa, dL_dopa);                                        \
+            }                                                                                     \
             dL_dopa *= T;                                                                         \
             if (has_bg) { /* (-T_final / (1 - alpha)) * (bg . dL_dpix): quotient refined by one residual step */ \
                 float qb = nTf * rinv;                                                            \
@@ -213,7 +221,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             V##6 = dchannel_dcolor * dLp0;                                                        \
             V##7 = dchannel_dcolor * dLp1;                                                        \
             V##8 = dchannel_dcolor * dLp2;                                                        \
-            V##9 = dchannel_dcolor * dLd;                                                         \
+            V##9 = DA ? dchannel_dcolor * dLd : 0.f;                                              \
         }
 #define GVD_BWD_STORE10(J, V)                                                                     \
         wave_reduce10(V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9);                \
@@ -620,7 +628,8 @@ void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 {
     // Extra (unused) dynamic LDS lowers the resident workgroups per CU: occupancy experiments only.
     static const size_t pad = getenv("GVD_BWD_LDS_PAD") ? (size_t)atol(getenv("GVD_BWD_LDS_PAD")) : 0;
-    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(256), pad, s, a);
+    if (a.dL_dpix_depth || a.dL_dalphas) hipLaunchKernelGGL(k_render_bwd<true>, dim3(T), dim3(256), pad, s, a);
+    else hipLaunchKernelGGL(k_render_bwd<false>, dim3(T), dim3(256), pad, s, a);
 }
 void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)
 {

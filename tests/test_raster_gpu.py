@@ -420,3 +420,28 @@ def test_tile_dispatch_order_is_a_permutation_by_image_region():
     for x in range(8):                      # per band: non-increasing up to the bucket resolution (1/16 of a power of two)
         ln = length[:full][x::8].astype(np.float64)
         assert np.all(ln[1:] <= ln[:-1] * 1.07 + 1.0), x
+
+
+def test_colour_only_backward_equals_zero_depth_and_alpha_gradients():
+    """render_bwd is specialised for the usual training step (no gradient for the depth / alpha images: NULL at the
+    C-ABI): it must return exactly what explicit all-zero depth / alpha gradients give."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    sc = syn.scene_c2(P=30000, W=320, H=240)
+    cam = sc["cameras"][2]
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    E = torch.Tensor([])
+    W, H = cam["image_width"], cam["image_height"]
+    bg, m3, op, scl, rot, sh = t(sc["bg"]), t(sc["means3D"]), t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"]), t(sc["shs"])
+    vm, pm, cp = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["campos"])
+    R, color, depth, alpha, radii, gb, bb, ib = _C.rasterize_gaussians(bg, m3, E, op, scl, rot, 1.0, E, vm, pm, cam["tanfovx"], cam["tanfovy"],
+                                                                      H, W, sh, sc["sh_degree"], cp, False, False)
+    gC = torch.randn(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) / (H * W)
+    z = torch.zeros(1, H, W, device=dev)
+    call = lambda gD, gA: _C.rasterize_gaussians_backward(bg, m3, radii, E, scl, rot, 1.0, E, vm, pm, cam["tanfovx"], cam["tanfovy"],
+                                                          gC, gD, gA, sh, sc["sh_degree"], cp, gb, R, bb, ib, alpha, False)
+    lean, full = call(None, None), call(z, z)
+    assert float(lean[3].abs().max()) > 0
+    for a, b in zip(lean, full):
+        assert torch.equal(a, b)
