@@ -511,18 +511,17 @@ __global__ void __launch_bounds__(CLASS == 0 ? 256 : 1024) k_sort_tiles(SortArgs
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_render_fwd: one workgroup (4 waves) per 16x16 tile; wave w owns the 16x4 pixel strip
-// rows 4w..4w+3 (x fastest, so output stores are 64-byte row segments).
+// k_render_fwd: one workgroup (4 waves) per 16x16 tile; wave w owns the 8x8 pixel quadrant (w & 1, w >> 1).
+// The workgroup first sorts the tile's list (merge_sort_u64; lists over kFusedSortMax arrive sorted).
 // Per batch of 256 list entries: each thread fetches one entry (id -> xy, conic/opacity, rgb+depth),
-// runs the conservative test against each of the four strips, and the survivors are compacted into one
-// LDS list PER STRIP with wave ballots + prefixes (order preserved, original list position kept for
-// n_contrib): a wave only walks the entries that can reach its own 64 pixels (about two thirds of the
-// tile's survivors on the C2 scene).  Every pixel then walks its strip's batch from LDS (broadcast reads)
-// with the reference's exact per-pixel sequence (forward.cu:329-368).
+// runs the conservative test against each of the four quadrants, and the survivors are compacted into one
+// LDS list PER QUADRANT with wave ballots + prefixes (order preserved, original list position kept for
+// n_contrib): a wave only walks the entries that can reach its own 64 pixels.  Every pixel then walks its
+// quadrant's batch from LDS (broadcast reads) with the reference's exact per-pixel sequence (forward.cu:329-368).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
 {
-    __shared__ float2 s_xy4[4][256];   // one compacted list per strip (= per wave)
+    __shared__ float2 s_xy4[4][256];   // one compacted list per quadrant (= per wave)
     __shared__ float4 s_co4[4][256];
     __shared__ float4 s_cd4[4][256];
     __shared__ uint32_t s_pos4[4][256];
@@ -651,7 +650,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         }
         uint32_t j = 0;
         for (; j + 4 <= n; j += 4) {
-            if (__all(T == 0.0f)) break;  // wave-uniform: this strip is finished
+            if (__all(T == 0.0f)) break;  // wave-uniform: this quadrant is finished
             const float2 xy0 = s_xy[j], xy1 = s_xy[j + 1], xy2 = s_xy[j + 2], xy3 = s_xy[j + 3];
             const float4 co0 = s_co[j], co1 = s_co[j + 1], co2 = s_co[j + 2], co3 = s_co[j + 3];
             const float4 cd0 = s_cd[j], cd1 = s_cd[j + 1], cd2 = s_cd[j + 2], cd3 = s_cd[j + 3];

@@ -233,20 +233,8 @@ __device__ __forceinline__ bool tile_may_contribute(float mx, float my, float co
     return rect_may_contribute(mx, my, conA, conB, conC, opacity, x0, y0, 15.0f, 15.0f);
 }
 
-// Bit s set: the Gaussian may contribute to the 16x4 pixel strip (rows 4s..4s+3 of the tile) that wave s of a
-// blend workgroup owns.  The union of the four strips is the tile.
-__device__ __forceinline__ uint32_t strip_mask(float mx, float my, float conA, float conB, float conC,
-                                               float opacity, float x0, float y0)
-{
-    uint32_t m = 0;
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-        m |= rect_may_contribute(mx, my, conA, conB, conC, opacity, x0, y0 + 4.0f * (float)s, 15.0f, 3.0f) ? (1u << s) : 0u;
-    return m;
-}
-
-// Same for the four 8x8 quadrants of the tile (bit q: columns 8*(q&1).., rows 8*(q>>1)..): a smaller perimeter than the
-// 16x4 strip, so about 10 % fewer (entry, wave) pairs survive.
+// Bit q set: the Gaussian may contribute to the 8x8 pixel quadrant q of the tile (columns 8*(q&1).., rows 8*(q>>1)..) that
+// wave q of a blend workgroup owns.  The union of the four quadrants is the tile.
 __device__ __forceinline__ uint32_t quad_mask(float mx, float my, float conA, float conB, float conC,
                                               float opacity, float x0, float y0)
 {
