@@ -10,7 +10,6 @@ fallback: CPU tensors raise unless a test has explicitly enabled the reference m
     ddim_step(...)                     the whole no-grad DDIM update of ddim.py:208-280 in one kernel
 """
 import ctypes
-import math
 import os
 
 import torch

@@ -1,7 +1,6 @@
 """Shared helpers for the GPU parity tests: run the HIP path through the drop-in operator, run the
 CPU oracle on the same inputs, and compare.  `python tests/raster_compare.py` prints a report
 (used during bring-up on the GPU box)."""
-import math
 import os
 import sys
 

@@ -5,7 +5,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in (ROOT, os.path.join(ROOT, "guidedvd-3dgs_amd"), os.path.join(ROOT, "tests")): sys.path.insert(0, p)
 import numpy as np, torch
 import synthetic as syn
-import diff_gaussian_rasterization as dgr
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
 dev = torch.device("cuda:0")
 sc = syn.scene_c2(); c = sc["cameras"][0]
