@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_d = 0.f, acc_a = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
-    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    const float nddelx_dx = -0.5f * a.W, nddely_dy = -0.5f * a.H;   // -(d delta / d mean2D): backward.cu:490-491
     const float nTf = -T_final;
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);  // wave-uniform (kernel argument)
 
@@ -207,17 +207,18 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                 dL_dopa = fmaf(qb, bg_dot, dL_dopa);                                              \
             }                                                                                     \
             lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
-            const float dL_dG = con##J.w * dL_dopa;                                               \
-            const float gdx = gm * DX, gdy = gm * DY;                                             \
-            const float dG_ddelx = fmaf(-gdy, con##J.y, -gdx * con##J.x);                         \
-            const float dG_ddely = fmaf(-gdx, con##J.y, -gdy * con##J.z);                         \
-            const float hq = -0.5f * dL_dG;                                                       \
-            V##0 = dL_dG * dG_ddelx * ddelx_dx;                                                   \
-            V##1 = dL_dG * dG_ddely * ddely_dy;                                                   \
-            V##2 = hq * gdx * DX;                                                                 \
-            V##3 = hq * gdx * DY;                                                                 \
-            V##4 = hq * gdy * DY;                                                                 \
+            /* dL_dG * G and its products with the offset polynomials, formed from q = o * G * dL_dalpha once */   \
             V##5 = gm * dL_dopa;                                                                  \
+            const float q = con##J.w * V##5;                                                      \
+            const float u = fmaf(con##J.y, DY, con##J.x * DX);                                    \
+            const float v = fmaf(con##J.y, DX, con##J.z * DY);                                    \
+            V##0 = (q * nddelx_dx) * u;                                                           \
+            V##1 = (q * nddely_dy) * v;                                                           \
+            const float h = -0.5f * q;                                                            \
+            const float hx = h * DX, hy = h * DY;                                                 \
+            V##2 = hx * DX;                                                                       \
+            V##3 = hx * DY;                                                                       \
+            V##4 = hy * DY;                                                                       \
             V##6 = dchannel_dcolor * dLp0;                                                        \
             V##7 = dchannel_dcolor * dLp1;                                                        \
             V##8 = dchannel_dcolor * dLp2;                                                        \
