@@ -52,6 +52,12 @@ def test_chunk_sizes_and_layout(capi):
     assert lay.point_list_keys + 8 * R <= lay.point_list and lay.point_list + 4 * R <= lay.bucket
     assert lay.bucket + 8 * R <= L.gvd_raster_binning_bytes(R)
     assert lay.ranges + 8 * 64 <= lay.n_contrib
+    assert lay.n_contrib + 4 * W * H <= lay.tile_order and lay.tile_order + 4 * 64 <= L.gvd_raster_image_bytes(W, H)
+    # the ctypes mirror must have exactly the members of the C struct (a shorter mirror would be overrun by the callee)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "gvd_raster.h")).read()
+    body = hdr[hdr.index("typedef struct gvd_chunk_layout {"):hdr.index("} gvd_chunk_layout;")]
+    members = re.findall(r"^\s*size_t\s+(\w+);", body, flags=re.M)
+    assert members == [n for n, _ in capi._ChunkLayout._fields_]
 
 
 def test_settings_and_operator_surface():
