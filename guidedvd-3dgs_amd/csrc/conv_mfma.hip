@@ -1,0 +1,567 @@
+// conv_mfma.hip -- hand-written gfx950 implicit-GEMM convolutions of the ViewCrafter U-Net / VAE on MFMA 32x32x16
+// (C-ABI: include/gvd_diffusion.h, gvd_conv_mfma / gvd_conv_config / gvd_group_norm_coef).
+//
+// Replaces (reference lines):
+//   ResBlock         GroupNorm32 -> SiLU -> Conv2d 3x3 (+ emb add, + skip)   lvdm/modules/networks/openaimodel3d.py:152-156,210-236
+//   Upsample         nearest x2 -> Conv2d 3x3                                 openaimodel3d.py:51-83
+//   TemporalConvBlock 4 x [GroupNorm32 -> SiLU -> Conv3d (3,1,1)] + identity  openaimodel3d.py:239-279
+//   VAE ResnetBlock / Upsample / conv_out                                     lvdm/modules/networks/ae_modules.py:151-210,112-128,575-578
+//
+// Layout: activations token-major  x[n][y][x][Cin]  (16-bit), output  out[n][y][x][Cout];  the temporal (3,1,1) form works
+// on  x[t][pixel][C]  (b = 1).  fp32 accumulation, fp32 GroupNorm affine + SiLU.
+//
+// Design (one workgroup = 256 threads = 4 waves; wave64):
+//   * A workgroup owns a PATCH of output pixels (TH x TW of one image, or PB pixels x all T frames) and BN output
+//     channels.  K runs over 32-channel chunks of Cin; for every chunk the input patch INCLUDING ITS HALO is staged
+//     ONCE into LDS and all taps (9 spatial / 3 temporal) read it through a tap-dependent LDS address shift -- an input
+//     element crosses L2->LDS once per chunk instead of once per tap, and the fused GroupNorm(+SiLU) prologue
+//     (y = silu(a x + b), fp32, zero padding applied AFTER the activation like the reference's conv padding) costs one
+//     evaluation per staged element instead of nine.
+//   * Weights are pre-packed on the host into the exact LDS image of a (cout tile, chunk, tap) slab: rows of 32 input
+//     channels (64 B) whose four 16-byte slots are XOR-swizzled by ((row >> 2) & 3), so the MFMA operand reads
+//     (ds_read_b128, lanes = 32 consecutive rows at one k-slot) are bank-conflict free without padding and staging is a
+//     linear 16-byte copy.
+//   * MFMA roles: A = weights (rows = output channels), B = activated pixels (columns = pixels).  The C/D layout then gives
+//     every lane 4 consecutive output channels of ONE pixel per register quad.
+//   * Patch pixel rows are 80 bytes (64 + 16 pad) so that 32 consecutive pixels at one k-slot hit distinct bank groups;
+//     TW = 16 tiles pad the patch row pitch to a multiple of 256 B for the same reason.
+//   * Pipeline: one barrier per (chunk, tap).  Weights of step i+1 and (late in a chunk) the next chunk's patch are
+//     fetched into registers before the MFMAs of step i and written to the other LDS buffer after them.  Two workgroups
+//     per CU (<= 80 KiB LDS, <= 256 VGPRs) de-synchronise and cover each other's staging.
+//   * Epilogue: accumulators go through LDS so that global stores are 16-byte, row-contiguous; bias, the per-frame
+//     embedding add (ResBlock `h + emb_out`), the residual and the 16-bit rounding are fused, and the GroupNorm statistics
+//     the NEXT norm needs (sum / sum of squares per (sample, group) of the ROUNDED outputs) are reduced in-block and added
+//     to fp64 accumulators -- the separate statistics pass over the activation disappears.
+#include "diffusion_common.h"
+
+using namespace gvdd;
+
+namespace {
+
+struct ConvArgs {
+    const void* x;        // input activations
+    const void* w;        // packed weights
+    const float2* coef;   // per-(n, cin) affine of the fused GroupNorm prologue (nullptr: plain convolution)
+    const float* bias;    // [Cout] or nullptr
+    const void* add_nc;   // [N][Cout] 16-bit per-sample channel add (nullptr if none; spatial mode only)
+    const void* res;      // residual, layout of out (nullptr if none)
+    void* out;
+    double* stats;        // [R][Nstat][G][2] accumulators (nullptr if not wanted)
+    int N, H, W, Cin, Cout;   // output geometry (temporal: N = T frames, H = 1, W = pixels per frame)
+    int ups, silu;
+    int tiles_x, tiles_y;
+    int nchunks;
+    int cpg, G, R;
+    int PB;               // temporal: pixels per tile
+    int coef_per_n;       // 1: coef is [N][Cin], 0: one [Cin] vector for all n (temporal, batch 1)
+};
+
+constexpr int BK = 32;          // input channels per chunk
+constexpr int PIX_BYTES = 80;   // one patch pixel: 32 channels (64 B) + 16 B pad
+constexpr int PB_MAX = 32;      // temporal: max pixels per tile
+
+template <int MODE, int PIX> struct Geo;
+template <int PIX> struct Geo<0, PIX> {   // spatial, 16-pixel-wide tiles
+    static constexpr int TW = 16, TH = PIX / 16, PW = TW + 2, PH = TH + 2, PITCH = 1536, NTAPS = 9;
+    static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
+};
+template <int PIX> struct Geo<1, PIX> {   // spatial, 32-pixel-wide tiles
+    static constexpr int TW = 32, TH = PIX / 32, PW = TW + 2, PH = TH + 2, PITCH = PW * PIX_BYTES, NTAPS = 9;
+    static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
+};
+template <int PIX> struct Geo<2, PIX> {   // temporal: rows = (t, p), one zero halo frame on both sides
+    static constexpr int NTAPS = 3, TW = 1, TH = 1, PW = 1, PITCH = 0;   // (spatial members: unused placeholders)
+    static constexpr int PATCH_BYTES = (PIX + 2 * PB_MAX) * PIX_BYTES, NPP_MAX = (PIX + 2 * PB_MAX) * 4;
+};
+
+__device__ __forceinline__ float silu32(float f) { return f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * f)); }
+
+template <typename T, int MI, int NI, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    constexpr int BN = WM * MI * 32, PIX = WN * NI * 32;
+    typedef Geo<MODE, PIX> G_;
+    constexpr int NTAPS = G_::NTAPS;
+    constexpr int WBYTES = BN * 64;
+    constexpr int PBYTES = (G_::PATCH_BYTES + 15) & ~15;
+    constexpr int NWP = BN * 4, WPT = (NWP + 255) / 256;
+    constexpr int PPT = (G_::NPP_MAX + 255) / 256;
+    // epilogue staging: EP_PIX pixels x BN channels in fp32 (row pitch BN*4 + 16), then the statistics scratch
+    constexpr int EP_PITCH = BN * 4 + 16;
+    constexpr int EP_PIX = (BN > 160) ? 32 : (BN > 32 ? 64 : PIX);
+    constexpr int NOCT = BN / 8, EP_ROWS = 256 / NOCT, EP_ACTIVE = EP_ROWS * NOCT;
+    static_assert(PIX % EP_PIX == 0 && EP_PIX % 32 == 0, "epilogue passes cover whole 32-pixel blocks");
+    static_assert(EP_PIX * EP_PITCH + 2 * EP_ROWS * BN * 4 <= 2 * WBYTES + 2 * PBYTES, "epilogue staging must fit the main-loop LDS");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const wbuf = lds;                    // [2][WBYTES]
+    unsigned char* const pbuf = lds + 2 * WBYTES;       // [2][PBYTES]
+
+    const T* __restrict__ x = (const T*)a.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, r32 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int co_tile = blockIdx.y;
+    const int Cin = a.Cin, Cout = a.Cout;
+
+    // ---- tile origin ----
+    int n = 0, ty0 = 0, tx0 = 0, p0 = 0;
+    if (MODE < 2) {
+        const int per_img = a.tiles_x * a.tiles_y;
+        n = blockIdx.x / per_img;
+        const int rem = blockIdx.x - n * per_img;
+        ty0 = (rem / a.tiles_x) * G_::TH;
+        tx0 = (rem % a.tiles_x) * G_::TW;
+    } else {
+        p0 = blockIdx.x * a.PB;
+    }
+    const int PB = a.PB;
+
+    // ---- patch staging map (piece = 16 bytes = 8 channels of one patch pixel) ----
+    const int k8 = tid & 3;   // 256 % 4 == 0: a thread always stages the same channel octet of the chunk
+    int goff[PPT], loff[PPT];
+    const int Hin = a.ups ? (a.H >> 1) : a.H, Win = a.ups ? (a.W >> 1) : a.W;
+    int npp;
+    if (MODE < 2) npp = G_::NPP_MAX; else npp = (a.N + 2) * PB * 4;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        const int q = tid + i * 256, pixel = q >> 2;
+        goff[i] = -1;
+        loff[i] = 0;
+        if (q < npp) {
+            if (MODE < 2) {
+                const int py = pixel / G_::PW, px = pixel - py * G_::PW;
+                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                loff[i] = py * G_::PITCH + px * PIX_BYTES + k8 * 16;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    goff[i] = ((n * Hin + (gy >> a.ups)) * Win + (gx >> a.ups)) * Cin;
+            } else {
+                const int tt = pixel / PB - 1, pp = pixel - (tt + 1) * PB, gp = p0 + pp;
+                loff[i] = pixel * PIX_BYTES + k8 * 16;
+                if (tt >= 0 && tt < a.N && gp < a.W) goff[i] = (tt * a.W + gp) * Cin;
+            }
+        } else {
+            loff[i] = -1;
+        }
+    }
+    const float2* __restrict__ coef = a.coef ? a.coef + (a.coef_per_n ? (size_t)n * Cin : 0) : nullptr;
+
+    // The next chunk's patch is fetched and written in two halves (pieces [0, PH0) then [PH0, PPT)) so that at most half of
+    // the staging registers are live next to the 160 accumulators.
+    constexpr int PH0 = (PPT + 1) / 2;
+    vec8 preg[PH0];
+    float2 cf[8];
+    bool chan_ok = false;
+    auto load_cf = [&](int chunk) {
+        const int c0 = chunk * BK + k8 * 8;
+        chan_ok = c0 < Cin;
+        if (coef && chan_ok) {
+            const float4* cp = reinterpret_cast<const float4*>(coef + c0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 v = cp[j];
+                cf[2 * j] = make_float2(v.x, v.y);
+                cf[2 * j + 1] = make_float2(v.z, v.w);
+            }
+        }
+    };
+    auto load_p = [&](int chunk, auto half_tag) {
+        constexpr int HALF = decltype(half_tag)::value;
+        const int c0 = chunk * BK + k8 * 8;
+#pragma unroll
+        for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++)
+            preg[i - HALF * PH0] = (goff[i] >= 0 && c0 < Cin) ? *reinterpret_cast<const vec8*>(x + (size_t)goff[i] + c0) : vec8{};
+    };
+    auto store_p = [&](int buf, auto half_tag) {
+        constexpr int HALF = decltype(half_tag)::value;
+        unsigned char* pb = pbuf + buf * PBYTES;
+#pragma unroll
+        for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++) {
+            if (loff[i] < 0) continue;
+            vec8 v = preg[i - HALF * PH0];
+            if (coef) {
+                if (goff[i] >= 0 && chan_ok) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        float f = fmaf((float)v[j], cf[j].x, cf[j].y);
+                        if (a.silu) f = silu32(f);
+                        v[j] = (T)f;
+                    }
+                } else {
+                    v = vec8{};   // conv zero padding applies to the ACTIVATED tensor
+                }
+            }
+            *reinterpret_cast<vec8*>(pb + loff[i]) = v;
+        }
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+
+    // ---- weight staging (linear copy of the pre-swizzled slab) ----
+    const T* __restrict__ wt = (const T*)a.w + (size_t)co_tile * a.nchunks * NTAPS * (BN * BK);
+    vec8 wreg[WPT];
+    auto load_w = [&](int it) {
+        const T* src = wt + (size_t)it * (BN * BK);
+#pragma unroll
+        for (int i = 0; i < WPT; i++) {
+            const int q = tid + i * 256;
+            if (q < NWP) wreg[i] = *reinterpret_cast<const vec8*>(src + q * 8);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; i++) {
+            const int q = tid + i * 256;
+            if (q < NWP) *reinterpret_cast<vec8*>(wbuf + buf * WBYTES + q * 16) = wreg[i];
+        }
+    };
+
+    // ---- MFMA operand addresses ----
+    int a_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) a_off[ks] = (wm * MI * 32 + r32) * 64 + ((((2 * ks + hi) ^ ((r32 >> 2) & 3))) << 4);
+    int b_off[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+        const int m = (wn * NI + ni) * 32 + r32;
+        if (MODE == 0) b_off[ni] = (m >> 4) * G_::PITCH + (m & 15) * PIX_BYTES + hi * 16;
+        else if (MODE == 1) b_off[ni] = (m >> 5) * G_::PITCH + (m & 31) * PIX_BYTES + hi * 16;
+        else b_off[ni] = m * PIX_BYTES + hi * 16;
+    }
+
+    f16v acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) acc[mi][ni] = f16v{};
+
+    const int total = a.nchunks * NTAPS;
+    load_w(0);
+    load_cf(0);
+    load_p(0, H0{});
+    store_w(0);
+    store_p(0, H0{});
+    load_p(0, H1{});
+    store_p(0, H1{});
+    int chunk = 0, tap = 0;
+    // taps at which the next chunk's patch halves are fetched / written (3-tap temporal form: everything one tap apart)
+    constexpr int T_L0 = NTAPS >= 9 ? NTAPS - 4 : 0, T_S0 = NTAPS >= 9 ? NTAPS - 3 : 1, T_S1 = NTAPS - 1;
+    for (int it = 0; it < total; it++) {
+        __syncthreads();
+        const bool more_w = it + 1 < total, more_p = chunk + 1 < a.nchunks;
+        if (more_w) load_w(it + 1);
+        if (more_p) {
+            if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); }
+        }
+
+        const unsigned char* wb = wbuf + (it & 1) * WBYTES;
+        int shift;
+        if (MODE < 2) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
+        else shift = tap * PB * PIX_BYTES;
+        const unsigned char* pb = pbuf + (chunk & 1) * PBYTES + shift;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            vec8 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048);
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) bf[ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32);
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
+        }
+
+        if (more_w) store_w((it + 1) & 1);
+        if (more_p) {
+            if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
+            if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
+        }
+        if (++tap == NTAPS) { tap = 0; chunk++; }
+    }
+    __syncthreads();   // all operand reads retired: the LDS is reused by the epilogue
+
+    // ---- epilogue ----
+    unsigned char* const ep = lds;                                         // [EP_PIX][EP_PITCH] fp32
+    float* const red = reinterpret_cast<float*>(lds + EP_PIX * EP_PITCH);  // [2][EP_ROWS][BN]
+    T* __restrict__ out = (T*)a.out;
+    const T* __restrict__ res = (const T*)a.res;
+    const int oct = tid % NOCT, prow = tid / NOCT;
+    const bool ep_thread = tid < EP_ACTIVE;
+    const int cout0 = co_tile * BN + oct * 8;
+    const bool full_oct = (cout0 + 8 <= Cout) && ((Cout & 7) == 0);
+    float badd[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        badd[j] = 0.f;
+        if (ep_thread && cout0 + j < Cout) {
+            if (a.bias) badd[j] = a.bias[cout0 + j];
+            if (MODE < 2 && a.add_nc) badd[j] += (float)((const T*)a.add_nc)[(size_t)n * Cout + cout0 + j];
+        }
+    }
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ssum[j] = 0.f; ssq[j] = 0.f; }
+
+    constexpr int NPASS = PIX / EP_PIX;
+    for (int pass = 0; pass < NPASS; pass++) {
+        // accumulators of this pass's pixel blocks -> LDS [pixel][channel] fp32 (a lane owns 4 consecutive channels per quad)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int pblk = wn * NI + ni;
+            if ((pblk * 32) / EP_PIX != pass) continue;
+            const int pl = pblk * 32 - pass * EP_PIX + r32;
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int cl = (wm * MI + mi) * 32 + 8 * rg + 4 * hi;
+                    const float4 v = make_float4(acc[mi][ni][4 * rg], acc[mi][ni][4 * rg + 1], acc[mi][ni][4 * rg + 2], acc[mi][ni][4 * rg + 3]);
+                    *reinterpret_cast<float4*>(ep + pl * EP_PITCH + cl * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (ep_thread) {
+            for (int pl = prow; pl < EP_PIX; pl += EP_ROWS) {
+                const int m = pass * EP_PIX + pl;
+                bool valid;
+                size_t off;
+                if (MODE == 2) {
+                    const int tt = m / PB, pp = m - tt * PB;
+                    valid = tt < a.N && p0 + pp < a.W;
+                    off = ((size_t)tt * a.W + p0 + pp) * Cout;
+                } else {
+                    const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
+                    valid = ty0 + ty < a.H && tx0 + tx < a.W;
+                    off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
+                }
+                if (!valid || cout0 >= Cout) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32);
+                const float4 v1 = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + 16);
+                float v[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+                vec8 o;
+                if (full_oct) {
+                    vec8 rv = vec8{};
+                    if (res) rv = *reinterpret_cast<const vec8*>(res + off + cout0);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
+                        const float f = (float)o[j];
+                        ssum[j] += f;
+                        ssq[j] = fmaf(f, f, ssq[j]);
+                    }
+                    *reinterpret_cast<vec8*>(out + off + cout0) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (cout0 + j >= Cout) continue;
+                        float f = v[j] + badd[j];
+                        if (res) f += (float)res[off + cout0 + j];
+                        const T h = (T)f;
+                        out[off + cout0 + j] = h;
+                        f = (float)h;
+                        ssum[j] += f;
+                        ssq[j] = fmaf(f, f, ssq[j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- GroupNorm statistics of the (rounded) outputs for the next norm ----
+    if (a.stats) {
+        if (ep_thread) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                red[prow * BN + oct * 8 + j] = ssum[j];
+                red[(EP_ROWS + prow) * BN + oct * 8 + j] = ssq[j];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {   // per-channel totals into row 0 (column-private: no race)
+            float s = 0.f, q = 0.f;
+            for (int rr = 0; rr < EP_ROWS; rr++) { s += red[rr * BN + c]; q += red[(EP_ROWS + rr) * BN + c]; }
+            red[c] = s;
+            red[EP_ROWS * BN + c] = q;
+        }
+        __syncthreads();
+        const int cb = co_tile * BN, ce = (cb + BN < Cout) ? cb + BN : Cout;
+        if (cb < ce) {
+            const int g_first = cb / a.cpg, g_last = (ce - 1) / a.cpg;
+            const int g = g_first + tid;
+            if (g <= g_last) {
+                const int c_lo = (g * a.cpg > cb) ? g * a.cpg : cb, c_hi = ((g + 1) * a.cpg < ce) ? (g + 1) * a.cpg : ce;
+                double s = 0.0, q = 0.0;
+                for (int c = c_lo; c < c_hi; c++) { s += (double)red[c - cb]; q += (double)red[EP_ROWS * BN + c - cb]; }
+                const int rep = blockIdx.x % a.R;
+                const int nstat = MODE < 2 ? n : 0, Nstat = MODE < 2 ? a.N : 1;
+                double* dst = a.stats + (((size_t)rep * Nstat + nstat) * a.G + g) * 2;
+                atomicAdd(dst, s);
+                atomicAdd(dst + 1, q);
+            }
+        }
+    }
+}
+
+// stats[nout][g][0..1] = sum over replicas r and merged samples m of partial[r][nout*merge + m][g][0..1]
+__global__ void __launch_bounds__(256) k_gn_merge(const double* __restrict__ partial, double* __restrict__ stats, int R, int Nin,
+                                                  int merge, int G, int total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k = i & 1, g = (i >> 1) % G, nout = (i >> 1) / G;
+    double s = 0.0;
+    for (int r = 0; r < R; r++)
+        for (int m = 0; m < merge; m++) s += partial[(((size_t)r * Nin + (size_t)nout * merge + m) * G + g) * 2 + k];
+    stats[i] = s;
+}
+
+__global__ void __launch_bounds__(256) k_gn_coef2(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float2* __restrict__ coef,
+                                                  int N, int C, int G, long long S, float eps)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C, cpg = C / G;
+    const double cnt = (double)cpg * (double)S;
+    const long long grp = (long long)n * G + c / cpg;
+    const double mean = stats[2 * grp] / cnt;
+    const double var = stats[2 * grp + 1] / cnt - mean * mean;
+    const float rstd = rsqrtf((float)(var > 0 ? var : 0) + eps);
+    const float a = rstd * gamma[c];
+    coef[i] = make_float2(a, beta[c] - (float)mean * a);
+}
+
+struct Cfg { int MI, NI, WM, WN; };
+
+template <typename T, int MI, int NI, int WM, int WN, int MODE>
+hipError_t launch_one(const ConvArgs& a, dim3 grid, hipStream_t stream)
+{
+    constexpr int BN = WM * MI * 32, PIX = WN * NI * 32;
+    constexpr int smem = 2 * BN * 64 + 2 * ((Geo<MODE, PIX>::PATCH_BYTES + 15) & ~15);
+    auto kern = k_conv_mfma<T, MI, NI, WM, WN, MODE>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 64 && !attr_done[dev]) {   // per-device attribute (dynamic LDS above 64 KiB)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <typename T, int MODE>
+hipError_t launch_cfg(int cfg, const ConvArgs& a, dim3 grid, hipStream_t stream)
+{
+    switch (cfg) {
+    case 0: return launch_one<T, 5, 2, 1, 4, MODE>(a, grid, stream);   // 160 channels x 256 pixels
+    case 1: return launch_one<T, 5, 2, 2, 2, MODE>(a, grid, stream);   // 320 x 128
+    case 2: return launch_one<T, 4, 2, 1, 4, MODE>(a, grid, stream);   // 128 x 256
+    case 3: return launch_one<T, 1, 2, 1, 4, MODE>(a, grid, stream);   //  32 x 256
+    default: return hipErrorInvalidValue;
+    }
+}
+
+const int CFG_BN[4] = { 160, 320, 128, 32 };
+const int CFG_PIX[4] = { 256, 128, 256, 256 };
+
+// tile configuration for a problem: cfg index, tile width class (0: 16, 1: 32) -- shared by gvd_conv_config and the launcher
+void choose(int mode, int N, int H, int W, int Cout, int* cfg, int* tw32)
+{
+    const long long pixels = (long long)N * H * W;
+    int c;
+    if (Cout <= 32) c = 3;
+    else if (Cout % 160 == 0) c = (mode == 1 || pixels >= 40000) ? 0 : 1;
+    else c = 2;
+    *cfg = c;
+    *tw32 = 1;
+    if (mode == 0) {
+        const int pix = CFG_PIX[c];
+        auto padded = [&](int tw) { const int th = pix / tw; return (long long)((H + th - 1) / th) * th * ((W + tw - 1) / tw) * tw; };
+        *tw32 = padded(32) <= padded(16) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block_n, int* tile_pixels, int* tile_width)
+{
+    if (mode < 0 || mode > 1 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(-1, "gvd_conv_config: bad arguments");
+    int cfg, tw32;
+    choose(mode, N, H, W, Cout, &cfg, &tw32);
+    if (block_n) *block_n = CFG_BN[cfg];
+    if (tile_pixels) *tile_pixels = CFG_PIX[cfg];
+    if (tile_width) *tile_width = mode == 0 ? (tw32 ? 32 : 16) : 0;
+    return 0;
+}
+
+int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
+                  const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
+                  int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || mode < 0 || mode > 1)
+        return fail(-1, "gvd_conv_mfma: bad arguments");
+    if ((Cin & 7) || (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)residual) & 15))
+        return fail(-1, "gvd_conv_mfma: Cin must be a multiple of 8 and tensors 16-byte aligned");
+    if (mode == 1 && (H != 1 || upsample)) return fail(-1, "gvd_conv_mfma: temporal mode takes N = frames, H = 1, W = pixels per frame");
+    if (upsample && ((H | W) & 1)) return fail(-1, "gvd_conv_mfma: upsample needs even output dims");
+    if (stats && (groups <= 0 || Cout % groups || stats_replicas <= 0)) return fail(-1, "gvd_conv_mfma: bad statistics arguments");
+    if ((long long)N * H * W * (long long)(Cin > Cout ? Cin : Cout) >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
+    if (is_bf16) return fail(-3, "gvd_conv_mfma: bf16 is not built (f16 only)");
+    int cfg, tw32;
+    choose(mode, N, H, W, Cout, &cfg, &tw32);
+    const int BN = CFG_BN[cfg], PIX = CFG_PIX[cfg];
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.coef = reinterpret_cast<const float2*>(coef); a.bias = bias; a.add_nc = add_nc; a.res = residual;
+    a.out = out; a.stats = stats;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ups = upsample ? 1 : 0; a.silu = silu ? 1 : 0;
+    a.nchunks = (Cin + BK - 1) / BK;
+    a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
+    a.coef_per_n = coef_per_n;
+    dim3 grid;
+    grid.y = (Cout + BN - 1) / BN;
+    hipError_t e;
+    if (mode == 0) {
+        const int tw = tw32 ? 32 : 16, th = PIX / tw;
+        a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
+        grid.x = (unsigned)(a.tiles_x * a.tiles_y * N);
+        e = tw32 ? launch_cfg<_Float16, 1>(cfg, a, grid, stream) : launch_cfg<_Float16, 0>(cfg, a, grid, stream);
+    } else {
+        int pb = PIX / N;
+        if (pb < 1) return fail(-1, "gvd_conv_mfma: too many frames for one tile");
+        if (pb > PB_MAX) pb = PB_MAX;
+        a.PB = pb;
+        a.tiles_x = (W + pb - 1) / pb; a.tiles_y = 1;
+        grid.x = (unsigned)a.tiles_x;
+        e = launch_cfg<_Float16, 2>(cfg, a, grid, stream);
+    }
+    if (e != hipSuccess) return fail(-2, "launch k_conv_mfma", e);
+    return 0;
+}
+
+int gvd_group_norm_coef(double* stats, const double* partial, int replicas, int merge, const float* gamma, const float* beta,
+                        int N, int C, long long S_total, int G, float eps, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!stats || !gamma || !beta || N <= 0 || C <= 0 || G <= 0 || C % G || S_total <= 0) return fail(-1, "gvd_group_norm_coef: bad arguments");
+    if (partial) {
+        if (replicas <= 0 || merge <= 0) return fail(-1, "gvd_group_norm_coef: bad replica / merge counts");
+        const int total = N * G * 2;
+        hipLaunchKernelGGL(k_gn_merge, dim3((total + 255) / 256), dim3(256), 0, stream, partial, stats, replicas, N * merge, merge, G, total);
+    }
+    float2* coef = reinterpret_cast<float2*>(stats + (size_t)N * G * 2);
+    hipLaunchKernelGGL(k_gn_coef2, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const double*)stats, gamma, beta, coef, N, C, G, S_total, eps);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_gn_coef", e);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+"""Hand-written MFMA convolutions of the diffusion path (csrc/conv_mfma.hip through the C-ABI `gvd_conv_mfma`).
+
+    fused_conv(x, conv, ...)     out = conv(silu?(GroupNorm(x))) + bias + add_nc + residual   (+ statistics for the next norm)
+
+`x` / `out` are token-major [N, H, W, C] 16-bit tensors; the temporal (3,1,1) form takes [T, pixels, C].  The weights stay
+the module's `nn.Conv2d` / `nn.Conv3d` parameters (reference state-dict keys); the packed MFMA image is cached on the
+parameter.  Forward and input gradient (the guided sampler differentiates w.r.t. x_t with frozen weights) run the same
+kernel -- the input gradient is the convolution with the transposed, tap-flipped weights.
+
+No CPU path: on CPU tensors `fused_conv` raises unless `ops.use_reference_math(True)` is active (tests / cpu_baseline only),
+in which case it evaluates the same expression with torch ops (the reference's own formulation).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+SPATIAL, TEMPORAL = 0, 1
+STATS_REPLICAS = 8
+
+
+def config(mode, N, H, W, Cin, Cout):
+    """(BN, tile pixels, tile width) the kernel uses for this problem (BN is the weight-packing granule)."""
+    bn, pix, tw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    ops._check(ops.lib().gvd_conv_config(mode, N, H, W, Cin, Cout, ctypes.byref(bn), ctypes.byref(pix), ctypes.byref(tw)))
+    return bn.value, pix.value, tw.value
+
+
+def pack_weight(w3, BN):
+    """[Cout, Cin, taps] -> the LDS image layout of include/gvd_diffusion.h (gvd_conv_mfma): [co tiles][chunks][taps][BN][4][8],
+    slot s of row r holds input channels (s ^ ((r >> 2) & 3)) * 8 .. +7 of the chunk."""
+    Cout, Cin, taps = w3.shape
+    nct, nch = -(-Cout // BN), -(-Cin // 32)
+    wp = w3.new_zeros(nct * BN, nch * 32, taps)
+    wp[:Cout, :Cin] = w3
+    wp = wp.reshape(nct, BN, nch, 4, 8, taps).permute(0, 2, 5, 1, 3, 4)          # [nct, nch, taps, BN, 4, 8]
+    r = torch.arange(BN, device=w3.device)
+    idx = torch.arange(4, device=w3.device)[None, :] ^ ((r >> 2) & 3)[:, None]     # [BN, 4]
+    idx = idx[None, None, None, :, :, None].expand(nct, nch, taps, BN, 4, 8)
+    return wp.gather(4, idx).contiguous()
+
+
+def _taps(weight):
+    """Conv2d [Co, Ci, 3, 3] / Conv3d [Co, Ci, 3, 1, 1] -> [Co, Ci, taps]."""
+    return weight.reshape(weight.shape[0], weight.shape[1], -1)
+
+
+def packed(weight, BN, backward=False, cin_pad=0):
+    """Packed image of a (frozen) conv weight, cached on the parameter.  backward: the input-gradient operator
+    (Cout <-> Cin transposed, taps flipped).  cin_pad: zero input channels appended (Cin not a multiple of 8)."""
+    key = (BN, backward, cin_pad, weight.dtype, weight.device)
+    cache = getattr(weight, "_gvd_packed", None)
+    tag = (weight._version, weight.data_ptr())
+    if cache is None or cache[0] != tag:
+        cache = (tag, {})
+        try:
+            weight._gvd_packed = cache
+        except AttributeError:
+            pass
+    hit = cache[1].get(key)
+    if hit is None:
+        w3 = _taps(weight.detach())
+        if backward:
+            w3 = w3.flip(2).transpose(0, 1)
+        if cin_pad:
+            w3 = F.pad(w3, (0, 0, 0, cin_pad))
+        hit = cache[1][key] = pack_weight(w3.contiguous(), BN)
+    return hit
+
+
+class NormState:
+    """GroupNorm statistics + per-(sample, channel) affine in the layout of gvd_group_norm (fp64 sums [N][G][2], then fp32
+    (a, b) [N][C]); what the fused convolution's prologue and the GroupNorm backward kernel read."""
+    __slots__ = ("buf", "N", "C", "G", "S", "eps", "gamma32")
+
+    def __init__(self, buf, N, C, G, S, eps, gamma32):
+        self.buf, self.N, self.C, self.G, self.S, self.eps, self.gamma32 = buf, N, C, G, S, eps, gamma32
+
+    @property
+    def coef_ptr(self):
+        return self.buf.data_ptr() + 16 * self.N * self.G
+
+
+class PartialStats:
+    """Sum / sum of squares per (sample, group) as accumulated by a convolution epilogue: fp64 [R, N, G, 2]."""
+    __slots__ = ("sums", "R", "N", "G", "S")
+
+    def __init__(self, sums, R, N, G, S):
+        self.sums, self.R, self.N, self.G, self.S = sums, R, N, G, S
+
+
+def norm_state(gn, x=None, partial=None, n_stat=None, merge=1):
+    """Norm state of GroupNorm module `gn` for input x [n_stat, ..., C] (token-major), from a statistics pass over x or
+    from the partial sums `partial` a producing convolution left (merge consecutive samples: per-frame -> per-video)."""
+    P, LL = ctypes.c_void_p, ctypes.c_longlong
+    G = gn.num_groups
+    g32, b32 = ops._f32_param(gn.weight), ops._f32_param(gn.bias)
+    C = g32.numel()
+    if partial is not None:
+        N = partial.N // merge
+        S = partial.S * merge
+        buf = torch.empty(2 * N * G + N * C, dtype=torch.float64, device=partial.sums.device)
+        with ops._on(buf.device):
+            ops._check(ops.lib().gvd_group_norm_coef(P(buf.data_ptr()), P(partial.sums.data_ptr()), partial.R, merge,
+                                                     P(g32.data_ptr()), P(b32.data_ptr()), N, C, LL(S), G,
+                                                     ctypes.c_float(gn.eps), P(ops._stream())))
+        return NormState(buf, N, C, G, S, gn.eps, g32)
+    x = x.contiguous()
+    N = n_stat
+    S = x.numel() // (N * C)
+    buf = torch.empty(2 * N * G + N * C, dtype=torch.float64, device=x.device)
+    bf = 1 if x.dtype == torch.bfloat16 else 0
+    with ops._on(x.device):
+        ops._check(ops.lib().gvd_group_norm_stats(P(x.data_ptr()), P(buf.data_ptr()), N, C, LL(S), G, 1, bf, P(ops._stream())))
+        ops._check(ops.lib().gvd_group_norm_coef(P(buf.data_ptr()), None, 1, 1, P(g32.data_ptr()), P(b32.data_ptr()), N, C, LL(S), G,
+                                                 ctypes.c_float(gn.eps), P(ops._stream())))
+    return NormState(buf, N, C, G, S, gn.eps, g32)
+
+
+def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, silu=False, bias=None, add_nc=None,
+            residual=None, stats_groups=0, upsample=False):
+    P = ctypes.c_void_p
+    out = torch.empty((N, H, W, Cout) if mode == SPATIAL else (N, W, Cout), dtype=x.dtype, device=x.device)
+    sums = None
+    if stats_groups:
+        n_stat = N if mode == SPATIAL else 1
+        sums = torch.zeros(STATS_REPLICAS, n_stat, stats_groups, 2, dtype=torch.float64, device=x.device)
+    with ops._on(x.device):
+        rc = ops.lib().gvd_conv_mfma(P(x.data_ptr()), P(wpk.data_ptr()), P(coef_ptr), coef_per_n,
+                                     P(bias.data_ptr() if bias is not None else None),
+                                     P(add_nc.data_ptr() if add_nc is not None else None),
+                                     P(residual.data_ptr() if residual is not None else None), P(out.data_ptr()),
+                                     P(sums.data_ptr() if sums is not None else None), STATS_REPLICAS, stats_groups, mode,
+                                     N, H, W, Cin, Cout, int(bool(upsample)), int(bool(silu)),
+                                     1 if x.dtype == torch.bfloat16 else 0, P(ops._stream()))
+    ops._check(rc)
+    if sums is not None:
+        S = H * W if mode == SPATIAL else N * W
+        return out, PartialStats(sums, STATS_REPLICAS, sums.shape[1], stats_groups, S)
+    return out, None
+
+
+def _geometry(x, mode, upsample):
+    if mode == SPATIAL:
+        N, Hin, Win, Cin = x.shape
+        return N, (2 * Hin if upsample else Hin), (2 * Win if upsample else Win), Cin
+    T, Pp, Cin = x.shape
+    return T, 1, Pp, Cin
+
+
+def _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, stats_groups):
+    N, H, W, Cin = _geometry(x, mode, upsample)
+    Cout = weight.shape[0]
+    pad = (-Cin) % 8
+    if pad:
+        if ns is not None:
+            raise RuntimeError("fused_conv: a GroupNorm prologue needs Cin % 8 == 0")
+        x = F.pad(x, (0, pad))
+    BN, _, _ = config(mode, N, H, W, Cin + pad, Cout)
+    wpk = packed(weight, BN, False, pad)
+    b32 = None if bias is None else ops._f32_param(bias)
+    if ns is not None and (ns.C != Cin or ns.N != (N if mode == SPATIAL else 1)):
+        raise RuntimeError(f"fused_conv: norm state is for {ns.N} x {ns.C} channels, input has {N if mode == SPATIAL else 1} x {Cin}")
+    return _launch(x.contiguous(), wpk, Cout, mode, N, H, W, Cin + pad,
+                   coef_ptr=None if ns is None else ns.coef_ptr, coef_per_n=1 if mode == SPATIAL else 0,
+                   silu=silu, bias=b32, add_nc=None if add_nc is None else add_nc.contiguous(),
+                   residual=None if residual is None else residual.contiguous(), stats_groups=stats_groups, upsample=upsample)
+
+
+class _FusedConvFn(torch.autograd.Function):
+    """out = conv(act(x)) + bias + add_nc + residual; gradients w.r.t. x and residual only (weights frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, mode, upsample, ns, silu, add_nc, stats_groups):
+        out, part = _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, stats_groups)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (mode, upsample, ns, silu, residual is not None)
+        ctx.mark_non_differentiable(*([] if part is None else [part.sums]))
+        ctx.part = part
+        return (out,) if part is None else (out, part.sums)
+
+    @staticmethod
+    def backward(ctx, gout, *unused):
+        x, weight = ctx.saved_tensors
+        mode, upsample, ns, silu, has_res = ctx.cfg
+        gout = gout.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            N, H, W, Cin = _geometry(x, mode, upsample)
+            Cout = weight.shape[0]
+            pad = (-Cout) % 8
+            g = F.pad(gout, (0, pad)) if pad else gout
+            BN, _, _ = config(mode, N, H, W, Cout + pad, Cin)
+            wpk = packed(weight, BN, True, pad)
+            d_act, _ = _launch(g, wpk, Cin, mode, N, H, W, Cout + pad)
+            if upsample:   # nearest x2 backward: each input pixel fed a 2x2 block
+                d_act = d_act.reshape(N, H // 2, 2, W // 2, 2, Cin).sum(dim=(2, 4))
+            if ns is None:
+                gx = d_act
+            else:
+                xs = x.reshape(ns.N, -1, ns.C)
+                gx = ops._hip_group_norm_bwd(xs, d_act.reshape(xs.shape), ns.gamma32, ns.buf, ns.G, ns.eps, silu, True).reshape(x.shape)
+        return gx, (gout if has_res else None), None, None, None, None, None, None, None, None
+
+
+def _reference(x, weight, bias, mode, upsample, gn, silu, add_nc, residual, n_stat):
+    """The same expression with stock torch ops (reference formulation): tests and the CPU baseline only."""
+    if gn is not None:
+        xs = x.reshape(n_stat, -1, x.shape[-1])
+        x = ops.group_norm_math(xs, gn.num_groups, gn.weight, gn.bias, gn.eps, silu=silu, channels_last=True).reshape(x.shape)
+    if mode == SPATIAL:
+        xi = x.permute(0, 3, 1, 2)
+        if upsample:
+            xi = F.interpolate(xi, scale_factor=2, mode="nearest")
+        y = F.conv2d(xi, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), padding=1).permute(0, 2, 3, 1)
+        if add_nc is not None:
+            y = y + add_nc.to(y.dtype)[:, None, None, :]
+    else:
+        xi = x.permute(2, 0, 1)[None, :, :, :, None]                              # [1, C, T, P, 1]
+        y = F.conv3d(xi, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0)
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_stat=None, silu=False, add_nc=None,
+               residual=None, stats_groups=0):
+    """x token-major ([N, H, W, Cin] or, temporal, [T, pixels, Cin]); `conv` the nn.Conv2d(3x3, pad 1) / nn.Conv3d((3,1,1))
+    module.  gn: GroupNorm module applied (with `silu`) in the kernel's prologue; norm: a NormState for it if the caller
+    already has one (from a producer's statistics), else a statistics pass over x runs first; n_stat: samples the norm
+    statistics span separately (frames for 2-D norms, 1 for the temporal ones).
+    Returns (out, PartialStats | None): the statistics of `out` for a following GroupNorm with `stats_groups` groups."""
+    on_dev = ops._require_device(x, "fused_conv")
+    if not on_dev or x.dtype not in (torch.float16,):
+        if on_dev and x.dtype == torch.bfloat16:
+            raise RuntimeError("fused_conv: the MFMA convolution is built for fp16 activations")
+        if on_dev and not ops._REFERENCE_MATH and x.dtype != torch.float32:
+            raise RuntimeError(f"fused_conv: unsupported dtype {x.dtype}")
+        n_stat = n_stat if n_stat is not None else (x.shape[0] if mode == SPATIAL else 1)
+        return _reference(x, conv.weight, conv.bias, mode, upsample, gn, silu, add_nc, residual, n_stat), None
+    if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+        raise RuntimeError("fused_conv: only the input gradient is implemented (freeze the weights)")
+    ns = None
+    if gn is not None:
+        n_stat = n_stat if n_stat is not None else (x.shape[0] if mode == SPATIAL else 1)
+        ns = norm if norm is not None else norm_state(gn, x=x.detach(), n_stat=n_stat)
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
+    if need_grad:
+        res = _FusedConvFn.apply(x, residual, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, stats_groups)
+        out = res[0]
+        part = None
+        if stats_groups:
+            N = x.shape[0]
+            S = out.shape[1] * out.shape[2] if mode == SPATIAL else out.shape[0] * out.shape[1]
+            part = PartialStats(res[1], STATS_REPLICAS, res[1].shape[1], stats_groups, S)
+        return out, part
+    return _run_forward(x, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, residual, stats_groups)

@@ -5,6 +5,8 @@ Provides exactly what `DDIMSampler` / `DDIMSamplerGuidance` read from `model` in
 parameterization, apply_model, predict_*_from_z_and_v, q_sample, differentiable_decode_first_stage,
 decode_first_stage, .model (DiffusionWrapper with .diffusion_model), .first_stage_model.
 """
+import importlib
+
 import torch
 import torch.nn as nn
 
@@ -23,6 +25,34 @@ VIEWCRAFTER_VAE = dict(double_z=True, z_channels=4, resolution=256, in_channels=
                        ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 
 
+def _cfg_get(config, key, default=None):
+    """Item access that works for dicts, OmegaConf nodes and attribute namespaces."""
+    if hasattr(config, "get"):
+        return config.get(key, default)
+    return getattr(config, key, default)
+
+
+def instantiate_from_config(config):
+    """utils_vc/diffusion_utils.py:32-47: build `config["target"]` with `config["params"]`."""
+    target = _cfg_get(config, "target")
+    if target is None:
+        if config in ("__is_first_stage__", "__is_unconditional__"):
+            return None
+        raise KeyError("Expected key `target` to instantiate.")
+    module, cls = target.rsplit(".", 1)
+    params = _cfg_get(config, "params") or {}
+    return getattr(importlib.import_module(module), cls)(**{k: params[k] for k in params})
+
+
+def _plain(node):
+    """OmegaConf / nested containers -> plain python (lists stay lists)."""
+    if hasattr(node, "items"):
+        return {k: _plain(v) for k, v in node.items()}
+    if isinstance(node, (list, tuple)) or type(node).__name__ == "ListConfig":
+        return [_plain(v) for v in node]
+    return node
+
+
 class DiffusionWrapper(nn.Module):
     """ddpm3d.py:1420-1491, 'hybrid' conditioning: channel-concat c_concat, token-concat c_crossattn."""
 
@@ -30,6 +60,8 @@ class DiffusionWrapper(nn.Module):
         super().__init__()
         if conditioning_key != "hybrid":
             raise NotImplementedError("ViewCrafter uses conditioning_key='hybrid'")
+        if not isinstance(unet, nn.Module):   # the reference passes the yaml node (ddpm3d.py:1421-1424)
+            unet = instantiate_from_config(unet)
         self.diffusion_model = unet
         self.conditioning_key = conditioning_key
 

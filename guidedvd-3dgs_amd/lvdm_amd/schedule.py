@@ -83,14 +83,15 @@ class DiffusionSchedule(torch.nn.Module):
 
     def __init__(self, timesteps=1000, linear_start=0.00085, linear_end=0.012, beta_schedule="linear",
                  rescale_betas_zero_snr=True, parameterization="v", use_dynamic_rescale=True, base_scale=0.3,
-                 turning_step=400):
+                 turning_step=400, cosine_s=8e-3, v_posterior=0., full_tables=False):
         super().__init__()
-        betas = make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end)
+        betas = make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end, cosine_s)
         if rescale_betas_zero_snr:
             betas = rescale_zero_terminal_snr(betas)
         ac = np.cumprod(1. - betas, axis=0)
         ac_prev = np.append(1., ac[:-1])
         self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
         self.parameterization = parameterization
         self.use_dynamic_rescale = use_dynamic_rescale
         f32 = lambda a: torch.tensor(a, dtype=torch.float32)
@@ -99,6 +100,22 @@ class DiffusionSchedule(torch.nn.Module):
         self.register_buffer("alphas_cumprod_prev", f32(ac_prev))
         self.register_buffer("sqrt_alphas_cumprod", f32(np.sqrt(ac)))
         self.register_buffer("sqrt_one_minus_alphas_cumprod", f32(np.sqrt(1. - ac)))
+        if full_tables:
+            # the remaining persistent buffers of DDPM.register_schedule (ddpm3d.py:152-171): not read by the samplers, but
+            # part of the checkpoint's state dict, so a strict load needs them
+            with np.errstate(divide="ignore", invalid="ignore"):
+                self.register_buffer("log_one_minus_alphas_cumprod", f32(np.log(1. - ac)))
+                if parameterization != "v":
+                    self.register_buffer("sqrt_recip_alphas_cumprod", f32(np.sqrt(1. / ac)))
+                    self.register_buffer("sqrt_recipm1_alphas_cumprod", f32(np.sqrt(1. / ac - 1)))
+                else:
+                    self.register_buffer("sqrt_recip_alphas_cumprod", torch.zeros(self.num_timesteps))
+                    self.register_buffer("sqrt_recipm1_alphas_cumprod", torch.zeros(self.num_timesteps))
+                pv = (1 - v_posterior) * betas * (1. - ac_prev) / (1. - ac) + v_posterior * betas
+                self.register_buffer("posterior_variance", f32(pv))
+                self.register_buffer("posterior_log_variance_clipped", f32(np.log(np.maximum(pv, 1e-20))))
+                self.register_buffer("posterior_mean_coef1", f32(betas * np.sqrt(ac_prev) / (1. - ac)))
+                self.register_buffer("posterior_mean_coef2", f32((1. - ac_prev) * np.sqrt(1. - betas) / (1. - ac)))
         if use_dynamic_rescale:
             self.register_buffer("scale_arr", f32(np.concatenate((np.linspace(1.0, base_scale, turning_step),
                                                                   np.full(self.num_timesteps, base_scale)))))

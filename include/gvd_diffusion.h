@@ -106,6 +106,44 @@ int gvd_layer_norm_bwd(const void* x, const void* dy, const void* gamma, void* d
                        int is_bf16, void* stream);
 int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, int is_bf16, void* stream);
 
+/* ---- implicit-GEMM convolutions on MFMA (csrc/conv_mfma.hip) -------------------------------------------------------
+ * One kernel family for the 3x3 convolutions of the U-Net ResBlock / Upsample (openaimodel3d.py:51-106,210-236), the VAE
+ * ResnetBlock / Upsample / conv_out (ae_modules.py:112-128,151-210,575-578) and the (3,1,1) temporal convolution of
+ * TemporalConvBlock (openaimodel3d.py:239-279).  These replace torch.nn.Conv2d / Conv3d (MIOpen) + the separate
+ * GroupNorm32+SiLU passes in front of them + the elementwise adds behind them.
+ *
+ *   out = conv(act(x)) + bias + add_nc[n] + residual,   act(v) = silu?(a[n,c] v + b[n,c])  (zero padding after act)
+ *
+ * mode 0 (spatial 3x3, stride 1, pad 1):  x [N][H_in][W_in][Cin], out [N][H][W][Cout] (16-bit, token-major).
+ *        upsample = 1: H_in = H/2, W_in = W/2 and the input is nearest-upsampled x2 on the fly.
+ * mode 1 (temporal 3 taps, pad 1 in t):   x [T = N][W = pixels][Cin], out [T][pixels][Cout]; H must be 1; batch 1.
+ * w_packed: weights in the layout gvd_conv_config describes:  [ceil(Cout/BN)][ceil(Cin/32)][taps][BN][4][8] 16-bit,
+ *        element (co_tile, chunk, tap, r, s, j) = W[co_tile*BN + r][chunk*32 + (s ^ ((r >> 2) & 3))*8 + j][tap]
+ *        (zero outside Cout x Cin; tap = ky*3 + kx, or kt).  The input gradient of the same convolution is this entry
+ *        point with W transposed in (Cout, Cin) and flipped in the taps.
+ * coef: fp32 (a, b) pairs [N][Cin] (coef_per_n = 1) or [Cin] (coef_per_n = 0), the per-(sample, channel) affine of the
+ *        GroupNorm in front (the second half of the buffer gvd_group_norm_coef / gvd_group_norm fill); NULL = no prologue.
+ * bias fp32 [Cout] | NULL;  add_nc 16-bit [N][Cout] | NULL (mode 0 only: ResBlock `h + emb_out[:, :, None, None]`);
+ * residual: 16-bit, layout of out | NULL.
+ * stats: NULL, or fp64 accumulators [stats_replicas][Nstat][groups][2] (zeroed by the caller) that receive the sum and
+ *        sum of squares of the ROUNDED outputs per (sample, group) -- Nstat = N in mode 0, 1 in mode 1 -- i.e. the first pass
+ *        of the next GroupNorm, spread over `stats_replicas` copies to keep the atomics apart (block b adds to copy b % R).
+ * Cin % 8 == 0.  Returns -3 for bf16 (not built). */
+int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
+                  const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
+                  int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream);
+
+/* Tile configuration gvd_conv_mfma uses for a problem: BN = output channels per workgroup (the packing granule of
+ * w_packed), pixels per workgroup tile, tile width (16 | 32; 0 in mode 1). */
+int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block_n, int* tile_pixels, int* tile_width);
+
+/* Finish GroupNorm statistics into the norm state the other entry points read: stats = [N][G][2] fp64 sums followed by the
+ * fp32 (a, b) affine [N][C].  partial != NULL: first stats[n][g] = sum over replicas r and m < merge of
+ * partial[r][n*merge + m][g] (what gvd_conv_mfma accumulated; merge = T turns per-frame sums into the per-video sums of the
+ * temporal norms).  partial == NULL: stats already holds the sums (gvd_group_norm_stats).  S_total = elements per channel. */
+int gvd_group_norm_coef(double* stats, const double* partial, int replicas, int merge, const float* gamma, const float* beta,
+                        int N, int C, long long S_total, int G, float eps, void* stream);
+
 const char* gvd_diff_last_error(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,200 @@
+"""GPU tests (-m gpu) of the hand-written MFMA convolutions (csrc/conv_mfma.hip, through the C-ABI gvd_conv_mfma) against a
+plain fp32 torch form of the same operator: 3x3 convolution with every tile configuration / tile width the launcher can
+pick, the fused GroupNorm(+SiLU) prologue, the bias / per-frame add / residual epilogue, the statistics it leaves for
+the next norm, nearest-x2 upsampling on the fly, the temporal (3,1,1) form, and the input gradient.
+
+Tolerance: operands are fp16, accumulation fp32, one rounding of the result to fp16 -> |err| <= 2^-11 |y| + accumulated
+product rounding; the tests allow 2e-3 of the largest |y| (measured ~5e-4)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6))
+
+
+def _conv_module(cin, cout, seed, three_d=False):
+    g = torch.Generator().manual_seed(seed)
+    m = nn.Conv3d(cin, cout, (3, 1, 1), padding=(1, 0, 0)) if three_d else nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / (cin * m.weight[0, 0].numel())) ** 0.5)
+        m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.3)
+    m = m.to(DEV).half()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m
+
+
+def _ref_spatial(x, m, gn=None, silu=False, add_nc=None, residual=None, upsample=False):
+    xf = x.float()
+    if gn is not None:
+        xf = F.group_norm(xf.permute(0, 3, 1, 2), gn.num_groups, gn.weight.float(), gn.bias.float(), gn.eps)
+        if silu:
+            xf = F.silu(xf)
+        xf = xf.half().float()       # the product path rounds the activated operand to fp16 before the MFMA
+    else:
+        xf = xf.permute(0, 3, 1, 2)
+    if upsample:
+        xf = F.interpolate(xf, scale_factor=2, mode="nearest")
+    torch.backends.cudnn.enabled = False   # native fp32 convolution: an independent implementation, not MIOpen's
+    try:
+        y = F.conv2d(xf, m.weight.float(), m.bias.float(), padding=1).permute(0, 2, 3, 1)
+    finally:
+        torch.backends.cudnn.enabled = True
+    if add_nc is not None:
+        y = y + add_nc.float()[:, None, None, :]
+    if residual is not None:
+        y = y + residual.float()
+    return y
+
+
+# (N, H, W, Cin, Cout): chosen so that the launcher takes each (tile configuration, tile width) once, with ragged edges
+SHAPES = [
+    (5, 72, 128, 64, 320),    # 160 x 256 px, 32-wide tiles, exact tiling
+    (5, 177, 48, 40, 320),    # 160 x 256 px, 16-wide tiles, ragged rows, Cin not a multiple of 32
+    (2, 18, 32, 96, 320),     # 320 x 128 px, 32-wide
+    (3, 9, 16, 160, 640),     # 320 x 128 px, 16-wide, two cout tiles
+    (1, 40, 72, 64, 256),     # 128 x 256 px, 16-wide (VAE class)
+    (1, 40, 64, 128, 128),    # 128 x 256 px, 32-wide
+    (2, 24, 32, 320, 4),      #  32 x 256 px (U-Net `out`), Cout not a multiple of 8
+    (2, 21, 37, 8, 320),      # Cin = 8 (U-Net input conv), odd sizes
+    (1, 16, 16, 4, 512),      # Cin = 4 (VAE conv_in): padded to 8 by the host wrapper
+    (1, 33, 20, 72, 200),     # Cout neither a multiple of 160 nor 128 -> masked tile
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", SHAPES)
+def test_conv3x3_matches_fp32(N, H, W, Cin, Cout):
+    from lvdm_amd import conv as C
+    g = torch.Generator(device=DEV).manual_seed(N * 1000 + H + W + Cin + Cout)
+    x = torch.randn(N, H, W, Cin, device=DEV, generator=g).half()
+    m = _conv_module(Cin, Cout, Cin + Cout)
+    y, part = C.fused_conv(x, m)
+    assert part is None and y.shape == (N, H, W, Cout) and y.dtype == torch.float16
+    ref = _ref_spatial(x, m)
+    assert _rel(y, ref) < 2e-3, _rel(y, ref)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,G", [(5, 72, 128, 320, 320, 32), (2, 18, 32, 640, 1280, 32), (1, 40, 72, 256, 128, 32),
+                                              (3, 10, 16, 1920, 640, 32)])
+def test_conv3x3_fused_prologue_epilogue_and_statistics(N, H, W, Cin, Cout, G):
+    from lvdm_amd import conv as C
+    g = torch.Generator(device=DEV).manual_seed(Cin * 3 + Cout)
+    x = (torch.randn(N, H, W, Cin, device=DEV, generator=g) * 1.7 + 0.4).half()
+    res = torch.randn(N, H, W, Cout, device=DEV, generator=g).half()
+    add = torch.randn(N, Cout, device=DEV, generator=g).half()
+    m = _conv_module(Cin, Cout, 7)
+    gn = nn.GroupNorm(G, Cin, eps=1e-5).to(DEV).half()
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(Cin, device=DEV, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(Cin, device=DEV, generator=g) * 0.2)
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    y, part = C.fused_conv(x, m, gn=gn, silu=True, add_nc=add, residual=res, stats_groups=G)
+    ref = _ref_spatial(x, m, gn, True, add, res)
+    assert _rel(y, ref) < 2.5e-3, _rel(y, ref)
+    # statistics of the rounded outputs, per (sample, group): exactly what a statistics pass over y would produce
+    sums = part.sums.sum(0)                                             # [N, G, 2]
+    yg = y.double().reshape(N, H * W, G, Cout // G)
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], -1)
+    assert torch.allclose(sums, want, rtol=2e-5, atol=1e-3), float((sums - want).abs().max())
+    # ... and they drive the next norm: the state built from them equals the state from a pass over y
+    gn2 = nn.GroupNorm(G, Cout, eps=1e-5).to(DEV).half()
+    a = C.norm_state(gn2, partial=part)
+    b = C.norm_state(gn2, x=y, n_stat=N)
+    ca = a.buf[2 * N * G:].view(torch.float32)
+    cb = b.buf[2 * N * G:].view(torch.float32)
+    assert torch.allclose(ca, cb, rtol=1e-4, atol=1e-5)
+    # without SiLU (VAE attention norm style) and without statistics
+    y2, _ = C.fused_conv(x, m, gn=gn, silu=False)
+    assert _rel(y2, _ref_spatial(x, m, gn, False)) < 2.5e-3
+
+
+@pytest.mark.parametrize("N,h,w,Cin,Cout", [(3, 9, 16, 320, 320), (1, 36, 64, 128, 128), (2, 5, 7, 64, 640)])
+def test_conv3x3_nearest_upsample_on_the_fly(N, h, w, Cin, Cout):
+    from lvdm_amd import conv as C
+    g = torch.Generator(device=DEV).manual_seed(h * w)
+    x = torch.randn(N, h, w, Cin, device=DEV, generator=g).half()
+    m = _conv_module(Cin, Cout, 11)
+    y, _ = C.fused_conv(x, m, upsample=True)
+    assert y.shape == (N, 2 * h, 2 * w, Cout)
+    assert _rel(y, _ref_spatial(x, m, upsample=True)) < 2e-3
+
+
+@pytest.mark.parametrize("T,Pp,Cc", [(25, 77, 320), (16, 64, 640), (25, 9216, 320), (3, 40, 1280), (25, 144, 1280)])
+def test_temporal_conv_matches_conv3d(T, Pp, Cc):
+    from lvdm_amd import conv as C
+    g = torch.Generator(device=DEV).manual_seed(T * Pp)
+    x = (torch.randn(T, Pp, Cc, device=DEV, generator=g) + 0.3).half()
+    res = torch.randn(T, Pp, Cc, device=DEV, generator=g).half()
+    m = _conv_module(Cc, Cc, 5, three_d=True)
+    gn = nn.GroupNorm(32, Cc).to(DEV).half()
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(Cc, device=DEV, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(Cc, device=DEV, generator=g) * 0.2)
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    y, part = C.fused_conv(x, m, mode=C.TEMPORAL, gn=gn, silu=True, residual=res, stats_groups=32)
+    xa = F.silu(F.group_norm(x.float().permute(2, 0, 1)[None], 32, gn.weight.float(), gn.bias.float(), gn.eps)).half().float()  # [1, C, T, P]
+    ref = F.conv3d(xa[..., None], m.weight.float(), m.bias.float(), padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0) + res.float()
+    assert _rel(y, ref) < 2.5e-3, _rel(y, ref)
+    sums = part.sums.sum(0)[0]                                          # [G, 2], one sample = the whole video
+    yg = y.double().reshape(T * Pp, 32, Cc // 32)
+    want = torch.stack([yg.sum(dim=(0, 2)), (yg * yg).sum(dim=(0, 2))], -1)
+    assert torch.allclose(sums, want, rtol=2e-5, atol=1e-3)
+
+
+def test_conv_input_gradients_match_autograd_of_the_fp32_form():
+    from lvdm_amd import conv as C
+    g = torch.Generator(device=DEV).manual_seed(99)
+    N, H, W, Cin, Cout = 2, 18, 32, 320, 640
+    x = (torch.randn(N, H, W, Cin, device=DEV, generator=g) + 0.2).half().requires_grad_(True)
+    res = torch.randn(N, H, W, Cout, device=DEV, generator=g).half().requires_grad_(True)
+    m = _conv_module(Cin, Cout, 3)
+    gn = nn.GroupNorm(32, Cin).to(DEV).half()
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    gy = torch.randn(N, H, W, Cout, device=DEV, generator=g).half()
+    y, _ = C.fused_conv(x, m, gn=gn, silu=True, residual=res)
+    gx, gr = torch.autograd.grad(y, [x, res], gy)
+    xf = x.detach().float().requires_grad_(True)
+    rf = res.detach().float().requires_grad_(True)
+    act = F.silu(F.group_norm(xf.permute(0, 3, 1, 2), 32, gn.weight.float(), gn.bias.float(), gn.eps))
+    yr = F.conv2d(act, m.weight.float(), m.bias.float(), padding=1).permute(0, 2, 3, 1) + rf
+    gxr, grr = torch.autograd.grad(yr, [xf, rf], gy.float())
+    assert _rel(gx, gxr) < 6e-3, _rel(gx, gxr)   # two fp16 roundings (d_act, dx) + the fp16 GroupNorm backward kernel
+    assert torch.equal(gr, gy)
+    # plain convolution, upsampled input, Cout not a multiple of 8 (U-Net `out` / VAE conv_out backward)
+    m2 = _conv_module(64, 4, 4)
+    x2 = torch.randn(2, 6, 8, 64, device=DEV, generator=g).half().requires_grad_(True)
+    y2, _ = C.fused_conv(x2, m2, upsample=True)
+    gy2 = torch.randn_like(y2)
+    (gx2,) = torch.autograd.grad(y2, [x2], gy2)
+    x2f = x2.detach().float().requires_grad_(True)
+    y2r = F.conv2d(F.interpolate(x2f.permute(0, 3, 1, 2), scale_factor=2, mode="nearest"), m2.weight.float(), m2.bias.float(), padding=1)
+    (gx2r,) = torch.autograd.grad(y2r, [x2f], gy2.float().permute(0, 3, 1, 2))
+    assert _rel(gx2, gx2r) < 4e-3
+    # temporal
+    m3 = _conv_module(320, 320, 8, three_d=True)
+    x3 = torch.randn(25, 50, 320, device=DEV, generator=g).half().requires_grad_(True)
+    y3, _ = C.fused_conv(x3, m3, mode=C.TEMPORAL)
+    gy3 = torch.randn_like(y3)
+    (gx3,) = torch.autograd.grad(y3, [x3], gy3)
+    x3f = x3.detach().float().requires_grad_(True)
+    y3r = F.conv3d(x3f.permute(2, 0, 1)[None, ..., None], m3.weight.float(), m3.bias.float(), padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0)
+    (gx3r,) = torch.autograd.grad(y3r, [x3f], gy3.float())
+    assert _rel(gx3, gx3r) < 4e-3
+
+
+def test_conv_rejects_what_it_does_not_cover():
+    from lvdm_amd import conv as C
+    m = _conv_module(64, 64, 1)
+    with pytest.raises(RuntimeError):
+        C.fused_conv(torch.randn(1, 8, 8, 64), m)                       # CPU tensor: no CPU path
+    with pytest.raises(RuntimeError):
+        C.fused_conv(torch.randn(1, 8, 8, 64, device=DEV).bfloat16(), m)
