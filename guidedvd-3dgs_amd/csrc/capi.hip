@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -77,15 +78,24 @@ struct ProfScope {
     }
 };
 
-// host-visible mirror of {num_rendered, max tile list}: written by k_tilescan, read after the sync
-volatile uint32_t* host_mirror()
+// Host-side state of a forward call, one slot per (host thread, device): the host-visible mirror of {num_rendered, max tile
+// list} that k_tilescan writes and the host reads after its wait, and the event that marks the end of stage 1.  Nothing here
+// is shared between threads or devices, so concurrent forwards on different streams / devices cannot read each other's R
+// (the C-ABI only forbids re-entrancy on ONE stream).  Slots live as long as their thread (64 pinned bytes + one event).
+struct HostSlot { uint32_t* mirror = nullptr; hipEvent_t ev = nullptr; };
+HostSlot* host_slot()
 {
-    static uint32_t* p = nullptr;
-    if (!p) {
-        if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped) != hipSuccess) p = nullptr;
-        if (p) memset((void*)p, 0, 64);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    static thread_local std::vector<HostSlot> slots;   // indexed by device ordinal
+    if ((int)slots.size() <= dev) slots.resize((size_t)dev + 1);
+    HostSlot& s = slots[(size_t)dev];
+    if (!s.mirror) {
+        if (hipHostMalloc((void**)&s.mirror, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { s.mirror = nullptr; return nullptr; }
+        memset((void*)s.mirror, 0, 64);
     }
-    return p;
+    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) s.ev = nullptr;   // created on `dev`
+    return &s;
 }
 
 // ---- speculative stage 2 (exact API, no idle gap after the read-back) --------------------------------------------
@@ -95,19 +105,20 @@ volatile uint32_t* host_mirror()
 // for the same (P, width, height) (+12.5 %), stage 2 is queued right behind stage 1 with that capacity, and only then
 // does the host wait -- for stage 1 alone, through an event.  If the guess was too small (or the longest tile list
 // needs a bigger sort class than guessed) everything is simply run again the exact way; the kernels are overflow-safe.
-// The capacity a binning chunk was laid out for is remembered per chunk address so that backward (which is handed the
-// exact num_rendered) finds the same offsets.  GVD_RASTER_SPECULATE=0 turns it off.
+// The capacity a speculative chunk was laid out for travels WITH the chunk: its byte size determines it uniquely
+// (gvd_raster_binning_capacity), and backward is told the size (gvd_raster_backward_conf).  Because the reference-signature
+// gvd_raster_backward only receives num_rendered, speculation is opt-in: gvd_raster_set_speculation(1) by a caller that
+// passes the chunk size to backward (the Python binding does).  GVD_RASTER_SPECULATE=0 turns it off altogether.
 struct SpecHint { int P, W, H; uint32_t r_max, list_max; };
 std::mutex g_spec_mu;
 std::vector<SpecHint> g_hints;
-std::unordered_map<const void*, uint32_t> g_chunk_cap;   // aligned binning chunk laid out SPECULATIVELY -> its capacity
-constexpr size_t kMaxSpecChunks = 1u << 16;               // beyond this many live entries speculation pauses
+std::atomic<int> g_spec_opt_in{0};
 
 bool spec_enabled()
 {
     static int on = -1;
     if (on < 0) { const char* e = getenv("GVD_RASTER_SPECULATE"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on == 1;
+    return on == 1 && g_spec_opt_in.load(std::memory_order_relaxed) != 0;
 }
 bool spec_lookup(int P, int W, int H, SpecHint* out)
 {
@@ -123,29 +134,18 @@ void spec_update(int P, int W, int H, uint32_t R, uint32_t max_list)
     if (g_hints.size() >= 16) g_hints.erase(g_hints.begin());
     g_hints.push_back(SpecHint{ P, W, H, R, max_list });
 }
-// Only chunks whose layout capacity differs from the num_rendered handed to backward need an entry; every other
-// forward ERASES the entry of the address it is about to use (the allocator may hand out the address of a dead
-// speculative chunk again).  Entries are never evicted while their chunk can still reach backward.
-void chunk_cap_set(const void* bin, uint32_t cap)
+// Capacity whose binning layout occupies exactly `bytes` (bin_bytes is strictly increasing in the capacity: the last
+// sub-array, the 48-byte partial records, ends the chunk unrounded).  Returns false if no capacity matches.
+bool capacity_of_bytes(size_t bytes, uint32_t* cap_out)
 {
-    std::lock_guard<std::mutex> lk(g_spec_mu);
-    g_chunk_cap[bin] = cap;
-}
-void chunk_cap_erase(const void* bin)
-{
-    std::lock_guard<std::mutex> lk(g_spec_mu);
-    g_chunk_cap.erase(bin);
-}
-bool chunk_cap_room()
-{
-    std::lock_guard<std::mutex> lk(g_spec_mu);
-    return g_chunk_cap.size() < kMaxSpecChunks;
-}
-uint32_t chunk_cap_get(const void* bin, uint32_t R)
-{
-    std::lock_guard<std::mutex> lk(g_spec_mu);
-    const auto it = g_chunk_cap.find(bin);
-    return (it != g_chunk_cap.end() && it->second >= R) ? it->second : R;
+    uint32_t lo = 0, hi = 0xfffffff0u;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (gvd::make_layout(0, 16, 16, mid).bin_bytes < bytes) lo = mid + 1; else hi = mid;
+    }
+    if (gvd::make_layout(0, 16, 16, lo).bin_bytes != bytes) return false;
+    *cap_out = lo;
+    return true;
 }
 inline int sort_class_of(uint32_t max_list) { return max_list > 16384 ? 2 : (max_list > 2048 ? 1 : 0); }
 
@@ -301,10 +301,13 @@ void gvd_raster_chunk_layout(int P, int width, int height, uint32_t num_rendered
     o->point_list_keys = L.keys; o->point_list = L.point_list; o->bucket = L.bucket; o->tile_order = L.tile_order;
 }
 
-uint32_t gvd_raster_chunk_capacity(const void* binning_chunk, uint32_t num_rendered)
+uint32_t gvd_raster_binning_capacity(size_t binning_chunk_bytes)
 {
-    return chunk_cap_get(align_up((char*)binning_chunk), num_rendered);
+    uint32_t cap = 0;
+    return capacity_of_bytes(binning_chunk_bytes, &cap) ? cap : 0xffffffffu;
 }
+
+void gvd_raster_set_speculation(int on) { g_spec_opt_in.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 int gvd_raster_forward(
     gvd_alloc_fn geometry_alloc, void* geometry_user, gvd_alloc_fn binning_alloc, void* binning_user,
@@ -333,12 +336,12 @@ int gvd_raster_forward(
     if (!geom || !img) return fail(GVD_ERR_ALLOC, "geometry/image allocator returned NULL");
     geom = align_up(geom);
     img = align_up(img);
-    volatile uint32_t* mirror = host_mirror();
-    if (!mirror) return fail(GVD_ERR_HIP, "hipHostMalloc(mirror) failed");
+    HostSlot* slot = host_slot();
+    if (!slot) return fail(GVD_ERR_HIP, "hipHostMalloc(mirror) failed");
+    volatile uint32_t* mirror = slot->mirror;
     SpecHint hint;
-    if (spec_enabled() && chunk_cap_room() && spec_lookup(P, width, height, &hint) && hint.r_max > 0 && hint.r_max < 0x60000000u) {
-        static thread_local hipEvent_t ev = nullptr;
-        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (spec_enabled() && spec_lookup(P, width, height, &hint) && hint.r_max > 0 && hint.r_max < 0x60000000u) {
+        hipEvent_t ev = slot->ev;
         if (ev) {
             const uint32_t cap = hint.r_max + hint.r_max / 8 + 4096;
             const int class_spec = sort_class_of(hint.list_max + hint.list_max / 4);
@@ -355,11 +358,7 @@ int gvd_raster_forward(
             const uint32_t Rs = mirror[0], max_list_s = mirror[1];
             if (Rs > 0x7fffffffu) return fail(GVD_ERR_OVERFLOW, "num_rendered exceeds int32");
             spec_update(P, width, height, Rs, max_list_s);
-            if (Rs <= cap && sort_class_of(max_list_s) <= class_spec) {
-                chunk_cap_set(bin_s, cap);
-                return (int)Rs;
-            }
-            chunk_cap_erase(bin_s);
+            if (Rs <= cap && sort_class_of(max_list_s) <= class_spec) return (int)Rs;   // (the chunk's size encodes `cap`)
             // guessed too small: fall through and run the exact path (stage 1 again, with no capacity limit)
         }
     }
@@ -375,7 +374,6 @@ int gvd_raster_forward(
     char* bin = binning_alloc(binning_user, L.bin_bytes);
     if (!bin) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
     bin = align_up(bin);
-    chunk_cap_erase(bin);   // exact layout: backward's num_rendered describes it
     const int max_class = sort_class_of(max_list);
     rc = forward_stage2(in, L, geom, bin, img, R, max_class, stream);
     if (rc != GVD_OK) return rc;
@@ -406,7 +404,6 @@ int gvd_raster_forward_capped(
     char* geom = align_up(geometry_chunk);
     char* img = align_up(image_chunk);
     char* bin = align_up(binning_chunk);
-    chunk_cap_erase(bin);   // the caller passes `capacity` to backward; drop a dead speculative chunk's entry for this address
     rc = forward_stage1(in, L, geom, img, capacity, d_status, nullptr, stream);
     if (rc != GVD_OK) return rc;
     return forward_stage2(in, L, geom, bin, img, capacity, 2, stream);
@@ -422,7 +419,7 @@ int gvd_raster_backward_conf(
     const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-    const float* confidence, int debug, void* stream_)
+    const float* confidence, size_t binning_chunk_bytes, int debug, void* stream_)
 {
     using namespace gvd;
     hipStream_t stream = (hipStream_t)stream_;
@@ -435,7 +432,12 @@ int gvd_raster_backward_conf(
     char* geom = align_up(geom_buffer);
     char* bin = align_up(binning_buffer);
     char* img = align_up(image_buffer);
-    const uint32_t cap = chunk_cap_get(bin, (uint32_t)R);   // layout capacity of this chunk (== R unless stage 2 ran speculatively)
+    // layout capacity of this chunk: num_rendered itself, unless the forward laid it out speculatively -- then its size says
+    uint32_t cap = (uint32_t)R;
+    if (binning_chunk_bytes) {
+        if (!capacity_of_bytes(binning_chunk_bytes, &cap)) return fail(GVD_ERR_INVALID, "binning_chunk_bytes is not the size of a binning chunk");
+        if (cap < (uint32_t)R) return fail(GVD_ERR_INVALID, "binning chunk is smaller than num_rendered requires");
+    }
     const Layout L = make_layout(P, width, height, cap);
     if (!radii) radii = (const int*)(geom + L.internal_radii);
     float* partials = (float*)(bin + L.partials);
@@ -494,7 +496,7 @@ int gvd_raster_backward(
                                     scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx,
                                     tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dpix_depth,
                                     dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
-                                    dL_dcov3D, dL_dsh, dL_dscale, dL_drot, nullptr, debug, stream_);
+                                    dL_dcov3D, dL_dsh, dL_dscale, dL_drot, nullptr, 0, debug, stream_);
 }
 
 int gvd_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

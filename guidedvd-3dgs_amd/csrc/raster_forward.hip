@@ -17,6 +17,7 @@
 // followed by an LDS-resident per-tile sort moves ~20 B/instance through HBM instead of
 // ~6 passes x 24 B/instance.  The sorted order is identical: (tile, depth bits, Gaussian id)
 // is a total order and equals the stable-sort order of the reference's emission sequence.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -716,11 +717,16 @@ void launch_scatter(const ScatterArgs& a, int blocks, bool lds_hist, hipStream_t
 }
 void launch_sort_tiles(const SortArgs& a, int T, int max_class, bool short_lists_too, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-        attr_set = true;
+    if (max_class >= 1) {   // the 128 KiB dynamic-LDS attribute is per DEVICE: set it once on each device that launches it
+        static std::atomic<unsigned long long> attr_mask{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (dev >= 64 || !(attr_mask.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            attr_mask.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     // lists of <= kFusedSortMax entries are normally sorted inside k_render_fwd
     if (short_lists_too) hipLaunchKernelGGL(k_sort_tiles<0>, dim3(T), dim3(256), (size_t)kFusedSortMax * 16, s, a);

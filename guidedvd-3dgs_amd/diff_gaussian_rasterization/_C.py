@@ -58,7 +58,12 @@ def lib():
         L.gvd_raster_backward.restype = _I
         L.gvd_raster_backward.argtypes = _bw + [_I, _P]
         L.gvd_raster_backward_conf.restype = _I
-        L.gvd_raster_backward_conf.argtypes = _bw + [_P, _I, _P]
+        L.gvd_raster_backward_conf.argtypes = _bw + [_P, ctypes.c_size_t, _I, _P]
+        L.gvd_raster_binning_capacity.restype = ctypes.c_uint32
+        L.gvd_raster_binning_capacity.argtypes = [ctypes.c_size_t]
+        L.gvd_raster_set_speculation.argtypes = [_I]
+        # this binding hands the binning chunk's size to backward, so the forward may lay it out speculatively (gvd_raster.h)
+        L.gvd_raster_set_speculation(1)
         L.gvd_raster_mark_visible.restype = _I
         L.gvd_raster_mark_visible.argtypes = [_I, _P, _P, _P, _P, _P]
         L.gvd_raster_chunk_layout.argtypes = [_I, _I, _I, ctypes.c_uint32, ctypes.POINTER(_ChunkLayout)]
@@ -268,7 +273,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                        _ptr(gC), _ptr(gD), _ptr(gA), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
                                        dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_ddepths.data_ptr(),
                                        dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M > 0 else None,
-                                       dL_dscales.data_ptr(), dL_drotations.data_ptr(), _ptr(conf), int(bool(debug)), _stream())
+                                       dL_dscales.data_ptr(), dL_drotations.data_ptr(), _ptr(conf), int(binningBuffer.numel()),
+                                       int(bool(debug)), _stream())
             if rc < 0:
                 raise _err(rc)
     if KEEP_BACKWARD_INTERNALS:   # parity tests: the per-Gaussian sums the reference keeps internal (rasterize_points.cu:172-176)
@@ -297,9 +303,9 @@ def chunk_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):
     """Typed views of the internal scratch arrays (tests / debugging only)."""
     lay = _ChunkLayout()
     L = lib()
-    L.gvd_raster_chunk_capacity.restype = ctypes.c_uint32
-    L.gvd_raster_chunk_capacity.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
-    cap = L.gvd_raster_chunk_capacity(binningBuffer.data_ptr(), int(R)) if binningBuffer.numel() else int(R)
+    cap = L.gvd_raster_binning_capacity(binningBuffer.numel()) if binningBuffer.numel() else int(R)
+    if cap == 0xffffffff:
+        raise RuntimeError("binningBuffer does not have the size of a binning chunk")
     L.gvd_raster_chunk_layout(P, W, H, cap, ctypes.byref(lay))
 
     def view(buf, off, nbytes, dtype):

@@ -166,6 +166,35 @@ class ParallelPlan:
                 self.cfg_group = g
         self.shard = FrameShard(self.frame_group, n_frames)
         self._world_shards = {}
+        # The latent x is replicated: every rank must draw the same x_T / per-step noise whatever its own RNG state is.
+        # One seed, chosen by rank 0, broadcast once; the samplers draw from plan.generator(device).
+        import random
+        seed = [random.SystemRandom().randrange(1 << 62) if rank == 0 else 0]
+        dist.broadcast_object_list(seed, src=0)
+        self.seed = int(seed[0])
+        self._generators = {}
+
+    def generator(self, device):
+        """The replicated-draw generator for `device` (same stream of numbers on every rank)."""
+        device = torch.device(device)
+        g = self._generators.get(device)
+        if g is None:
+            g = self._generators[device] = torch.Generator(device=device).manual_seed(self.seed)
+        return g
+
+    def reseed(self, seed):
+        """Restart the replicated noise stream (call with the same value on every rank, e.g. for reproducible runs)."""
+        self.seed = int(seed)
+        self._generators = {}
+
+    def check_replicated(self, x, what="latent"):
+        """Debug aid: raise if `x` differs across ranks (one tiny all-reduce of a checksum)."""
+        s = x.detach().double().sum().reshape(1)
+        lo, hi = s.clone(), s.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(hi - lo) != 0.0:
+            raise RuntimeError(f"{what} is not replicated across ranks (checksum spread {float(hi - lo):.3e})")
 
     # -- one U-Net evaluation on this rank's frames, result gathered to all frames -----------------------------
     def _shard_cond(self, cond):

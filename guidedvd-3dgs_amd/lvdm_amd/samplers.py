@@ -33,11 +33,26 @@ def _cat_cond(c, uc):
 
 
 class DDIMSampler(object):
+    # "device": draw on the latent's device from its global generator (what the reference does on CUDA); "cpu": draw on the
+    # CPU generator and move -- reproduces a CPU trajectory on the GPU (tests/test_diffusion_goldens_gpu.py).
+    noise_device = "device"
+
     def __init__(self, model, schedule="linear", **kwargs):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.counter = 0
+
+    def _randn(self, shape, device):
+        """Every latent-shaped draw of the samplers.  With a multi-GPU plan the latent is replicated on all ranks, so the
+        draws must be too: they come from the plan's generator (one seed, broadcast from rank 0 when the plan was made),
+        never from the per-process global generator."""
+        plan = getattr(self, "parallel", None)
+        if plan is not None:
+            return torch.randn(shape, device=device, generator=plan.generator(device))
+        if self.noise_device == "cpu":
+            return torch.randn(shape).to(device)
+        return torch.randn(shape, device=device)
 
     # ---- tables -------------------------------------------------------------------------------
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
@@ -106,7 +121,7 @@ class DDIMSampler(object):
                       fs=None, guidance_rescale=0.0, **kwargs):
         device = self.model.betas.device
         b = shape[0]
-        img = torch.randn(shape, device=device) if x_T is None else x_T
+        img = self._randn(shape, device) if x_T is None else x_T
         if precision == 16:
             img = img.to(dtype=torch.float16)
         timesteps = self.ddim_timesteps
@@ -166,7 +181,7 @@ class DDIMSampler(object):
             e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
         k = self._step_constants(index)
         if noise is None:
-            noise = torch.randn(x.shape, device=x.device)
+            noise = self._randn(x.shape, x.device)
         return ops.ddim_step(x.float(), e_cond.float(), None if e_uncond is None else e_uncond.float(), noise,
                              cfg_scale=float(unconditional_guidance_scale), guidance_rescale=float(guidance_rescale),
                              sqrt_ac_t=k["sqrt_ac_t"], sqrt_1mac_t=k["sqrt_1mac_t"], sqrt_a_prev=k["sqrt_a_prev"],
@@ -229,7 +244,7 @@ class DDIMSamplerGuidance(DDIMSampler):
             pred_x0 = (k["sqrt_ac_t"] * x - k["sqrt_1mac_t"] * v) * k["x0_rescale"]
             with torch.no_grad():
                 dir_xt = k["dir_coef"] * e_t
-                nz = torch.randn(x.shape, device=x.device) if noise is None else noise
+                nz = self._randn(x.shape, x.device) if noise is None else noise
                 x_prev = k["sqrt_a_prev"] * pred_x0 + dir_xt + k["sigma_t"] * temperature * nz
             # per-frame decode + loss gradient w.r.t. the (detached) x0 latent of that frame
             n_frames = pred_x0.shape[2]
@@ -258,6 +273,6 @@ class DDIMSamplerGuidance(DDIMSampler):
                 rms = torch.stack([(gx * gx).mean().sqrt(), (correction ** 2).mean().sqrt()]).tolist()  # one host sync
                 rho = 0.0 if rms[0] == 0 else rms[1] * s / rms[0] * (0.2 * w)
                 x_prev = x_prev - rho * gx
-                rz = torch.randn(x.shape, device=x.device) if renoise is None else renoise
+                rz = self._randn(x.shape, x.device) if renoise is None else renoise
                 x = float(np.sqrt(np.float32(beta_t))) * x_prev + float(np.sqrt(np.float32(1 - beta_t))) * rz
         return x_prev.detach(), pred_x0.detach()

@@ -18,11 +18,11 @@ import torch
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
     if schedule == "linear":  # "linear" is linear in sqrt(beta); torch.linspace (not numpy's) to match the reference's fp64 bits
-        return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+        return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu") ** 2).numpy()
     if schedule == "sqrt_linear":
-        return torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64).numpy()
+        return torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64, device="cpu").numpy()
     if schedule == "sqrt":
-        return (torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5).numpy()
+        return (torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64, device="cpu") ** 0.5).numpy()
     if schedule == "cosine":
         ts = np.arange(n_timestep + 1, dtype=np.float64) / n_timestep + cosine_s
         a = np.cos(ts / (1 + cosine_s) * np.pi / 2) ** 2
@@ -94,7 +94,7 @@ class DiffusionSchedule(torch.nn.Module):
         self.linear_start, self.linear_end = linear_start, linear_end
         self.parameterization = parameterization
         self.use_dynamic_rescale = use_dynamic_rescale
-        f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+        f32 = lambda a: torch.tensor(a, dtype=torch.float32, device="cpu")   # host tables (also under a torch.device(...) context)
         self.register_buffer("betas", f32(betas))
         self.register_buffer("alphas_cumprod", f32(ac))
         self.register_buffer("alphas_cumprod_prev", f32(ac_prev))
@@ -109,8 +109,8 @@ class DiffusionSchedule(torch.nn.Module):
                     self.register_buffer("sqrt_recip_alphas_cumprod", f32(np.sqrt(1. / ac)))
                     self.register_buffer("sqrt_recipm1_alphas_cumprod", f32(np.sqrt(1. / ac - 1)))
                 else:
-                    self.register_buffer("sqrt_recip_alphas_cumprod", torch.zeros(self.num_timesteps))
-                    self.register_buffer("sqrt_recipm1_alphas_cumprod", torch.zeros(self.num_timesteps))
+                    self.register_buffer("sqrt_recip_alphas_cumprod", torch.zeros(self.num_timesteps, device="cpu"))
+                    self.register_buffer("sqrt_recipm1_alphas_cumprod", torch.zeros(self.num_timesteps, device="cpu"))
                 pv = (1 - v_posterior) * betas * (1. - ac_prev) / (1. - ac) + v_posterior * betas
                 self.register_buffer("posterior_variance", f32(pv))
                 self.register_buffer("posterior_log_variance_clipped", f32(np.log(np.maximum(pv, 1e-20))))

@@ -27,8 +27,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint as _ckpt
 
-from . import ops, parallel
+from . import conv as mconv, ops, parallel
 from .schedule import timestep_embedding
+
+
+def _fused(t, module=None):
+    """The hand-written MFMA convolution path (csrc/conv_mfma.hip) applies: fp16 activations on a ROCm device, inference
+    (dropout inactive), frames not sharded over ranks.  Everything else -- fp32 parity runs, the CPU reference form, the
+    frame-sharded multi-GPU layout -- takes the module-by-module form below (torch convolutions)."""
+    return (t.is_cuda and t.dtype == torch.float16 and parallel.active() is None
+            and not (module is not None and module.training))
 
 
 def zero_module(m):
@@ -301,7 +309,32 @@ class TemporalConvBlock(nn.Module):
                 out[bi, :-1].reshape(-1, co).addmm_(hs[bi, 1:].reshape(-1, c), w2)
         return out
 
-    def forward_tokens(self, tok, b):  # tok [(b t), H, W, C] contiguous
+    def _forward_tokens_fused(self, tok, b, stats=None):
+        """Four launches of the temporal MFMA kernel per sample: GroupNorm+SiLU in the operand load, the identity add in the
+        last epilogue, and each convolution leaves the statistics its successor's norm needs (openaimodel3d.py:270-278)."""
+        bt, hh, ww, c = tok.shape
+        T = bt // b
+        outs = []
+        for bi in range(b):
+            x0 = tok[bi * T:(bi + 1) * T].reshape(T, hh * ww, c)
+            h, part = x0, (stats if b == 1 else None)
+            seqs = (self.conv1, self.conv2, self.conv3, self.conv4)
+            for k, seq in enumerate(seqs):
+                gn, conv = seq[0], seq[-1]
+                if part is None:
+                    ns = mconv.norm_state(gn, x=h.detach(), n_stat=1)
+                else:  # per-frame sums of a 2-D producer merge into the per-video statistics of this 5-D norm
+                    ns = mconv.norm_state(gn, partial=part, merge=part.N)
+                last = k == len(seqs) - 1
+                h, part = mconv.fused_conv(h, conv, mode=mconv.TEMPORAL, gn=gn, norm=ns, silu=True,
+                                           residual=x0 if last else None, stats_groups=0 if last else gn.num_groups)
+            outs.append(h)
+        out = outs[0] if b == 1 else torch.cat(outs, 0)
+        return out.reshape(bt, hh, ww, c)
+
+    def forward_tokens(self, tok, b, stats=None):  # tok [(b t), H, W, C] contiguous
+        if _fused(tok, self):
+            return self._forward_tokens_fused(tok, b, stats)
         bt, hh, ww, c = tok.shape
         shard = parallel.active()
         if shard is None:
@@ -347,7 +380,31 @@ class ResBlock(nn.Module):
             h = _img(self.temopral_conv.forward_tokens(_tok(h), batch_size))
         return h
 
+    def _fwd_fused(self, x, emb, batch_size):
+        """Two launches of the MFMA convolution (+ the 1x1 skip GEMM when channels change): both GroupNorm+SiLU pairs live in
+        the operand loads, `+ emb_out`, `+ skip` and the 16-bit rounding in the epilogues; the first convolution leaves the
+        statistics of its output for the second norm, the second for the temporal block's first norm."""
+        tok = _tok(x)
+        gn1, conv1 = self.in_layers[0], self.in_layers[2]
+        gn2, conv2 = self.out_layers[0], self.out_layers[3]
+        emb_out = self.emb_layers[1](F.silu(emb)).to(tok.dtype)
+        h, part = mconv.fused_conv(tok, conv1, gn=gn1, silu=True, add_nc=emb_out, stats_groups=gn2.num_groups)
+        ns2 = mconv.norm_state(gn2, partial=part)
+        if isinstance(self.skip_connection, nn.Identity):
+            skip = tok
+        else:  # 1x1 convolution == per-token GEMM on the same bytes
+            sc = self.skip_connection
+            skip = F.linear(tok, sc.weight.flatten(1), sc.bias)
+        temporal = self.use_temporal_conv and batch_size
+        h, part = mconv.fused_conv(h, conv2, gn=gn2, norm=ns2, silu=True, residual=skip,
+                                   stats_groups=self.temopral_conv.conv1[0].num_groups if temporal else 0)
+        if temporal:
+            h = self.temopral_conv.forward_tokens(h, batch_size, stats=part)
+        return _img(h)
+
     def forward(self, x, emb, batch_size=None):
+        if _fused(x, self):
+            return _run(lambda a, e: self._fwd_fused(a, e, batch_size), self.use_checkpoint, x, emb)
         return _run(lambda a, e: self._fwd(a, e, batch_size), self.use_checkpoint, x, emb)
 
 
@@ -366,6 +423,8 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(channels, out_channels or channels, 3, padding=1)
 
     def forward(self, x):
+        if _fused(x, self):  # the x2 nearest upsampling happens in the kernel's patch addressing: no 4x-sized intermediate
+            return _img(mconv.fused_conv(_tok(x), self.conv, upsample=True)[0])
         return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"))
 
 
@@ -380,6 +439,8 @@ class TimestepEmbedSequential(nn.Sequential):
                 x = layer(x, context, shared_frames)
             elif isinstance(layer, TemporalTransformer):
                 x = layer(x, batch_size)
+            elif isinstance(layer, nn.Conv2d) and layer.kernel_size == (3, 3) and layer.stride == (1, 1) and _fused(x, layer):
+                x = _img(mconv.fused_conv(_tok(x), layer)[0])
             else:
                 x = layer(x)
         return x
@@ -503,5 +564,8 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb, context, b, shared)
         for module in self.output_blocks:
             h = module(torch.cat([h, hs.pop()], dim=1), emb, context, b, shared)
-        y = self.out[2](self.out[0](h, silu=True)).to(xin_dtype)
+        if _fused(h, self):
+            y = _img(mconv.fused_conv(_tok(h), self.out[2], gn=self.out[0], silu=True)[0]).to(xin_dtype)
+        else:
+            y = self.out[2](self.out[0](h, silu=True)).to(xin_dtype)
         return y.reshape(b, t, -1, hh, ww).transpose(1, 2)

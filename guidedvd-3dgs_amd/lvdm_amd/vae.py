@@ -9,7 +9,21 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import conv as mconv, ops
+
+
+def _fused(t, module=None):
+    """fp16 activations on a ROCm device in inference mode take the hand-written MFMA convolutions (csrc/conv_mfma.hip) on
+    token-major data; fp32 parity runs and the CPU reference form take the torch convolutions."""
+    return t.is_cuda and t.dtype == torch.float16 and not (module is not None and module.training)
+
+
+def _tok(x):
+    return x.permute(0, 2, 3, 1).contiguous()   # a view when x is channels_last
+
+
+def _img(tok):
+    return tok.permute(0, 3, 1, 2)
 
 
 def _norm(c):
@@ -40,7 +54,22 @@ class ResnetBlock(nn.Module):
         if in_channels != out_channels:
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1)
 
+    def forward_tokens(self, tok, stats=None, want_stats=False):
+        """tok [N, H, W, C] -> (out tokens, statistics of out for the next norm | None).  Two MFMA convolution launches:
+        norm + swish in the operand load, the shortcut add in the second epilogue (ae_modules.py:186-210)."""
+        ns1 = mconv.norm_state(self.norm1, partial=stats) if stats is not None else None
+        h, part = mconv.fused_conv(tok, self.conv1, gn=self.norm1, norm=ns1, silu=True, stats_groups=32)
+        ns2 = mconv.norm_state(self.norm2, partial=part)
+        if hasattr(self, "nin_shortcut"):
+            skip = F.linear(tok, self.nin_shortcut.weight.flatten(1), self.nin_shortcut.bias)
+        else:
+            skip = tok
+        return mconv.fused_conv(h, self.conv2, gn=self.norm2, norm=ns2, silu=True, residual=skip,
+                                stats_groups=32 if want_stats else 0)
+
     def forward(self, x):
+        if _fused(x, self):
+            return _img(self.forward_tokens(_tok(x))[0])
         h = self.conv1(_gn_swish(self.norm1, x))
         h = self.conv2(_gn_swish(self.norm2, h))
         return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
@@ -54,7 +83,18 @@ class AttnBlock(nn.Module):
         self.norm = _norm(c)
         self.q, self.k, self.v, self.proj_out = (nn.Conv2d(c, c, 1) for _ in range(4))
 
+    def forward_tokens(self, tok):
+        """tok [N, H, W, C]: norm -> q/k/v (1x1 convolutions == per-token GEMMs) -> single-head attention -> proj_out -> + x."""
+        n, h, w, c = tok.shape
+        t = tok.reshape(n, h * w, c)
+        hn = ops.group_norm(t, 32, self.norm.weight, self.norm.bias, self.norm.eps, silu=False, channels_last=True)
+        lin = lambda m, a: F.linear(a, m.weight.flatten(1), m.bias)
+        o = ops.attention(lin(self.q, hn), lin(self.k, hn), lin(self.v, hn), heads=1)
+        return (t + lin(self.proj_out, o)).reshape(n, h, w, c)
+
     def forward(self, x):
+        if _fused(x, self):
+            return _img(self.forward_tokens(_tok(x)))
         b, c, h, w = x.shape
         hn = _gn(self.norm, x, False)
         tok = lambda t: t.flatten(2).transpose(1, 2)  # [b, hw, c]
@@ -68,6 +108,8 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
+        if _fused(x, self):
+            return _img(mconv.fused_conv(_tok(x), self.conv, upsample=True)[0])
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
@@ -99,7 +141,26 @@ class Decoder(nn.Module):
         self.norm_out = _norm(block_in)
         self.conv_out = nn.Conv2d(block_in, out_ch, 3, padding=1)
 
+    def _forward_fused(self, z):
+        """The whole decoder on token-major data with the MFMA convolutions; every convolution epilogue hands the next
+        GroupNorm its statistics, so no separate statistics / normalisation pass touches the (up to 576x1024x128) maps."""
+        t, st = mconv.fused_conv(_tok(z), self.conv_in, stats_groups=32)
+        t, _ = self.mid.block_1.forward_tokens(t, st)
+        t = self.mid.attn_1.forward_tokens(t)
+        t, st = self.mid.block_2.forward_tokens(t, None, want_stats=True)
+        for i_level in reversed(range(self.num_resolutions)):
+            blocks = self.up[i_level].block
+            for k, blk in enumerate(blocks):
+                last = k == len(blocks) - 1
+                t, st = blk.forward_tokens(t, st, want_stats=not (last and i_level != 0))
+            if i_level != 0:
+                t, st = mconv.fused_conv(t, self.up[i_level].upsample.conv, upsample=True, stats_groups=32)
+        ns = mconv.norm_state(self.norm_out, partial=st)
+        return _img(mconv.fused_conv(t, self.conv_out, gn=self.norm_out, norm=ns, silu=True)[0])
+
     def forward(self, z):
+        if _fused(z, self):
+            return self._forward_fused(z)
         h = self.conv_in(z)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for i_level in reversed(range(self.num_resolutions)):

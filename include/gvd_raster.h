@@ -85,11 +85,15 @@ int gvd_raster_forward(
     int debug,
     void* stream);
 
-/* Capacity the binning chunk `binning_chunk` (as returned by the allocator callback) was laid out for by the forward
- * that produced it: num_rendered itself, or the larger speculative capacity when stage 2 was queued before the
- * read-back (see capi.hip, GVD_RASTER_SPECULATE).  gvd_raster_backward looks this up itself; tests that inspect the
- * internal arrays pass it to gvd_raster_chunk_layout instead of num_rendered. */
-uint32_t gvd_raster_chunk_capacity(const void* binning_chunk, uint32_t num_rendered);
+/* Speculative stage 2 (MI355X addition, off by default so that the two reference-signature entry points keep the reference's
+ * contract): after gvd_raster_set_speculation(1), gvd_raster_forward may lay the binning chunk out for MORE instances than
+ * num_rendered (it queues scatter/sort/blend before the read-back, sized from earlier renders of the same P x width x height;
+ * see capi.hip).  The capacity is encoded in the chunk's byte size -- the allocator callback is asked for exactly
+ * gvd_raster_binning_bytes(capacity) bytes -- so a caller that opts in must hand that size to gvd_raster_backward_conf
+ * (binning_chunk_bytes).  Nothing is keyed on chunk addresses: chunks may be cloned, offloaded and restored freely.
+ * gvd_raster_binning_capacity inverts gvd_raster_binning_bytes (0xffffffff if `bytes` is not a chunk size). */
+void gvd_raster_set_speculation(int on);
+uint32_t gvd_raster_binning_capacity(size_t binning_chunk_bytes);
 
 /* Sync-free variant (MI355X addition; no reference counterpart): the caller supplies the
  * binning chunk up front, sized gvd_raster_binning_bytes(capacity, ...).  num_rendered stays
@@ -168,7 +172,9 @@ int gvd_raster_backward(
  * folds the Python-side scaling of diff_gaussian_rasterization/__init__.py:147-157 into the gather
  * kernel -- dL_dmean3D, dL_dopacity, dL_dcolor, dL_dsh, dL_dscale, dL_drot, dL_dcov3D are returned
  * already multiplied by confidence; dL_dmean2D is not (ref :149).  dL_dpix_depth / dL_dalphas may be
- * NULL (== zero gradient for that output), here and in gvd_raster_backward. */
+ * NULL (== zero gradient for that output), here and in gvd_raster_backward.
+ * binning_chunk_bytes: byte size of the binning chunk as requested from the allocator callback (0 = laid out for exactly R;
+ * required after gvd_raster_set_speculation(1)). */
 int gvd_raster_backward_conf(
     int P, int D, int M, int R,
     const float* background,
@@ -203,6 +209,7 @@ int gvd_raster_backward_conf(
     float* dL_dscale,
     float* dL_drot,
     const float* confidence,
+    size_t binning_chunk_bytes,
     int debug,
     void* stream);
 

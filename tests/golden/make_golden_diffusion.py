@@ -166,6 +166,28 @@ def main():
         xp, p0 = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
                                  guidance_rescale=0.7, loss_guidance_fn=LG(gi_, gm_))
         out[f"guided{index}_xprev"], out[f"guided{index}_x0"] = xp.numpy(), p0.numpy()
+    # ---------------- G6b: a U-Net whose heads are 64 wide (the ViewCrafter head size) on a 16x24 latent: the case the
+    # `-m gpu` tests push through the fp16 HIP path (MFMA attention needs d = 64; the convolution tiles need > 8x8) ----
+    cfg64 = dict(cfg, num_head_channels=64, context_dim=64)
+    unet64 = fill_by_name(UNetModel(**cfg64)).eval()
+    g2 = torch.Generator().manual_seed(64)
+    for tag, T, L in (("shared", 4, 77 + 24), ("perframe", 2, 77 + 2 * 16)):
+        x = torch.randn(1, 8, T, 16, 24, generator=g2)
+        ctx = torch.randn(1, L, 64, generator=g2)
+        x.requires_grad_(True)
+        y = unet64(x, torch.tensor([250]), context=ctx, fs=torch.tensor([10]))
+        gy = torch.randn(y.shape, generator=g2)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        out[f"unet64_{tag}_x"], out[f"unet64_{tag}_ctx"], out[f"unet64_{tag}_y"] = x.detach().numpy(), ctx.numpy(), y.detach().numpy()
+        out[f"unet64_{tag}_gy"], out[f"unet64_{tag}_gx"] = gy.numpy(), gx.numpy()
+    # ---------------- G9b: VAE decoder with a 64-channel single-head mid attention on a 12x20 latent ----
+    dd64 = dict(dd, ch=32, ch_mult=[1, 2])
+    dec64 = fill_by_name(Decoder(**dd64)).eval()
+    z = torch.randn(1, 4, 12, 20, generator=g2).requires_grad_(True)
+    img = dec64(z)
+    gi = torch.randn(img.shape, generator=g2)
+    (gz,) = torch.autograd.grad(img, z, gi)
+    out["dec64_z"], out["dec64_img"], out["dec64_gi"], out["dec64_gz"] = z.detach().numpy(), img.detach().numpy(), gi.numpy(), gz.numpy()
     np.savez_compressed(os.path.join(HERE, "diffusion_ref.npz"), **out)
     print("wrote", os.path.getsize(os.path.join(HERE, "diffusion_ref.npz")), "bytes;", len(out), "arrays")
 

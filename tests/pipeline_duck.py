@@ -28,7 +28,7 @@ class PipeDuck(torch.nn.Module):
 
     @property
     def device(self):
-        return torch.device("cpu")
+        return self.txt.weight.device
 
     # -- conditioning side (N2 modules in the real model) --
     def embedder(self, img):                               # [b,3,h,w] -> [b,4,8]
@@ -39,7 +39,7 @@ class PipeDuck(torch.nn.Module):
         return torch.tanh(e) * 0.5 + 0.1
 
     def get_learned_conditioning(self, prompts):
-        ids = torch.tensor([[len(p) % 4, (len(p) + 1) % 4, 3] for p in prompts])
+        ids = torch.tensor([[len(p) % 4, (len(p) + 1) % 4, 3] for p in prompts], device=self.device)
         return self.txt(ids)
 
     def encode_first_stage(self, x):                       # [(b t),3,H,W] -> [(b t),4,H/2,W/2]

@@ -96,6 +96,14 @@ def _worker(rank, world, cfg, port, q):
         for k in ref:
             scale = float(ref[k].abs().max())
             errs[k] = float((got[k] - ref[k]).abs().max()) / scale
+        # replicated draws: with rank-dependent global RNG state (the common seed + rank convention) the x_T / sigma noise /
+        # re-noise of the samplers must still be identical on every rank -- they come from the plan's broadcast-seeded generator
+        torch.manual_seed(1000 + rank)
+        from lvdm_amd.samplers import DDIMSampler
+        sr = DDIMSampler(built[0])
+        sr.parallel = plan
+        for _ in range(3):
+            plan.check_replicated(sr._randn((1, 4, T, HL, WL), torch.device("cpu")), "sampler noise under a plan")
         # the guidance term must actually be exercised: guided != plain
         moved = float((ref["guided_xprev"] - ref["plain_xprev"]).abs().max())
         q.put((rank, errs, moved, (plan.cfg, plan.F, plan.cfg_rank, plan.frame_rank, plan.shard.counts)))
