@@ -1,18 +1,23 @@
 #!/usr/bin/env python
-"""bench.py -- hot-path benchmark of the MI355X-native Gaussian rasterizer.
+"""bench.py -- hot-path benchmark: the MI355X-native Gaussian rasterizer + the ViewCrafter DDIM loop.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+(with --gpus N > 1 and no WORLD_SIZE in the environment the script launches those N ranks itself.)
 
-Workload (BASELINE.json configs[1]): Replica-like room, ~200k Gaussians, 640x480, 6 ring cameras,
-SH degree 3; one step = one training-view rasterization forward + backward through the drop-in
-operator (GaussianRasterizer + autograd), RGB-only loss gradient, inputs resident in HBM.
-N > 1: per-camera shards -- every rank owns a replica of the Gaussians and renders its own view
-(weak scaling, no data-path collective); value = views/s over all ranks.
+BASELINE.json's metric has two halves, "3DGS train iters/s + ViewCrafter 25-frame DDIM steps/s"; the ONE JSON line carries
+both: the top level is the raster half (BASELINE configs[1]), the `ddim` object the diffusion half (configs[2]).
 
-Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel, HIP-event timed inside the
-timed region) and `cpu_baseline` (the C oracle on the host cores; baseline only).
+Raster (top level): Replica-like room, ~200k Gaussians, 640x480, 6 ring cameras, SH degree 3; one step = one training-view
+rasterization forward + backward through the drop-in operator (GaussianRasterizer + autograd), RGB-only loss gradient, inputs
+resident in HBM.  N > 1: data-parallel view shards -- every rank holds a replica of the Gaussians, renders its own view and
+the per-Gaussian gradients are summed with ONE fused all-reduce over RCCL (multiview.allreduce_gradients; 62 floats per
+Gaussian): value = views/s over all ranks, weak scaling; `replicas_value` is the same without the collective.
+DDIM (`ddim`): 25 frames, 576x1024, CFG 7.5, rescale 0.7, eta 1, random-init 1.44 B-parameter U-Net, fp16; one step = one
+DDIM step (2 U-Net forwards + the fused update).  N > 1: CFG pair x frame shards over RCCL (strong scaling).
+
+Both carry `roofline` (dominant kernel, HIP-event timed inside the timed region) and `cpu_baseline` (host cores; baseline only).
 """
 import argparse
 import json
@@ -37,8 +42,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--workload", choices=["raster", "ddim", "ddim_guided"], default="raster",
-                    help="raster = BASELINE configs[1] (default, the driver's line); ddim = configs[2], ViewCrafter 25-frame DDIM")
+    ap.add_argument("--workload", choices=["all", "raster", "ddim", "ddim_guided"], default="all",
+                    help="all = raster line + `ddim` object (default, the driver's line); raster = BASELINE configs[1] only; "
+                         "ddim / ddim_guided = configs[2] as a line of its own")
+    ap.add_argument("--ddim-steps", type=int, default=10, help="timed DDIM steps of the `ddim` object in the default run")
     ap.add_argument("--ddim-height", type=int, default=576)
     ap.add_argument("--ddim-width", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=25)
@@ -53,25 +60,65 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_spawn(args.gpus)
+
+    import lvdm_amd
+    lvdm_amd.configure_tuning()   # recorded hipBLASLt / MIOpen choices (explicit opt-in; before the first GEMM)
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    if args.workload in ("ddim", "ddim_guided"):
-        return ddim_main(args)
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
+    local_rank = local_rank % torch.cuda.device_count()   # (several ranks per GPU only in the gloo dry run)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        local_rank = local_rank % torch.cuda.device_count()   # (several ranks per GPU only in the gloo dry run below)
-        torch.cuda.set_device(local_rank)
         _init_dist(dist, torch, local_rank)
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+    try:
+        if args.workload in ("ddim", "ddim_guided"):
+            line = ddim_run(args, dev, rank, world, guided=args.workload == "ddim_guided", steps=min(args.steps, 50),
+                            warm=min(args.warmup, 5), cpu_leg_wanted=not args.no_cpu_baseline)
+        else:
+            line = raster_run(args, dev, rank, world)
+            if args.workload == "all":
+                d = ddim_run(args, dev, rank, world, guided=False, steps=args.ddim_steps, warm=2,
+                             cpu_leg_wanted=not args.no_cpu_baseline)
+                if rank == 0:
+                    line["metric"] = "3dgs_raster_train_iters_per_s (+ ddim.value: viewcrafter_ddim_steps_per_s)"
+                    line["ddim"] = d
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _self_spawn(n):
+    """--gpus N without a launcher: start the N ranks (one per GPU, RCCL) exactly as the driver would."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def raster_run(args, dev, rank, world):
+    """BASELINE configs[1]; returns the JSON line (rank 0) or None."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     import synthetic as syn
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
@@ -129,29 +176,45 @@ def main():
             torch.autograd.backward([color], [gC])
         else:
             loss_fn(color).backward()
+        if reduce_grads:   # data-parallel training step: sum the per-Gaussian gradients of the N views (one fused all-reduce)
+            multiview.allreduce_gradients(params)
         return color
 
+    import multiview
     L = _C.lib()
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    L.gvd_profile_reset()
-    L.gvd_profile_enable(1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    L.gvd_profile_enable(0)
-    if world > 1:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
+
+    def timed_region(n_warm, n_steps, profile):
+        for i in range(n_warm):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if profile:
+            L.gvd_profile_reset()
+            L.gvd_profile_enable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(n_warm + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if profile:
+            L.gvd_profile_enable(0)
+        if world > 1:
+            et = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(et, op=dist.ReduceOp.MAX)
+            el = float(et.item())
+        return el
+
+    replicas_value = None
+    reduce_grads = False
+    if world > 1:   # the same views without the collective (independent replicas), for reference next to the headline
+        replicas_value = round(args.steps * world / timed_region(args.warmup, args.steps, False), 2)
+        reduce_grads = True
+    elapsed = timed_region(args.warmup, args.steps, True)
+    reduce_grads = False
 
     # ---- per-kernel HIP-event times (rank 0's stream) ----
     # The two blend kernels were timed live inside the timed region (level 1).  The small kernels are
@@ -272,16 +335,17 @@ def main():
                        "gaussians": P, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cams),
                        "num_rendered_mean": int(R_mean), "visible_mean": int(vis_mean),
                        "mean_tile_list": round(R_mean / (((W + 15) // 16) * ((H + 15) // 16)), 1),
-                       "parallelism": f"per-camera shards x{world}"},
+                       "parallelism": "single GPU" if world == 1 else
+                       f"dp{world}: one view per rank + ONE fused fp32 gradient all-reduce per step over RCCL "
+                       f"({sum(p_.numel() for p_ in params) * 4 / 1e6:.1f} MB)"},
+            "replicas_value": replicas_value,
             "roofline": roofline,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "variants": variants,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 def _init_dist(dist, torch, local_rank):
@@ -294,25 +358,15 @@ def _init_dist(dist, torch, local_rank):
         dist.init_process_group(backend=backend)
 
 
-def ddim_main(args):
+def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted):
     """BASELINE configs[2]: ViewCrafter 25-frame DDIM (unguided: 2 U-Net forwards + fused update per step),
     random-init U-Net with the zero-init modules re-randomised (SURVEY 7 'random-init U-Net is degenerate'),
     fp16 weights/activations with fp32 GroupNorm statistics and fp32 sampler math, synthetic conditioning.
-    One step = one DDIM step.  --gpus N > 1: CFG pair x frame shards over RCCL (lvdm_amd/parallel.py), strong scaling."""
+    One step = one DDIM step.  world > 1: CFG pair x frame shards over RCCL (lvdm_amd/parallel.py), strong scaling.
+    Returns the result dict on rank 0 (None elsewhere)."""
     import numpy as np
     import torch
     import torch.distributed as dist
-    assert torch.cuda.is_available()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = local_rank % torch.cuda.device_count()
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    if world > 1:  # CFG pair x frame shards, one rank per GPU over RCCL (lvdm_amd/parallel.py)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        _init_dist(dist, torch, local_rank)
     torch.backends.cudnn.benchmark = os.environ.get("GVD_CONV_FIND", "1") == "1"  # let MIOpen time its NHWC solvers once per shape
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from lvdm_amd import ops
@@ -330,9 +384,8 @@ def ddim_main(args):
         for p_ in unet.parameters():  # re-randomise zero-init modules, std 0.02
             if float(p_.abs().max()) == 0.0:
                 p_.copy_(torch.randn(p_.shape, device=dev, generator=g) * 0.02)
-    unet = unet.half().eval().to_token_major()
+    unet = unet.half().eval().to_token_major().requires_grad_(False)
 
-    guided = args.workload == "ddim_guided"
     vae = None
     if guided:  # B3/B13: per-frame KL-VAE decode inside the step, random-init decoder (no checkpoints offline)
         from lvdm_amd.guidance import LossGuidance
@@ -341,9 +394,7 @@ def ddim_main(args):
         from lvdm_amd.vae import AutoencoderKLDecoder
         with torch.device(dev):
             vae = AutoencoderKLDecoder(VIEWCRAFTER_VAE)
-        vae = vae.half().eval()
-        if os.environ.get("GVD_VAE_TOKEN_MAJOR", "0") == "1":  # measured: 0.520 vs 0.533 steps/s for NCHW @576x1024 -> off
-            vae = vae.to_token_major()
+        vae = vae.half().eval().to_token_major()   # token-major throughout: the MFMA convolutions' layout
         for p_ in list(unet.parameters()) + list(vae.parameters()):
             p_.requires_grad_(False)
 
@@ -387,7 +438,6 @@ def ddim_main(args):
         lg.set_guidance_masks((torch.rand(T, 1, args.ddim_height, args.ddim_width, device=dev, generator=g) > 0.3).float())
     x = torch.randn(1, 4, T, h, w, device=dev, generator=g)
     fs = torch.tensor([10], device=dev)
-    steps, warm = min(args.steps, 50), min(args.warmup, 5)
     idx = list(range(49, -1, -1))
 
     def one(i, x):
@@ -409,41 +459,63 @@ def ddim_main(args):
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    # attention kernel time inside the timed region (HIP events on torch's current stream = the launch stream)
-    ev = []
-    orig = ops._hip_attention_fwd
+    # Kernel time inside the timed region: HIP events on torch's current stream (= the stream the C-ABI launches go to)
+    # around every launch of the two MFMA kernel families -- the implicit-GEMM convolutions and flash attention.
+    from lvdm_amd import conv as mconv
+    ev_attn, ev_conv = [], []
+    orig_attn, orig_conv = ops._hip_attention_fwd, mconv._launch
 
     def timed_attn(q, k, v, heads, frame_major=False, want_lse=False):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        o = orig(q, k, v, heads, frame_major, want_lse)
+        o = orig_attn(q, k, v, heads, frame_major, want_lse)
         b.record()
         nb, nq, nk = (q.shape[1], q.shape[0], k.shape[0]) if frame_major else (q.shape[0], q.shape[1], k.shape[1])
-        ev.append((a, b, nb * heads, nq, nk))
+        ev_attn.append((a, b, 4.0 * nb * heads * nq * nk * 64))
         return o
 
-    ops._hip_attention_fwd = timed_attn
+    def timed_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        o = orig_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw)
+        b.record()
+        ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * (9 if mode == mconv.SPATIAL else 3)))
+        return o
+
+    ops._hip_attention_fwd, mconv._launch = timed_attn, timed_conv
     t0 = time.perf_counter()
-    for i in range(steps):
-        x = one(warm + i, x)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    try:
+        for i in range(steps):
+            x = one(warm + i, x)
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ops._hip_attention_fwd = orig
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        ops._hip_attention_fwd, mconv._launch = orig_attn, orig_conv
     assert torch.isfinite(x).all()
     if world > 1:  # max over ranks
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
         if rank != 0:
-            dist.barrier()
-            dist.destroy_process_group()
-            return
-    att_ms = sum(a.elapsed_time(b) for a, b, *_ in ev)
-    att_flops = sum(4.0 * bh * nq * nk * 64 for _, _, bh, nq, nk in ev)
+            return None
     MFMA_PEAK = 2500.0  # TFLOP/s dense f16/bf16 (MI355X_MICROARCH.md)
+
+    def roof(evs, name):
+        ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+        fl = sum(f for _, _, f in evs)
+        if not ms:
+            return None
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "launches": len(evs), "ms_per_step": round(ms / steps, 2),
+                "alg_tflop_per_step": round(fl / steps / 1e12, 2)}
+
+    r_conv = roof(ev_conv, "k_conv_mfma (3x3 / upsample / temporal implicit-GEMM convolutions, fused GroupNorm+SiLU prologue)")
+    r_attn = roof(ev_attn, "k_attn_fwd (all spatial / cross / temporal attention launches)")
+    dominant = r_conv if (r_conv and (not r_attn or r_conv["ms_per_step"] >= r_attn["ms_per_step"])) else r_attn
     unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
     line = {
         "metric": "viewcrafter_guided_ddim_steps_per_s" if guided else "viewcrafter_ddim_steps_per_s", "value": round(steps / elapsed, 4), "unit": "steps/s", "n_gpus": world,
@@ -459,20 +531,15 @@ def ddim_main(args):
                    "parallelism": "single GPU" if plan is None else f"cfg{plan.cfg} x frames{plan.F} (frame counts {plan.shard.counts})",
                    "baseline_note": "vs_baseline = steps/s over the ViewCrafter README A100 figure 0.42 steps/s (120 s / 50 steps, "
                                     "whole pipeline incl. VAE/CLIP; third_party/ViewCrafter/README.md:116-118)"},
-        "roofline": {"bound": "mfma", "kernel": "k_attn_fwd (all spatial/cross/temporal attention launches)",
-                     "achieved": round(att_flops / (att_ms * 1e-3) / 1e12, 2) if att_ms else None, "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                     "frac": round(att_flops / (att_ms * 1e-3) / 1e12 / MFMA_PEAK, 4) if att_ms else None, "traffic": None,
-                     "launches": len(ev), "attention_ms_per_step": round(att_ms / steps, 2)},
+        "roofline": dominant,
+        "roofline_conv": r_conv, "roofline_attention": r_attn,
         "unet_achieved_tflops": (round(2 * unet_tflop * steps / elapsed, 1) if unet_tflop and not guided else None),
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
     }
-    if not args.no_cpu_baseline and unet_tflop and world == 1:
+    if cpu_leg_wanted and unet_tflop and world == 1:
         line["cpu_baseline"] = ddim_cpu_leg(unet, T, unet_tflop, guided)
-    print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
 def ddim_cpu_leg(unet, T, unet_tflop, guided):

@@ -47,10 +47,12 @@ def _taps(weight):
     return weight.reshape(weight.shape[0], weight.shape[1], -1)
 
 
-def packed(weight, BN, backward=False, cin_pad=0):
-    """Packed image of a (frozen) conv weight, cached on the parameter.  backward: the input-gradient operator
-    (Cout <-> Cin transposed, taps flipped).  cin_pad: zero input channels appended (Cin not a multiple of 8)."""
-    key = (BN, backward, cin_pad, weight.dtype, weight.device)
+def packed(weight, BN, backward=False, cin_pad=0, dtype=None):
+    """Packed image of a conv weight in `dtype` (the activations' 16-bit type; fp32 master weights under autocast are cast
+    here, once), cached on the parameter until it is modified.  backward: the input-gradient operator (Cout <-> Cin
+    transposed, taps flipped).  cin_pad: zero input channels appended (Cin not a multiple of 8)."""
+    dtype = dtype or weight.dtype
+    key = (BN, backward, cin_pad, dtype, weight.device)
     cache = getattr(weight, "_gvd_packed", None)
     tag = (weight._version, weight.data_ptr())
     if cache is None or cache[0] != tag:
@@ -61,7 +63,7 @@ def packed(weight, BN, backward=False, cin_pad=0):
             pass
     hit = cache[1].get(key)
     if hit is None:
-        w3 = _taps(weight.detach())
+        w3 = _taps(weight.detach()).to(dtype)
         if backward:
             w3 = w3.flip(2).transpose(0, 1)
         if cin_pad:
@@ -73,10 +75,11 @@ def packed(weight, BN, backward=False, cin_pad=0):
 class NormState:
     """GroupNorm statistics + per-(sample, channel) affine in the layout of gvd_group_norm (fp64 sums [N][G][2], then fp32
     (a, b) [N][C]); what the fused convolution's prologue and the GroupNorm backward kernel read."""
-    __slots__ = ("buf", "N", "C", "G", "S", "eps", "gamma32")
+    __slots__ = ("buf", "N", "C", "G", "S", "eps", "gamma32", "group")
 
-    def __init__(self, buf, N, C, G, S, eps, gamma32):
-        self.buf, self.N, self.C, self.G, self.S, self.eps, self.gamma32 = buf, N, C, G, S, eps, gamma32
+    def __init__(self, buf, N, C, G, S, eps, gamma32, group=None):
+        # S: elements per (sample, channel) the statistics span -- over ALL ranks of `group` when the norm is sharded
+        self.buf, self.N, self.C, self.G, self.S, self.eps, self.gamma32, self.group = buf, N, C, G, S, eps, gamma32, group
 
     @property
     def coef_ptr(self):
@@ -91,32 +94,37 @@ class PartialStats:
         self.sums, self.R, self.N, self.G, self.S = sums, R, N, G, S
 
 
-def norm_state(gn, x=None, partial=None, n_stat=None, merge=1):
+def norm_state(gn, x=None, partial=None, n_stat=None, merge=1, group=None, S_total=None):
     """Norm state of GroupNorm module `gn` for input x [n_stat, ..., C] (token-major), from a statistics pass over x or
-    from the partial sums `partial` a producing convolution left (merge consecutive samples: per-frame -> per-video)."""
+    from the partial sums `partial` a producing convolution left (merge consecutive samples: per-frame -> per-video).
+    group / S_total: the statistics span the slices held by the ranks of `group` (frame-sharded temporal norms): the local
+    sums are all-reduced (2 G doubles per sample) before the affine is formed; S_total = global elements per channel."""
     P, LL = ctypes.c_void_p, ctypes.c_longlong
     G = gn.num_groups
     g32, b32 = ops._f32_param(gn.weight), ops._f32_param(gn.bias)
     C = g32.numel()
     if partial is not None:
-        N = partial.N // merge
-        S = partial.S * merge
-        buf = torch.empty(2 * N * G + N * C, dtype=torch.float64, device=partial.sums.device)
-        with ops._on(buf.device):
-            ops._check(ops.lib().gvd_group_norm_coef(P(buf.data_ptr()), P(partial.sums.data_ptr()), partial.R, merge,
-                                                     P(g32.data_ptr()), P(b32.data_ptr()), N, C, LL(S), G,
-                                                     ctypes.c_float(gn.eps), P(ops._stream())))
-        return NormState(buf, N, C, G, S, gn.eps, g32)
-    x = x.contiguous()
-    N = n_stat
-    S = x.numel() // (N * C)
-    buf = torch.empty(2 * N * G + N * C, dtype=torch.float64, device=x.device)
-    bf = 1 if x.dtype == torch.bfloat16 else 0
-    with ops._on(x.device):
-        ops._check(ops.lib().gvd_group_norm_stats(P(x.data_ptr()), P(buf.data_ptr()), N, C, LL(S), G, 1, bf, P(ops._stream())))
-        ops._check(ops.lib().gvd_group_norm_coef(P(buf.data_ptr()), None, 1, 1, P(g32.data_ptr()), P(b32.data_ptr()), N, C, LL(S), G,
-                                                 ctypes.c_float(gn.eps), P(ops._stream())))
-    return NormState(buf, N, C, G, S, gn.eps, g32)
+        N, S, dev = partial.N // merge, partial.S * merge, partial.sums.device
+    else:
+        x = x.contiguous()
+        N, dev = n_stat, x.device
+        S = x.numel() // (N * C)
+    buf = torch.empty(2 * N * G + N * C, dtype=torch.float64, device=dev)
+    L, eps, st = ops.lib(), ctypes.c_float(gn.eps), P(ops._stream())
+    with ops._on(dev):
+        if partial is not None:   # merge replicas / samples (and, unsharded, form the affine in the same call)
+            ops._check(L.gvd_group_norm_coef(P(buf.data_ptr()), P(partial.sums.data_ptr()), partial.R, merge, P(g32.data_ptr()),
+                                             P(b32.data_ptr()), N, C, LL(S), G, eps, st))
+        else:
+            ops._check(L.gvd_group_norm_stats(P(x.data_ptr()), P(buf.data_ptr()), N, C, LL(S), G, 1,
+                                              1 if x.dtype == torch.bfloat16 else 0, st))
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(buf[:2 * N * G], group=group)
+            S = int(S_total) if S_total is not None else ops._global_count(S, group, dev)
+        if partial is None or group is not None:
+            ops._check(L.gvd_group_norm_coef(P(buf.data_ptr()), None, 1, 1, P(g32.data_ptr()), P(b32.data_ptr()), N, C, LL(S), G, eps, st))
+    return NormState(buf, N, C, G, S, gn.eps, g32, group)
 
 
 def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, silu=False, bias=None, add_nc=None,
@@ -159,7 +167,7 @@ def _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, st
             raise RuntimeError("fused_conv: a GroupNorm prologue needs Cin % 8 == 0")
         x = F.pad(x, (0, pad))
     BN, _, _ = config(mode, N, H, W, Cin + pad, Cout)
-    wpk = packed(weight, BN, False, pad)
+    wpk = packed(weight, BN, False, pad, x.dtype)
     b32 = None if bias is None else ops._f32_param(bias)
     if ns is not None and (ns.C != Cin or ns.N != (N if mode == SPATIAL else 1)):
         raise RuntimeError(f"fused_conv: norm state is for {ns.N} x {ns.C} channels, input has {N if mode == SPATIAL else 1} x {Cin}")
@@ -193,7 +201,7 @@ class _FusedConvFn(torch.autograd.Function):
             pad = (-Cout) % 8
             g = F.pad(gout, (0, pad)) if pad else gout
             BN, _, _ = config(mode, N, H, W, Cout + pad, Cin)
-            wpk = packed(weight, BN, True, pad)
+            wpk = packed(weight, BN, True, pad, gout.dtype)
             d_act, _ = _launch(g, wpk, Cin, mode, N, H, W, Cout + pad)
             if upsample:   # nearest x2 backward: each input pixel fed a 2x2 block
                 d_act = d_act.reshape(N, H // 2, 2, W // 2, 2, Cin).sum(dim=(2, 4))
@@ -201,7 +209,8 @@ class _FusedConvFn(torch.autograd.Function):
                 gx = d_act
             else:
                 xs = x.reshape(ns.N, -1, ns.C)
-                gx = ops._hip_group_norm_bwd(xs, d_act.reshape(xs.shape), ns.gamma32, ns.buf, ns.G, ns.eps, silu, True).reshape(x.shape)
+                gx = ops._hip_group_norm_bwd(xs, d_act.reshape(xs.shape), ns.gamma32, ns.buf, ns.G, ns.eps, silu, True,
+                                             ns.group, ns.S if ns.group is not None else None).reshape(x.shape)
         return gx, (gout if has_res else None), None, None, None, None, None, None, None, None
 
 
@@ -226,7 +235,7 @@ def _reference(x, weight, bias, mode, upsample, gn, silu, add_nc, residual, n_st
 
 
 def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_stat=None, silu=False, add_nc=None,
-               residual=None, stats_groups=0):
+               residual=None, stats_groups=0, group=None, S_total=None):
     """x token-major ([N, H, W, Cin] or, temporal, [T, pixels, Cin]); `conv` the nn.Conv2d(3x3, pad 1) / nn.Conv3d((3,1,1))
     module.  gn: GroupNorm module applied (with `silu`) in the kernel's prologue; norm: a NormState for it if the caller
     already has one (from a producer's statistics), else a statistics pass over x runs first; n_stat: samples the norm
@@ -240,12 +249,12 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
             raise RuntimeError(f"fused_conv: unsupported dtype {x.dtype}")
         n_stat = n_stat if n_stat is not None else (x.shape[0] if mode == SPATIAL else 1)
         return _reference(x, conv.weight, conv.bias, mode, upsample, gn, silu, add_nc, residual, n_stat), None
-    if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+    if torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)):
         raise RuntimeError("fused_conv: only the input gradient is implemented (freeze the weights)")
     ns = None
     if gn is not None:
         n_stat = n_stat if n_stat is not None else (x.shape[0] if mode == SPATIAL else 1)
-        ns = norm if norm is not None else norm_state(gn, x=x.detach(), n_stat=n_stat)
+        ns = norm if norm is not None else norm_state(gn, x=x.detach(), n_stat=n_stat, group=group, S_total=S_total)
     need_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
     if need_grad:
         res = _FusedConvFn.apply(x, residual, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, stats_groups)

@@ -33,10 +33,9 @@ from .schedule import timestep_embedding
 
 def _fused(t, module=None):
     """The hand-written MFMA convolution path (csrc/conv_mfma.hip) applies: fp16 activations on a ROCm device, inference
-    (dropout inactive), frames not sharded over ranks.  Everything else -- fp32 parity runs, the CPU reference form, the
-    frame-sharded multi-GPU layout -- takes the module-by-module form below (torch convolutions)."""
-    return (t.is_cuda and t.dtype == torch.float16 and parallel.active() is None
-            and not (module is not None and module.training))
+    (dropout inactive).  Everything else -- fp32 parity runs, the CPU reference form -- takes the module-by-module form below
+    (torch convolutions)."""
+    return t.is_cuda and t.dtype == torch.float16 and not (module is not None and module.training)
 
 
 def zero_module(m):
@@ -311,24 +310,35 @@ class TemporalConvBlock(nn.Module):
 
     def _forward_tokens_fused(self, tok, b, stats=None):
         """Four launches of the temporal MFMA kernel per sample: GroupNorm+SiLU in the operand load, the identity add in the
-        last epilogue, and each convolution leaves the statistics its successor's norm needs (openaimodel3d.py:270-278)."""
+        last epilogue, and each convolution leaves the statistics its successor's norm needs (openaimodel3d.py:270-278).
+        Frame-sharded (parallel.py): the block works on [all T, this rank's pixels] between one all-to-all each way, and
+        the per-video norm statistics are completed across the shard group by a 2 G-double all-reduce per norm."""
         bt, hh, ww, c = tok.shape
-        T = bt // b
+        shard = parallel.active()
+        if shard is not None:
+            x_all = parallel.frames_to_pixels(tok.reshape(bt, hh * ww, c), shard)      # [T, local pixels, c]
+            group, total = shard.group, shard.T * hh * ww
+            samples = [x_all]
+        else:
+            T = bt // b
+            group = total = None
+            samples = [tok[bi * T:(bi + 1) * T].reshape(T, hh * ww, c) for bi in range(b)]
         outs = []
-        for bi in range(b):
-            x0 = tok[bi * T:(bi + 1) * T].reshape(T, hh * ww, c)
+        for x0 in samples:
             h, part = x0, (stats if b == 1 else None)
             seqs = (self.conv1, self.conv2, self.conv3, self.conv4)
             for k, seq in enumerate(seqs):
                 gn, conv = seq[0], seq[-1]
                 if part is None:
-                    ns = mconv.norm_state(gn, x=h.detach(), n_stat=1)
+                    ns = mconv.norm_state(gn, x=h.detach(), n_stat=1, group=group, S_total=total)
                 else:  # per-frame sums of a 2-D producer merge into the per-video statistics of this 5-D norm
-                    ns = mconv.norm_state(gn, partial=part, merge=part.N)
+                    ns = mconv.norm_state(gn, partial=part, merge=part.N, group=group, S_total=total)
                 last = k == len(seqs) - 1
                 h, part = mconv.fused_conv(h, conv, mode=mconv.TEMPORAL, gn=gn, norm=ns, silu=True,
                                            residual=x0 if last else None, stats_groups=0 if last else gn.num_groups)
             outs.append(h)
+        if shard is not None:
+            return parallel.pixels_to_frames(outs[0], shard, hh * ww).reshape(bt, hh, ww, c)
         out = outs[0] if b == 1 else torch.cat(outs, 0)
         return out.reshape(bt, hh, ww, c)
 

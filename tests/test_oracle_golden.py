@@ -85,3 +85,39 @@ def test_keys_sorted_and_ranges_partition(oracle):
     assert lens.sum() == st["R"]
     tiles = (k >> np.uint64(32)).astype(np.int64)
     assert np.array_equal(np.bincount(tiles, minlength=r.shape[0]), lens)
+
+
+def test_synthetic_cameras_match_reference_camera_class():
+    """synthetic.make_camera (what every raster test and bench.py feed the rasterizer) against the reference's own
+    PseudoCamera (scene/cameras.py:72-93: getWorld2View2, the non-standard getProjectionMatrix, the transposes, the
+    full_proj_transform product, camera_center), recorded by tests/golden/make_golden_camera.py."""
+    z = np.load(os.path.join(G, "raster_camera_ref.npz"))
+    c1, c2 = syn.scene_c1(), syn.scene_c2(P=16)
+    cams = [("c1_0", c1["cameras"][0])] + [(f"c2_{i}", c) for i, c in enumerate(c2["cameras"])]
+    for tag, cam in cams:
+        np.testing.assert_allclose(cam["viewmatrix"], z[f"{tag}_world_view_transform"], rtol=0, atol=1e-6, err_msg=tag)
+        np.testing.assert_allclose(cam["projmatrix"], z[f"{tag}_full_proj_transform"], rtol=0, atol=2e-6, err_msg=tag)
+        np.testing.assert_allclose(cam["campos"], z[f"{tag}_camera_center"], rtol=0, atol=2e-6, err_msg=tag)
+        P = z[f"{tag}_projection_matrix"]          # transposed non-standard projection: P^T[2,2] = P^T[2,3] = 1, no near/far terms
+        assert P[2, 2] == 1.0 and P[2, 3] == 1.0 and P[3, 3] == 0.0 and P[3, 2] == 0.0
+        assert abs(P[0, 0] - 1.0 / cam["tanfovx"]) < 1e-6 and abs(P[1, 1] - 1.0 / cam["tanfovy"]) < 1e-6
+
+
+def test_python_sh_and_python_cov_branches_end_to_end(oracle):
+    """gaussian_renderer/__init__.py:66-88: with `convert_SHs_python` / `compute_cov3D_python` the reference evaluates SH ->
+    colour and the 3-D covariance in Python and hands `colors_precomp` / `cov3D_precomp` to the operator.  Feeding the
+    REFERENCE's Python results (golden) through those operator inputs must render what the in-kernel SH / covariance path
+    renders -- the two front ends of the rasterizer pinned against each other through the reference's own formulas."""
+    z = np.load(os.path.join(G, "raster_camera_ref.npz"))
+    sc = syn.scene_c1()
+    cam = sc["cameras"][0]
+    args = (sc["means3D"], sc["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"], sc["bg"],
+            cam["image_width"], cam["image_height"], cam["tanfovx"], cam["tanfovy"])
+    for deg in (0, 3):
+        a = oracle.forward(*args, shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"], sh_degree=deg)
+        b = oracle.forward(*args, colors_precomp=np.ascontiguousarray(z[f"c1_colors_precomp_deg{deg}"], dtype=np.float32),
+                           cov3D_precomp=np.ascontiguousarray(z["c1_cov3D_precomp"], dtype=np.float32), sh_degree=deg)
+        # covariances agree to fp32 rounding, so a radius can differ by one at a ceil() boundary for a rare Gaussian
+        assert np.mean(a["radii"] != b["radii"]) < 5e-3 and np.abs(a["radii"] - b["radii"]).max() <= 1
+        for k in ("color", "depth", "alpha"):
+            np.testing.assert_allclose(b[k], a[k], rtol=0, atol=2e-5, err_msg=f"{k} deg{deg}")
