@@ -48,7 +48,9 @@ struct ConvArgs {
     void* out;
     double* stats;        // [R][Nstat][G][2] accumulators (nullptr if not wanted)
     int N, H, W, Cin, Cout;   // output geometry (temporal: N = T frames, H = 1, W = pixels per frame)
-    int ups, silu;
+    int Hin, Win;             // input geometry of the spatial modes
+    int ups, silu;            // ups: 0 none, 1 nearest x2 on the fly, 2 zero-stuffed x2 (input gradient of a stride-2 convolution)
+    int pad_lo;               // stride-2 mode: zero rows / columns in front of the image (1: U-Net Downsample, 0: VAE Downsample)
     int tiles_x, tiles_y;
     int nchunks;
     int cpg, G, R;
@@ -69,6 +71,10 @@ template <int PIX> struct Geo<1, PIX> {   // spatial, 32-pixel-wide tiles
     static constexpr int TW = 32, TH = PIX / 32, PW = TW + 2, PH = TH + 2, PITCH = PW * PIX_BYTES, NTAPS = 9;
     static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
 };
+template <int PIX> struct Geo<3, PIX> {   // spatial stride 2, 32-pixel-wide output tiles: the patch holds (2 TH + 1) x (2 TW + 1) input pixels
+    static constexpr int TW = 32, TH = PIX / 32, PW = 2 * TW + 1, PH = 2 * TH + 1, PITCH = PW * PIX_BYTES, NTAPS = 9;
+    static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
+};
 template <int PIX> struct Geo<2, PIX> {   // temporal: rows = (t, p), one zero halo frame on both sides
     static constexpr int NTAPS = 3, TW = 1, TH = 1, PW = 1, PITCH = 0;   // (spatial members: unused placeholders)
     static constexpr int PATCH_BYTES = (PIX + 2 * PB_MAX) * PIX_BYTES, NPP_MAX = (PIX + 2 * PB_MAX) * 4;
@@ -76,8 +82,20 @@ template <int PIX> struct Geo<2, PIX> {   // temporal: rows = (t, p), one zero h
 
 __device__ __forceinline__ float silu32(float f) { return f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * f)); }
 
+// dynamic LDS of one workgroup: weights + patch double buffers during the main loop, fp32 output staging + statistics scratch
+// in the epilogue (the two phases alias)
+template <int MI, int NI, int WM, int WN, int MODE>
+constexpr int lds_bytes()
+{
+    constexpr int BN = WM * MI * 32, PIX = WN * NI * 32;
+    constexpr int main_loop = 2 * BN * 64 + 2 * ((Geo<MODE, PIX>::PATCH_BYTES + 15) & ~15);
+    constexpr int ep_pix = (BN > 160) ? 32 : (BN > 32 ? 64 : PIX);
+    constexpr int epilogue = ep_pix * (BN * 4 + 16) + 2 * (256 / (BN / 8)) * BN * 4;
+    return main_loop > epilogue ? main_loop : epilogue;
+}
+
 template <typename T, int MI, int NI, int WM, int WN, int MODE>
-__global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
+__global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const ConvArgs a)   // (stride 2: one workgroup per CU, its patch fills the LDS)
 {
     typedef typename Tr<T>::vec8 vec8;
     constexpr int BN = WM * MI * 32, PIX = WN * NI * 32;
@@ -92,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
     constexpr int EP_PIX = (BN > 160) ? 32 : (BN > 32 ? 64 : PIX);
     constexpr int NOCT = BN / 8, EP_ROWS = 256 / NOCT, EP_ACTIVE = EP_ROWS * NOCT;
     static_assert(PIX % EP_PIX == 0 && EP_PIX % 32 == 0, "epilogue passes cover whole 32-pixel blocks");
-    static_assert(EP_PIX * EP_PITCH + 2 * EP_ROWS * BN * 4 <= 2 * WBYTES + 2 * PBYTES, "epilogue staging must fit the main-loop LDS");
+    // (the launcher sizes the dynamic LDS as the larger of the main-loop buffers and this epilogue staging: lds_bytes())
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const wbuf = lds;                    // [2][WBYTES]
@@ -106,8 +124,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
     const int Cin = a.Cin, Cout = a.Cout;
 
     // ---- tile origin ----
+    constexpr bool SPATIAL = MODE != 2;
     int n = 0, ty0 = 0, tx0 = 0, p0 = 0;
-    if (MODE < 2) {
+    if (SPATIAL) {
         const int per_img = a.tiles_x * a.tiles_y;
         n = blockIdx.x / per_img;
         const int rem = blockIdx.x - n * per_img;
@@ -121,21 +140,28 @@ __global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
     // ---- patch staging map (piece = 16 bytes = 8 channels of one patch pixel) ----
     const int k8 = tid & 3;   // 256 % 4 == 0: a thread always stages the same channel octet of the chunk
     int goff[PPT], loff[PPT];
-    const int Hin = a.ups ? (a.H >> 1) : a.H, Win = a.ups ? (a.W >> 1) : a.W;
+    const int Hin = a.Hin, Win = a.Win;
     int npp;
-    if (MODE < 2) npp = G_::NPP_MAX; else npp = (a.N + 2) * PB * 4;
+    if (SPATIAL) npp = G_::NPP_MAX; else npp = (a.N + 2) * PB * 4;
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
         const int q = tid + i * 256, pixel = q >> 2;
         goff[i] = -1;
         loff[i] = 0;
         if (q < npp) {
-            if (MODE < 2) {
+            if (MODE == 3) {        // stride 2: patch origin = input pixel (2 ty0 - pad, 2 tx0 - pad)
+                const int py = pixel / G_::PW, px = pixel - py * G_::PW;
+                const int gy = 2 * ty0 + py - a.pad_lo, gx = 2 * tx0 + px - a.pad_lo;
+                loff[i] = py * G_::PITCH + px * PIX_BYTES + k8 * 16;
+                if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) goff[i] = ((n * Hin + gy) * Win + gx) * Cin;
+            } else if (SPATIAL) {
                 const int py = pixel / G_::PW, px = pixel - py * G_::PW;
                 const int gy = ty0 + py - 1, gx = tx0 + px - 1;
                 loff[i] = py * G_::PITCH + px * PIX_BYTES + k8 * 16;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    goff[i] = ((n * Hin + (gy >> a.ups)) * Win + (gx >> a.ups)) * Cin;
+                const int sh = a.ups ? 1 : 0;
+                bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                if (a.ups == 2) ok = ok && !((gy | gx) & 1);   // zero-stuffed upsampling: odd rows / columns are zeros
+                if (ok) goff[i] = ((n * Hin + (gy >> sh)) * Win + (gx >> sh)) * Cin;
             } else {
                 const int tt = pixel / PB - 1, pp = pixel - (tt + 1) * PB, gp = p0 + pp;
                 loff[i] = pixel * PIX_BYTES + k8 * 16;
@@ -227,6 +253,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
         const int m = (wn * NI + ni) * 32 + r32;
         if (MODE == 0) b_off[ni] = (m >> 4) * G_::PITCH + (m & 15) * PIX_BYTES + hi * 16;
         else if (MODE == 1) b_off[ni] = (m >> 5) * G_::PITCH + (m & 31) * PIX_BYTES + hi * 16;
+        else if (MODE == 3) b_off[ni] = 2 * (m >> 5) * G_::PITCH + 2 * (m & 31) * PIX_BYTES + hi * 16;
         else b_off[ni] = m * PIX_BYTES + hi * 16;
     }
 
@@ -257,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
 
         const unsigned char* wb = wbuf + (it & 1) * WBYTES;
         int shift;
-        if (MODE < 2) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
+        if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
         else shift = tap * PB * PIX_BYTES;
         const unsigned char* pb = pbuf + (chunk & 1) * PBYTES + shift;
 #pragma unroll
@@ -297,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
         badd[j] = 0.f;
         if (ep_thread && cout0 + j < Cout) {
             if (a.bias) badd[j] = a.bias[cout0 + j];
-            if (MODE < 2 && a.add_nc) badd[j] += (float)((const T*)a.add_nc)[(size_t)n * Cout + cout0 + j];
+            if (SPATIAL && a.add_nc) badd[j] += (float)((const T*)a.add_nc)[(size_t)n * Cout + cout0 + j];
         }
     }
     float ssum[8], ssq[8];
@@ -397,7 +424,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_mfma(const ConvArgs a)
                 double s = 0.0, q = 0.0;
                 for (int c = c_lo; c < c_hi; c++) { s += (double)red[c - cb]; q += (double)red[EP_ROWS * BN + c - cb]; }
                 const int rep = blockIdx.x % a.R;
-                const int nstat = MODE < 2 ? n : 0, Nstat = MODE < 2 ? a.N : 1;
+                const int nstat = SPATIAL ? n : 0, Nstat = SPATIAL ? a.N : 1;
                 double* dst = a.stats + (((size_t)rep * Nstat + nstat) * a.G + g) * 2;
                 atomicAdd(dst, s);
                 atomicAdd(dst + 1, q);
@@ -440,8 +467,7 @@ struct Cfg { int MI, NI, WM, WN; };
 template <typename T, int MI, int NI, int WM, int WN, int MODE>
 hipError_t launch_one(const ConvArgs& a, dim3 grid, hipStream_t stream)
 {
-    constexpr int BN = WM * MI * 32, PIX = WN * NI * 32;
-    constexpr int smem = 2 * BN * 64 + 2 * ((Geo<MODE, PIX>::PATCH_BYTES + 15) & ~15);
+    constexpr int smem = lds_bytes<MI, NI, WM, WN, MODE>();
     auto kern = k_conv_mfma<T, MI, NI, WM, WN, MODE>;
     static bool attr_done[64] = {};
     int dev = 0;
@@ -463,19 +489,31 @@ hipError_t launch_cfg(int cfg, const ConvArgs& a, dim3 grid, hipStream_t stream)
     case 1: return launch_one<T, 5, 2, 2, 2, MODE>(a, grid, stream);   // 320 x 128
     case 2: return launch_one<T, 4, 2, 1, 4, MODE>(a, grid, stream);   // 128 x 256
     case 3: return launch_one<T, 1, 2, 1, 4, MODE>(a, grid, stream);   //  32 x 256
+    case 4: return launch_one<T, 2, 2, 2, 2, MODE>(a, grid, stream);   // 128 x 128
     default: return hipErrorInvalidValue;
     }
 }
 
-const int CFG_BN[4] = { 160, 320, 128, 32 };
-const int CFG_PIX[4] = { 256, 128, 256, 256 };
+template <typename T>
+hipError_t launch_stride2(int cfg, const ConvArgs& a, dim3 grid, hipStream_t stream)
+{   // the stride-2 patch is (2 TH + 1) x 65 pixels: only the 128-pixel tiles fit the LDS double buffer
+    switch (cfg) {
+    case 1: return launch_one<T, 5, 2, 2, 2, 3>(a, grid, stream);
+    case 4: return launch_one<T, 2, 2, 2, 2, 3>(a, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+const int CFG_BN[5] = { 160, 320, 128, 32, 128 };
+const int CFG_PIX[5] = { 256, 128, 256, 256, 128 };
 
 // tile configuration for a problem: cfg index, tile width class (0: 16, 1: 32) -- shared by gvd_conv_config and the launcher
 void choose(int mode, int N, int H, int W, int Cout, int* cfg, int* tw32)
 {
     const long long pixels = (long long)N * H * W;
     int c;
-    if (Cout <= 32) c = 3;
+    if (mode >= 2) c = (Cout % 160 == 0) ? 1 : 4;          // stride 2
+    else if (Cout <= 32) c = 3;
     else if (Cout % 160 == 0) c = (mode == 1 || pixels >= 40000) ? 0 : 1;
     else c = 2;
     *cfg = c;
@@ -493,47 +531,60 @@ extern "C" {
 
 int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block_n, int* tile_pixels, int* tile_width)
 {
-    if (mode < 0 || mode > 1 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(-1, "gvd_conv_config: bad arguments");
+    if (mode < 0 || mode > 3 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(-1, "gvd_conv_config: bad arguments");
     int cfg, tw32;
     choose(mode, N, H, W, Cout, &cfg, &tw32);
     if (block_n) *block_n = CFG_BN[cfg];
     if (tile_pixels) *tile_pixels = CFG_PIX[cfg];
-    if (tile_width) *tile_width = mode == 0 ? (tw32 ? 32 : 16) : 0;
+    if (tile_width) *tile_width = mode == 1 ? 0 : (tw32 ? 32 : 16);
     return 0;
 }
 
 int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
                   const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
-                  int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream_)
+                  int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || mode < 0 || mode > 1)
+    if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || mode < 0 || mode > 3)
         return fail(-1, "gvd_conv_mfma: bad arguments");
     if ((Cin & 7) || (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)residual) & 15))
         return fail(-1, "gvd_conv_mfma: Cin must be a multiple of 8 and tensors 16-byte aligned");
     if (mode == 1 && (H != 1 || upsample)) return fail(-1, "gvd_conv_mfma: temporal mode takes N = frames, H = 1, W = pixels per frame");
-    if (upsample && ((H | W) & 1)) return fail(-1, "gvd_conv_mfma: upsample needs even output dims");
+    if (upsample < 0 || upsample > 2 || (upsample && mode != 0)) return fail(-1, "gvd_conv_mfma: upsample is 0, 1 (nearest) or 2 (zero-stuffed), stride-1 spatial mode only");
     if (stats && (groups <= 0 || Cout % groups || stats_replicas <= 0)) return fail(-1, "gvd_conv_mfma: bad statistics arguments");
-    if ((long long)N * H * W * (long long)(Cin > Cout ? Cin : Cout) >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
-    if (is_bf16) return fail(-3, "gvd_conv_mfma: bf16 is not built (f16 only)");
     int cfg, tw32;
     choose(mode, N, H, W, Cout, &cfg, &tw32);
     const int BN = CFG_BN[cfg], PIX = CFG_PIX[cfg];
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.coef = reinterpret_cast<const float2*>(coef); a.bias = bias; a.add_nc = add_nc; a.res = residual;
     a.out = out; a.stats = stats;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ups = upsample ? 1 : 0; a.silu = silu ? 1 : 0;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ups = upsample; a.silu = silu ? 1 : 0;
+    if (mode >= 2) {   // stride 2: out = floor((in + pad_lo + 1 - 3) / 2) + 1 with one zero row / column behind the image
+        a.pad_lo = mode == 2 ? 1 : 0;
+        if (H_in <= 0 || W_in <= 0 || H != (H_in + a.pad_lo - 2) / 2 + 1 || W != (W_in + a.pad_lo - 2) / 2 + 1)
+            return fail(-1, "gvd_conv_mfma: stride-2 modes need H_in, W_in with H = (H_in + pad_lo - 2) / 2 + 1");
+        a.Hin = H_in; a.Win = W_in;
+    } else if (upsample) {
+        if ((H | W) & 1) return fail(-1, "gvd_conv_mfma: upsample needs even output dims");
+        a.Hin = H >> 1; a.Win = W >> 1;
+    } else {
+        a.Hin = H; a.Win = W;
+    }
+    const long long in_elems = (long long)N * a.Hin * a.Win * Cin, out_elems = (long long)N * H * W * Cout;
+    if (in_elems >= (1LL << 31) || out_elems >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
+    if (is_bf16) return fail(-3, "gvd_conv_mfma: bf16 is not built (f16 only)");
     a.nchunks = (Cin + BK - 1) / BK;
     a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
     a.coef_per_n = coef_per_n;
     dim3 grid;
     grid.y = (Cout + BN - 1) / BN;
     hipError_t e;
-    if (mode == 0) {
-        const int tw = tw32 ? 32 : 16, th = PIX / tw;
+    if (mode != 1) {
+        const int tw = (mode >= 2 || tw32) ? 32 : 16, th = PIX / tw;
         a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
         grid.x = (unsigned)(a.tiles_x * a.tiles_y * N);
-        e = tw32 ? launch_cfg<_Float16, 1>(cfg, a, grid, stream) : launch_cfg<_Float16, 0>(cfg, a, grid, stream);
+        if (mode >= 2) e = launch_stride2<_Float16>(cfg, a, grid, stream);
+        else e = tw32 ? launch_cfg<_Float16, 1>(cfg, a, grid, stream) : launch_cfg<_Float16, 0>(cfg, a, grid, stream);
     } else {
         int pb = PIX / N;
         if (pb < 1) return fail(-1, "gvd_conv_mfma: too many frames for one tile");

@@ -17,7 +17,8 @@ import torch.nn.functional as F
 
 from . import ops
 
-SPATIAL, TEMPORAL = 0, 1
+SPATIAL, TEMPORAL, STRIDE2, STRIDE2_PAD_HI = 0, 1, 2, 3   # C-ABI `mode` values (include/gvd_diffusion.h)
+NEAREST, ZERO_STUFF = 1, 2                               # C-ABI `upsample` values
 STATS_REPLICAS = 8
 
 
@@ -128,12 +129,12 @@ def norm_state(gn, x=None, partial=None, n_stat=None, merge=1, group=None, S_tot
 
 
 def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, silu=False, bias=None, add_nc=None,
-            residual=None, stats_groups=0, upsample=False):
+            residual=None, stats_groups=0, upsample=0, H_in=0, W_in=0):
     P = ctypes.c_void_p
-    out = torch.empty((N, H, W, Cout) if mode == SPATIAL else (N, W, Cout), dtype=x.dtype, device=x.device)
+    out = torch.empty((N, W, Cout) if mode == TEMPORAL else (N, H, W, Cout), dtype=x.dtype, device=x.device)
     sums = None
     if stats_groups:
-        n_stat = N if mode == SPATIAL else 1
+        n_stat = 1 if mode == TEMPORAL else N
         sums = torch.zeros(STATS_REPLICAS, n_stat, stats_groups, 2, dtype=torch.float64, device=x.device)
     with ops._on(x.device):
         rc = ops.lib().gvd_conv_mfma(P(x.data_ptr()), P(wpk.data_ptr()), P(coef_ptr), coef_per_n,
@@ -141,25 +142,29 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
                                      P(add_nc.data_ptr() if add_nc is not None else None),
                                      P(residual.data_ptr() if residual is not None else None), P(out.data_ptr()),
                                      P(sums.data_ptr() if sums is not None else None), STATS_REPLICAS, stats_groups, mode,
-                                     N, H, W, Cin, Cout, int(bool(upsample)), int(bool(silu)),
+                                     N, H, W, H_in, W_in, Cin, Cout, int(upsample), int(bool(silu)),
                                      1 if x.dtype == torch.bfloat16 else 0, P(ops._stream()))
     ops._check(rc)
     if sums is not None:
-        S = H * W if mode == SPATIAL else N * W
+        S = N * W if mode == TEMPORAL else H * W
         return out, PartialStats(sums, STATS_REPLICAS, sums.shape[1], stats_groups, S)
     return out, None
 
 
 def _geometry(x, mode, upsample):
+    """(N, H, W, Cin, H_in, W_in): output geometry of the convolution of x, and the input's for the stride-2 modes."""
+    if mode == TEMPORAL:
+        T, Pp, Cin = x.shape
+        return T, 1, Pp, Cin, 0, 0
+    N, Hin, Win, Cin = x.shape
     if mode == SPATIAL:
-        N, Hin, Win, Cin = x.shape
-        return N, (2 * Hin if upsample else Hin), (2 * Win if upsample else Win), Cin
-    T, Pp, Cin = x.shape
-    return T, 1, Pp, Cin
+        return N, (2 * Hin if upsample else Hin), (2 * Win if upsample else Win), Cin, 0, 0
+    pad_lo = 1 if mode == STRIDE2 else 0
+    return N, (Hin + pad_lo - 2) // 2 + 1, (Win + pad_lo - 2) // 2 + 1, Cin, Hin, Win
 
 
 def _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, stats_groups):
-    N, H, W, Cin = _geometry(x, mode, upsample)
+    N, H, W, Cin, H_in, W_in = _geometry(x, mode, upsample)
     Cout = weight.shape[0]
     pad = (-Cin) % 8
     if pad:
@@ -169,12 +174,14 @@ def _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, st
     BN, _, _ = config(mode, N, H, W, Cin + pad, Cout)
     wpk = packed(weight, BN, False, pad, x.dtype)
     b32 = None if bias is None else ops._f32_param(bias)
-    if ns is not None and (ns.C != Cin or ns.N != (N if mode == SPATIAL else 1)):
-        raise RuntimeError(f"fused_conv: norm state is for {ns.N} x {ns.C} channels, input has {N if mode == SPATIAL else 1} x {Cin}")
+    n_norm = 1 if mode == TEMPORAL else N
+    if ns is not None and (ns.C != Cin or ns.N != n_norm):
+        raise RuntimeError(f"fused_conv: norm state is for {ns.N} x {ns.C} channels, input has {n_norm} x {Cin}")
     return _launch(x.contiguous(), wpk, Cout, mode, N, H, W, Cin + pad,
-                   coef_ptr=None if ns is None else ns.coef_ptr, coef_per_n=1 if mode == SPATIAL else 0,
+                   coef_ptr=None if ns is None else ns.coef_ptr, coef_per_n=0 if mode == TEMPORAL else 1,
                    silu=silu, bias=b32, add_nc=None if add_nc is None else add_nc.contiguous(),
-                   residual=None if residual is None else residual.contiguous(), stats_groups=stats_groups, upsample=upsample)
+                   residual=None if residual is None else residual.contiguous(), stats_groups=stats_groups,
+                   upsample=NEAREST if upsample else 0, H_in=H_in, W_in=W_in)
 
 
 class _FusedConvFn(torch.autograd.Function):
@@ -196,13 +203,22 @@ class _FusedConvFn(torch.autograd.Function):
         gout = gout.contiguous()
         gx = None
         if ctx.needs_input_grad[0]:
-            N, H, W, Cin = _geometry(x, mode, upsample)
+            N, H, W, Cin, H_in, W_in = _geometry(x, mode, upsample)
             Cout = weight.shape[0]
             pad = (-Cout) % 8
             g = F.pad(gout, (0, pad)) if pad else gout
-            BN, _, _ = config(mode, N, H, W, Cout + pad, Cin)
-            wpk = packed(weight, BN, True, pad, gout.dtype)
-            d_act, _ = _launch(g, wpk, Cin, mode, N, H, W, Cout + pad)
+            if mode == STRIDE2_PAD_HI:
+                raise NotImplementedError("fused_conv: the input gradient of the VAE-encoder Downsample is not on the guided path")
+            if mode == STRIDE2:
+                # transposed convolution = stride-1 convolution (transposed, tap-flipped weights) of the zero-stuffed gradient
+                BN, _, _ = config(SPATIAL, N, 2 * H, 2 * W, Cout + pad, Cin)
+                d_act, _ = _launch(g, packed(weight, BN, True, pad, gout.dtype), Cin, SPATIAL, N, 2 * H, 2 * W, Cout + pad,
+                                   upsample=ZERO_STUFF)
+                if (2 * H, 2 * W) != (H_in, W_in):
+                    d_act = d_act[:, :H_in, :W_in].contiguous()
+            else:
+                BN, _, _ = config(mode, N, H, W, Cout + pad, Cin)
+                d_act, _ = _launch(g, packed(weight, BN, True, pad, gout.dtype), Cin, mode, N, H, W, Cout + pad)
             if upsample:   # nearest x2 backward: each input pixel fed a 2x2 block
                 d_act = d_act.reshape(N, H // 2, 2, W // 2, 2, Cin).sum(dim=(2, 4))
             if ns is None:
@@ -219,11 +235,14 @@ def _reference(x, weight, bias, mode, upsample, gn, silu, add_nc, residual, n_st
     if gn is not None:
         xs = x.reshape(n_stat, -1, x.shape[-1])
         x = ops.group_norm_math(xs, gn.num_groups, gn.weight, gn.bias, gn.eps, silu=silu, channels_last=True).reshape(x.shape)
-    if mode == SPATIAL:
+    if mode != TEMPORAL:
         xi = x.permute(0, 3, 1, 2)
         if upsample:
             xi = F.interpolate(xi, scale_factor=2, mode="nearest")
-        y = F.conv2d(xi, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), padding=1).permute(0, 2, 3, 1)
+        if mode == STRIDE2_PAD_HI:
+            xi = F.pad(xi, (0, 1, 0, 1))
+        y = F.conv2d(xi, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), stride=1 if mode == SPATIAL else 2,
+                     padding=0 if mode == STRIDE2_PAD_HI else 1).permute(0, 2, 3, 1)
         if add_nc is not None:
             y = y + add_nc.to(y.dtype)[:, None, None, :]
     else:
@@ -237,7 +256,8 @@ def _reference(x, weight, bias, mode, upsample, gn, silu, add_nc, residual, n_st
 def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_stat=None, silu=False, add_nc=None,
                residual=None, stats_groups=0, group=None, S_total=None):
     """x token-major ([N, H, W, Cin] or, temporal, [T, pixels, Cin]); `conv` the nn.Conv2d(3x3, pad 1) / nn.Conv3d((3,1,1))
-    module.  gn: GroupNorm module applied (with `silu`) in the kernel's prologue; norm: a NormState for it if the caller
+    module; mode STRIDE2 / STRIDE2_PAD_HI: the stride-2 Downsample convolutions of the U-Net / the VAE encoder.
+    gn: GroupNorm module applied (with `silu`) in the kernel's prologue; norm: a NormState for it if the caller
     already has one (from a producer's statistics), else a statistics pass over x runs first; n_stat: samples the norm
     statistics span separately (frames for 2-D norms, 1 for the temporal ones).
     Returns (out, PartialStats | None): the statistics of `out` for a following GroupNorm with `stats_groups` groups."""
@@ -247,13 +267,13 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
             raise RuntimeError("fused_conv: the MFMA convolution is built for fp16 activations")
         if on_dev and not ops._REFERENCE_MATH and x.dtype != torch.float32:
             raise RuntimeError(f"fused_conv: unsupported dtype {x.dtype}")
-        n_stat = n_stat if n_stat is not None else (x.shape[0] if mode == SPATIAL else 1)
+        n_stat = n_stat if n_stat is not None else (1 if mode == TEMPORAL else x.shape[0])
         return _reference(x, conv.weight, conv.bias, mode, upsample, gn, silu, add_nc, residual, n_stat), None
     if torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)):
         raise RuntimeError("fused_conv: only the input gradient is implemented (freeze the weights)")
     ns = None
     if gn is not None:
-        n_stat = n_stat if n_stat is not None else (x.shape[0] if mode == SPATIAL else 1)
+        n_stat = n_stat if n_stat is not None else (1 if mode == TEMPORAL else x.shape[0])
         ns = norm if norm is not None else norm_state(gn, x=x.detach(), n_stat=n_stat, group=group, S_total=S_total)
     need_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
     if need_grad:
@@ -262,7 +282,7 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
         part = None
         if stats_groups:
             N = x.shape[0]
-            S = out.shape[1] * out.shape[2] if mode == SPATIAL else out.shape[0] * out.shape[1]
+            S = out.shape[0] * out.shape[1] if mode == TEMPORAL else out.shape[1] * out.shape[2]
             part = PartialStats(res[1], STATS_REPLICAS, res[1].shape[1], stats_groups, S)
         return out, part
     return _run_forward(x, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, residual, stats_groups)

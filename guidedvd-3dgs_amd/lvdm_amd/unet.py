@@ -424,6 +424,8 @@ class Downsample(nn.Module):
         self.op = nn.Conv2d(channels, out_channels or channels, 3, stride=2, padding=1)
 
     def forward(self, x):
+        if _fused(x, self):   # stride-2 form of the MFMA convolution (forward) / zero-stuffed form (input gradient)
+            return _img(mconv.fused_conv(_tok(x), self.op, mode=mconv.STRIDE2)[0])
         return self.op(x)
 
 

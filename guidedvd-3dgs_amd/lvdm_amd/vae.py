@@ -179,6 +179,8 @@ class Downsample(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
 
     def forward(self, x):
+        if _fused(x, self) and not (torch.is_grad_enabled() and x.requires_grad):
+            return _img(mconv.fused_conv(_tok(x), self.conv, mode=mconv.STRIDE2_PAD_HI)[0])
         return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
 
 
@@ -215,7 +217,24 @@ class Encoder(nn.Module):
         self.norm_out = _norm(block_in)
         self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
 
+    def _forward_fused(self, x):
+        """Token-major encoder on the MFMA convolutions (conv-in pads its 3 input channels to 8; stride-2 Downsample mode)."""
+        t, st = mconv.fused_conv(_tok(x), self.conv_in, stats_groups=32)
+        for i_level in range(self.num_resolutions):
+            blocks = self.down[i_level].block
+            for k, blk in enumerate(blocks):
+                t, st = blk.forward_tokens(t, st, want_stats=not (k == len(blocks) - 1 and i_level != self.num_resolutions - 1))
+            if i_level != self.num_resolutions - 1:
+                t, st = mconv.fused_conv(t, self.down[i_level].downsample.conv, mode=mconv.STRIDE2_PAD_HI, stats_groups=32)
+        t, _ = self.mid.block_1.forward_tokens(t, st)
+        t = self.mid.attn_1.forward_tokens(t)
+        t, st = self.mid.block_2.forward_tokens(t, None, want_stats=True)
+        ns = mconv.norm_state(self.norm_out, partial=st)
+        return _img(mconv.fused_conv(t, self.conv_out, gn=self.norm_out, norm=ns, silu=True)[0])
+
     def forward(self, x):
+        if _fused(x, self) and not (torch.is_grad_enabled() and x.requires_grad):
+            return self._forward_fused(x)
         h = self.conv_in(x)
         for i_level in range(self.num_resolutions):
             for blk in self.down[i_level].block:

@@ -114,9 +114,14 @@ int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, i
  *
  *   out = conv(act(x)) + bias + add_nc[n] + residual,   act(v) = silu?(a[n,c] v + b[n,c])  (zero padding after act)
  *
- * mode 0 (spatial 3x3, stride 1, pad 1):  x [N][H_in][W_in][Cin], out [N][H][W][Cout] (16-bit, token-major).
- *        upsample = 1: H_in = H/2, W_in = W/2 and the input is nearest-upsampled x2 on the fly.
+ * mode 0 (spatial 3x3, stride 1, pad 1):  x [N][H_in][W_in][Cin], out [N][H][W][Cout] (16-bit, token-major); H_in, W_in are
+ *        derived (pass 0).  upsample = 1: H_in = H/2, W_in = W/2 and the input is nearest-upsampled x2 on the fly (Upsample,
+ *        openaimodel3d.py:80-106); upsample = 2: the input is ZERO-STUFFED x2 (odd rows / columns are zero) -- with the
+ *        transposed, tap-flipped weights this is the input gradient of a stride-2 convolution.
  * mode 1 (temporal 3 taps, pad 1 in t):   x [T = N][W = pixels][Cin], out [T][pixels][Cout]; H must be 1; batch 1.
+ * mode 2 (spatial 3x3, stride 2, pad 1: U-Net Downsample, openaimodel3d.py:51-77) and
+ * mode 3 (spatial 3x3, stride 2 on an input padded by one zero row / column at the bottom / right only: VAE Downsample,
+ *        ae_modules.py:90-109):  x [N][H_in][W_in][Cin] with H = (H_in + pad_lo - 2) / 2 + 1 (pad_lo = 1 / 0), same for W.
  * w_packed: weights in the layout gvd_conv_config describes:  [ceil(Cout/BN)][ceil(Cin/32)][taps][BN][4][8] 16-bit,
  *        element (co_tile, chunk, tap, r, s, j) = W[co_tile*BN + r][chunk*32 + (s ^ ((r >> 2) & 3))*8 + j][tap]
  *        (zero outside Cout x Cin; tap = ky*3 + kx, or kt).  The input gradient of the same convolution is this entry
@@ -131,7 +136,7 @@ int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, i
  * Cin % 8 == 0.  Returns -3 for bf16 (not built). */
 int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
                   const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
-                  int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream);
+                  int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream);
 
 /* Tile configuration gvd_conv_mfma uses for a problem: BN = output channels per workgroup (the packing granule of
  * w_packed), pixels per workgroup tile, tile width (16 | 32; 0 in mode 1). */

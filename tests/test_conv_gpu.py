@@ -149,6 +149,38 @@ def test_temporal_conv_matches_conv3d(T, Pp, Cc):
     assert torch.allclose(sums, want, rtol=2e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("N,Hin,Win,Cin,Cout,mode", [(3, 72, 128, 320, 320, "unet"), (2, 18, 32, 1280, 1280, "unet"), (2, 9, 15, 64, 640, "unet"),
+                                                     (1, 64, 96, 128, 128, "vae"), (1, 33, 47, 256, 256, "vae"), (2, 40, 56, 320, 320, "unet")])
+def test_stride2_downsample_convolutions(N, Hin, Win, Cin, Cout, mode):
+    """U-Net Downsample (3x3, stride 2, pad 1: openaimodel3d.py:51-77) and VAE-encoder Downsample (pad (0,1,0,1), stride 2:
+    ae_modules.py:90-109), forward; and for the U-Net form the input gradient (zero-stuffed stride-1 form)."""
+    from lvdm_amd import conv as C
+    g = torch.Generator(device=DEV).manual_seed(Hin * Win + Cin)
+    x = torch.randn(N, Hin, Win, Cin, device=DEV, generator=g).half().requires_grad_(mode == "unet")
+    m = _conv_module(Cin, Cout, 13)
+    y, _ = C.fused_conv(x, m, mode=C.STRIDE2 if mode == "unet" else C.STRIDE2_PAD_HI)
+    xf = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    torch.backends.cudnn.enabled = False
+    try:
+        if mode == "unet":
+            ref = F.conv2d(xf, m.weight.float(), m.bias.float(), stride=2, padding=1)
+        else:
+            ref = F.conv2d(F.pad(xf, (0, 1, 0, 1)), m.weight.float(), m.bias.float(), stride=2)
+    finally:
+        torch.backends.cudnn.enabled = True
+    assert y.shape == tuple(ref.permute(0, 2, 3, 1).shape)
+    assert _rel(y, ref.permute(0, 2, 3, 1)) < 2e-3, _rel(y, ref.permute(0, 2, 3, 1))
+    if mode == "unet":
+        gy = torch.randn(y.shape, device=DEV, generator=g).half()
+        (gx,) = torch.autograd.grad(y, [x], gy)
+        torch.backends.cudnn.enabled = False
+        try:
+            (gr,) = torch.autograd.grad(ref, [xf], gy.float().permute(0, 3, 1, 2))
+        finally:
+            torch.backends.cudnn.enabled = True
+        assert _rel(gx, gr.permute(0, 2, 3, 1)) < 3e-3, _rel(gx, gr.permute(0, 2, 3, 1))
+
+
 def test_conv_input_gradients_match_autograd_of_the_fp32_form():
     from lvdm_amd import conv as C
     g = torch.Generator(device=DEV).manual_seed(99)
