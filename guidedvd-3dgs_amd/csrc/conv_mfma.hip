@@ -25,6 +25,8 @@
 //     every lane 4 consecutive output channels of ONE pixel per register quad.
 //   * Patch pixel rows are 80 bytes (64 + 16 pad) so that 32 consecutive pixels at one k-slot hit distinct bank groups;
 //     TW = 16 tiles pad the patch row pitch to a multiple of 256 B for the same reason.
+//   * All staging loads are unconditional (dummy address + select): a predicated load makes hipcc serialise the stage's loads
+//     behind vmcnt(0) waits; removing the predicates took the L0-L2 shapes from 700-820 to 790-985 TFLOP/s.
 //   * Pipeline: one barrier per (chunk, tap).  Weights of step i+1 and (late in a chunk) the next chunk's patch are
 //     fetched into registers before the MFMAs of step i and written to the other LDS buffer after them.  Two workgroups
 //     per CU (<= 80 KiB LDS, <= 256 VGPRs) de-synchronise and cover each other's staging.
@@ -32,6 +34,8 @@
 //     embedding add (ResBlock `h + emb_out`), the residual and the 16-bit rounding are fused, and the GroupNorm statistics
 //     the NEXT norm needs (sum / sum of squares per (sample, group) of the ROUNDED outputs) are reduced in-block and added
 //     to fp64 accumulators -- the separate statistics pass over the activation disappears.
+#include <stdlib.h>
+
 #include "diffusion_common.h"
 
 using namespace gvdd;
@@ -179,11 +183,15 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     vec8 preg[PH0];
     float2 cf[8];
     bool chan_ok = false;
+    // NOTE on the staging loads: every global load below is UNCONDITIONAL (out-of-image / out-of-range pieces read a valid
+    // dummy address and are zeroed or dropped at store time).  A per-piece `cond ? load : 0` makes hipcc branch around each
+    // load and wait vmcnt(0) in between -- the loads of a stage then complete one L2 round trip after the other instead of
+    // all being in flight together (measured: the first version of this kernel).
     auto load_cf = [&](int chunk) {
         const int c0 = chunk * BK + k8 * 8;
         chan_ok = c0 < Cin;
-        if (coef && chan_ok) {
-            const float4* cp = reinterpret_cast<const float4*>(coef + c0);
+        if (coef) {   // wave-uniform (kernel argument)
+            const float4* cp = reinterpret_cast<const float4*>(coef + (chan_ok ? c0 : 0));
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float4 v = cp[j];
@@ -195,9 +203,10 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     auto load_p = [&](int chunk, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
         const int c0 = chunk * BK + k8 * 8;
+        const int c0s = c0 < Cin ? c0 : 0;
 #pragma unroll
         for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++)
-            preg[i - HALF * PH0] = (goff[i] >= 0 && c0 < Cin) ? *reinterpret_cast<const vec8*>(x + (size_t)goff[i] + c0) : vec8{};
+            preg[i - HALF * PH0] = *reinterpret_cast<const vec8*>(x + (size_t)(goff[i] >= 0 ? goff[i] : 0) + c0s);
     };
     auto store_p = [&](int buf, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
@@ -206,18 +215,16 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++) {
             if (loff[i] < 0) continue;
             vec8 v = preg[i - HALF * PH0];
+            const bool ok = goff[i] >= 0 && chan_ok;
             if (coef) {
-                if (goff[i] >= 0 && chan_ok) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        float f = fmaf((float)v[j], cf[j].x, cf[j].y);
-                        if (a.silu) f = silu32(f);
-                        v[j] = (T)f;
-                    }
-                } else {
-                    v = vec8{};   // conv zero padding applies to the ACTIVATED tensor
+                for (int j = 0; j < 8; j++) {
+                    float f = fmaf((float)v[j], cf[j].x, cf[j].y);
+                    if (a.silu) f = silu32(f);
+                    v[j] = (T)f;
                 }
             }
+            if (!ok) v = vec8{};   // conv zero padding applies to the ACTIVATED tensor (and dummy reads are dropped here)
             *reinterpret_cast<vec8*>(pb + loff[i]) = v;
         }
     };
@@ -232,7 +239,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int q = tid + i * 256;
-            if (q < NWP) wreg[i] = *reinterpret_cast<const vec8*>(src + q * 8);
+            wreg[i] = *reinterpret_cast<const vec8*>(src + (q < NWP ? q : NWP - 1) * 8);   // unconditional (see the note above)
         }
     };
     auto store_w = [&](int buf) {
@@ -242,7 +249,6 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
             if (q < NWP) *reinterpret_cast<vec8*>(wbuf + buf * WBYTES + q * 16) = wreg[i];
         }
     };
-
     // ---- MFMA operand addresses ----
     int a_off[2];
 #pragma unroll
@@ -433,17 +439,21 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     }
 }
 
-// stats[nout][g][0..1] = sum over replicas r and merged samples m of partial[r][nout*merge + m][g][0..1]
+// stats[nout][g][0..1] = sum over replicas r and merged samples m of partial[r][nout*merge + m][g][0..1]; one wave per output
 __global__ void __launch_bounds__(256) k_gn_merge(const double* __restrict__ partial, double* __restrict__ stats, int R, int Nin,
                                                   int merge, int G, int total)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= total) return;
     const int k = i & 1, g = (i >> 1) % G, nout = (i >> 1) / G;
     double s = 0.0;
-    for (int r = 0; r < R; r++)
-        for (int m = 0; m < merge; m++) s += partial[(((size_t)r * Nin + (size_t)nout * merge + m) * G + g) * 2 + k];
-    stats[i] = s;
+    for (int j = lane; j < R * merge; j += 64) {
+        const int r = j / merge, m = j - r * merge;
+        s += partial[(((size_t)r * Nin + (size_t)nout * merge + m) * G + g) * 2 + k];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) stats[i] = s;
 }
 
 __global__ void __launch_bounds__(256) k_gn_coef2(const double* __restrict__ stats, const float* __restrict__ gamma,
@@ -462,7 +472,8 @@ __global__ void __launch_bounds__(256) k_gn_coef2(const double* __restrict__ sta
     coef[i] = make_float2(a, beta[c] - (float)mean * a);
 }
 
-struct Cfg { int MI, NI, WM, WN; };
+// (Measured alternative, not kept: staging the weight slabs with LDS-DMA (global_load_lds) instead of through registers was
+//  within +-3 % on every U-Net / VAE shape -- two workgroups per CU already cover the ds_write pass.)
 
 template <typename T, int MI, int NI, int WM, int WN, int MODE>
 hipError_t launch_one(const ConvArgs& a, dim3 grid, hipStream_t stream)
@@ -606,7 +617,7 @@ int gvd_group_norm_coef(double* stats, const double* partial, int replicas, int 
     if (partial) {
         if (replicas <= 0 || merge <= 0) return fail(-1, "gvd_group_norm_coef: bad replica / merge counts");
         const int total = N * G * 2;
-        hipLaunchKernelGGL(k_gn_merge, dim3((total + 255) / 256), dim3(256), 0, stream, partial, stats, replicas, N * merge, merge, G, total);
+        hipLaunchKernelGGL(k_gn_merge, dim3((total + 3) / 4), dim3(256), 0, stream, partial, stats, replicas, N * merge, merge, G, total);
     }
     float2* coef = reinterpret_cast<float2*>(stats + (size_t)N * G * 2);
     hipLaunchKernelGGL(k_gn_coef2, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const double*)stats, gamma, beta, coef, N, C, G, S_total, eps);
