@@ -335,8 +335,10 @@ __global__ void __launch_bounds__(256) k_ddim_apply(const float* __restrict__ x,
 }
 
 
-// number of channel octets a 256-thread block walks in parallel in the NSC statistics kernel
-__device__ __host__ __forceinline__ int oct_stride(int oct) { return oct < 256 ? (oct < 32 ? 32 : (oct <= 64 ? 64 : (oct <= 128 ? 128 : 256))) : 256; }
+// NSC (token-major) kernels: a 256-thread block covers W = min(octets, 256) channel octets x R = 256 / W rows at a time;
+// thread t owns octet t % W (+ k W) and rows t / W, t / W + R, ...; the 256 - R W left-over threads idle (< W of them: 6 % for
+// C = 320, none for power-of-two channel counts) -- the earlier power-of-two lane map left 37 % (C = 320) to 50 % (C = 128) idle.
+__device__ __host__ __forceinline__ int oct_width(int oct) { return oct < 256 ? oct : 256; }
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm (+ optional SiLU), 16-bit activations, fp32 statistics (lvdm/basics.py:76-86 semantics).
@@ -439,11 +441,11 @@ __global__ void __launch_bounds__(256) k_gn_stats_nsc(const T* __restrict__ x, d
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
     const T* base = x + (long long)n * S * C;
-    for (int o = threadIdx.x % oct_stride(oct), lane_row = threadIdx.x / oct_stride(oct); o < oct; o += oct_stride(oct)) {
+    const int Wd = oct_width(oct), rstep = 256 / Wd, lane_row = threadIdx.x / Wd;
+    for (int o = threadIdx.x % Wd; o < oct && lane_row < rstep; o += Wd) {
         float s[8], q[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) { s[k] = 0.f; q[k] = 0.f; }
-        const int rstep = 256 / oct_stride(oct);
 #pragma unroll 4
         for (long long r = r0 + lane_row; r < r1; r += rstep) {
             const vec8 v = *reinterpret_cast<const vec8*>(base + r * C + o * 8);
@@ -461,27 +463,36 @@ __global__ void __launch_bounds__(256) k_gn_stats_nsc(const T* __restrict__ x, d
     for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[(long long)n * 2 * G + i], (double)sh_g[i]);
 }
 
+// NSC apply: same lane map as the statistics kernel -- a thread keeps the (a, b) pairs of its channel octet in registers and
+// streams down its rows (the earlier flat-index version re-read 64 B of coefficients per 16 B of data and paid a 64-bit division
+// per vector).
 template <typename T>
 __global__ void __launch_bounds__(256) k_gn_apply_nsc(const T* __restrict__ x, T* __restrict__ y, const float2* __restrict__ coef,
-                                                      int C, long long S, int silu, long long total)
+                                                      int C, long long S, int silu, int rows_per_block)
 {
     typedef typename Tr<T>::vec8 vec8;
-    const long long step = (long long)gridDim.x * 256 * 8;
-    const long long SC = S * C;
-    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < total; i += step) {
-        const long long n = i / SC;
-        const int c0 = (int)((i - n * SC) % C);
-        const float4* cf = reinterpret_cast<const float4*>(coef + n * C + c0);   // 8 (a, b) pairs, 64 B, L1/L2 resident
-        vec8 v = *reinterpret_cast<const vec8*>(x + i);
+    const int n = blockIdx.y, oct = C / 8;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
+    const T* bx = x + (long long)n * S * C;
+    T* by = y + (long long)n * S * C;
+    const int Wd = oct_width(oct), rstep = 256 / Wd, lane_row = threadIdx.x / Wd;
+    for (int o = threadIdx.x % Wd; o < oct && lane_row < rstep; o += Wd) {
+        float a[8], b[8];
+        const float4* cf = reinterpret_cast<const float4*>(coef + (long long)n * C + o * 8);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float4 ab = cf[k];
-            float f0 = fmaf(to_f(v[2 * k]), ab.x, ab.y), f1 = fmaf(to_f(v[2 * k + 1]), ab.z, ab.w);
-            if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
-            v[2 * k] = (T)f0;
-            v[2 * k + 1] = (T)f1;
+        for (int k = 0; k < 4; k++) { const float4 ab = cf[k]; a[2 * k] = ab.x; b[2 * k] = ab.y; a[2 * k + 1] = ab.z; b[2 * k + 1] = ab.w; }
+#pragma unroll 4
+        for (long long r = r0 + lane_row; r < r1; r += rstep) {
+            vec8 v = *reinterpret_cast<const vec8*>(bx + r * C + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float f = fmaf(to_f(v[k]), a[k], b[k]);
+                if (silu) f = silu_f(f);
+                v[k] = (T)f;
+            }
+            *reinterpret_cast<vec8*>(by + r * C + o * 8) = v;
         }
-        *reinterpret_cast<vec8*>(y + i) = v;
     }
 }
 
@@ -561,11 +572,12 @@ __global__ void __launch_bounds__(256) k_gn_bwd_stats_nsc(const T* __restrict__ 
     const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
     const T* bx = x + (long long)n * S * C;
     const T* bg = dy + (long long)n * S * C;
-    for (int o = threadIdx.x % oct_stride(oct), lane_row = threadIdx.x / oct_stride(oct); o < oct; o += oct_stride(oct)) {
+    const int Wd = oct_width(oct), rstep = 256 / Wd, lane_row = threadIdx.x / Wd;
+    for (int o = threadIdx.x % Wd; o < oct && lane_row < rstep; o += Wd) {
         float a[8], b[8], s1[8], s2[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) { const float2 ab = coef[(long long)n * C + o * 8 + k]; a[k] = ab.x; b[k] = ab.y; s1[k] = 0.f; s2[k] = 0.f; }
-        const int rstep = 256 / oct_stride(oct);
+#pragma unroll 2
         for (long long r = r0 + lane_row; r < r1; r += rstep) {
             const vec8 vx = *reinterpret_cast<const vec8*>(bx + r * C + o * 8), vg = *reinterpret_cast<const vec8*>(bg + r * C + o * 8);
 #pragma unroll
@@ -638,28 +650,38 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply_ncs(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) k_gn_bwd_apply_nsc(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                           const float2* __restrict__ coef, const float2* __restrict__ coef2,
-                                                          int C, long long S, int silu, long long total)
+                                                          int C, long long S, int silu, int rows_per_block)
 {
     typedef typename Tr<T>::vec8 vec8;
-    const long long step = (long long)gridDim.x * 256 * 8;
-    const long long SC = S * C;
-    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < total; i += step) {
-        const long long n = i / SC;
-        const int c0 = (int)((i - n * SC) % C);
-        const float4* cf = reinterpret_cast<const float4*>(coef + n * C + c0);
-        const float4* kf = reinterpret_cast<const float4*>(coef2 + n * C + c0);
-        const vec8 vx = *reinterpret_cast<const vec8*>(x + i), vg = *reinterpret_cast<const vec8*>(dy + i);
-        vec8 r;
+    const int n = blockIdx.y, oct = C / 8;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
+    const long long base = (long long)n * S * C;
+    const int Wd = oct_width(oct), rstep = 256 / Wd, lane_row = threadIdx.x / Wd;
+    for (int o = threadIdx.x % Wd; o < oct && lane_row < rstep; o += Wd) {
+        float a[8], b[8], k0[8], k1[8];   // per-channel constants of this thread's octet, loaded once
+        const float4* cf = reinterpret_cast<const float4*>(coef + (long long)n * C + o * 8);
+        const float4* kf = reinterpret_cast<const float4*>(coef2 + (long long)n * C + o * 8);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const float4 ab = cf[k], kk = kf[k];
-            const float x0 = to_f(vx[2 * k]), x1 = to_f(vx[2 * k + 1]);
-            float d0 = to_f(vg[2 * k]), d1 = to_f(vg[2 * k + 1]);
-            if (silu) { d0 *= silu_grad_f(fmaf(x0, ab.x, ab.y)); d1 *= silu_grad_f(fmaf(x1, ab.z, ab.w)); }
-            r[2 * k] = (T)fmaf(ab.x, d0, fmaf(kk.y, x0, kk.x));
-            r[2 * k + 1] = (T)fmaf(ab.z, d1, fmaf(kk.w, x1, kk.z));
+            a[2 * k] = ab.x; b[2 * k] = ab.y; a[2 * k + 1] = ab.z; b[2 * k + 1] = ab.w;
+            k0[2 * k] = kk.x; k1[2 * k] = kk.y; k0[2 * k + 1] = kk.z; k1[2 * k + 1] = kk.w;
         }
-        *reinterpret_cast<vec8*>(dx + i) = r;
+#pragma unroll 2
+        for (long long r = r0 + lane_row; r < r1; r += rstep) {
+            const long long i = base + r * C + o * 8;
+            const vec8 vx = *reinterpret_cast<const vec8*>(x + i), vg = *reinterpret_cast<const vec8*>(dy + i);
+            vec8 rr;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xf = to_f(vx[k]);
+                float dz = to_f(vg[k]);
+                if (silu) dz *= silu_grad_f(fmaf(xf, a[k], b[k]));
+                rr[k] = (T)fmaf(a[k], dz, fmaf(k1[k], xf, k0[k]));
+            }
+            *reinterpret_cast<vec8*>(dx + i) = rr;
+        }
     }
 }
 
@@ -964,8 +986,10 @@ int gvd_group_norm_apply(const void* x, void* y, const float* gamma, const float
         if (is_bf16) hipLaunchKernelGGL(k_gn_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, S, silu, total);
         else hipLaunchKernelGGL(k_gn_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, S, silu, total);
     } else {
-        if (is_bf16) hipLaunchKernelGGL(k_gn_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, C, S, silu, total);
-        else hipLaunchKernelGGL(k_gn_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, C, S, silu, total);
+        const int rows = gn_rows_per_block(N, S);
+        dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_apply_nsc<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, coef, C, S, silu, rows);
+        else hipLaunchKernelGGL(k_gn_apply_nsc<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (_Float16*)y, coef, C, S, silu, rows);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_apply_*", e);
@@ -1019,8 +1043,10 @@ int gvd_group_norm_bwd_apply(const void* x, const void* dy, void* dx, const doub
         if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, coef, (const float2*)coef2, S, silu, total);
         else hipLaunchKernelGGL(k_gn_bwd_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)dx, coef, (const float2*)coef2, S, silu, total);
     } else {
-        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_nsc<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, coef, (const float2*)coef2, C, S, silu, total);
-        else hipLaunchKernelGGL(k_gn_bwd_apply_nsc<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)dx, coef, (const float2*)coef2, C, S, silu, total);
+        const int rows = gn_rows_per_block(N, S);
+        dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_nsc<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, coef, (const float2*)coef2, C, S, silu, rows);
+        else hipLaunchKernelGGL(k_gn_bwd_apply_nsc<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)dx, coef, (const float2*)coef2, C, S, silu, rows);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_bwd_apply_*", e);
