@@ -13,7 +13,8 @@ Raster (top level): Replica-like room, ~200k Gaussians, 640x480, 6 ring cameras,
 rasterization forward + backward through the drop-in operator (GaussianRasterizer + autograd), RGB-only loss gradient, inputs
 resident in HBM.  N > 1: data-parallel view shards -- every rank holds a replica of the Gaussians, renders its own view and
 the per-Gaussian gradients are summed with ONE fused all-reduce over RCCL (multiview.allreduce_gradients; 62 floats per
-Gaussian): value = views/s over all ranks, weak scaling; `replicas_value` is the same without the collective.
+Gaussian) inside rank PAIRS -- the reference's training step is two views wide (train + pseudo view), so N ranks form N/2
+independent width-2 steps: value = views/s over all ranks, weak scaling; `replicas_value` is the same without the collective.
 DDIM (`ddim`): 25 frames, 576x1024, CFG 7.5, rescale 0.7, eta 1, random-init 1.44 B-parameter U-Net, fp16; one step = one
 DDIM step (2 U-Net forwards + the fused update).  N > 1: CFG pair x frame shards over RCCL (strong scaling).
 
@@ -42,9 +43,13 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--workload", choices=["all", "raster", "ddim", "ddim_guided"], default="all",
+    ap.add_argument("--workload", choices=["all", "raster", "ddim", "ddim_guided", "config4"], default="all",
                     help="all = raster line + `ddim` object (default, the driver's line); raster = BASELINE configs[1] only; "
-                         "ddim / ddim_guided = configs[2] as a line of its own")
+                         "ddim / ddim_guided = configs[2] as a line of its own; config4 = BASELINE configs[3]: the raster training "
+                         "loop and the guided diffusion co-resident on one GPU at the train_guidedvd.py cadence")
+    ap.add_argument("--c4-iters", type=int, default=260, help="config4: raster training iterations between diffusion runs")
+    ap.add_argument("--c4-ddim-steps", type=int, default=6, help="config4: timed guided DDIM steps per diffusion run (of 50)")
+    ap.add_argument("--c4-rounds", type=int, default=2, help="config4: (iterations, diffusion run) rounds")
     ap.add_argument("--ddim-steps", type=int, default=10, help="timed DDIM steps of the `ddim` object in the default run")
     ap.add_argument("--ddim-height", type=int, default=576)
     ap.add_argument("--ddim-width", type=int, default=1024)
@@ -81,7 +86,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         _init_dist(dist, torch, local_rank)
     try:
-        if args.workload in ("ddim", "ddim_guided"):
+        if args.workload == "config4":
+            line = config4_run(args, dev, rank, world)
+        elif args.workload in ("ddim", "ddim_guided"):
             line = ddim_run(args, dev, rank, world, guided=args.workload == "ddim_guided", steps=min(args.steps, 50),
                             warm=min(args.warmup, 5), cpu_leg_wanted=not args.no_cpu_baseline)
         else:
@@ -176,8 +183,8 @@ def raster_run(args, dev, rank, world):
             torch.autograd.backward([color], [gC])
         else:
             loss_fn(color).backward()
-        if reduce_grads:   # data-parallel training step: sum the per-Gaussian gradients of the N views (one fused all-reduce)
-            multiview.allreduce_gradients(params)
+        if reduce_grads:   # width-2 training step of a rank pair: sum the per-Gaussian gradients of its two views
+            multiview.allreduce_gradients(params, group=pair_group)
         return color
 
     import multiview
@@ -208,11 +215,20 @@ def raster_run(args, dev, rank, world):
             el = float(et.item())
         return el
 
+    # The reference's training step is two views wide (train view + pseudo view, train_guidedvd.py:334,357); wider would change the
+    # optimisation.  So ranks pair up (2k, 2k+1): each pair is one data-parallel training step with ONE fused
+    # gradient all-reduce over RCCL, and the world holds world/2 independent pairs.  An odd last rank trains alone.
+    pair_group = None
+    if world > 1:
+        for k in range(world // 2):
+            grp = dist.new_group([2 * k, 2 * k + 1])
+            if rank // 2 == k and rank < 2 * (world // 2):
+                pair_group = grp
     replicas_value = None
     reduce_grads = False
     if world > 1:   # the same views without the collective (independent replicas), for reference next to the headline
         replicas_value = round(args.steps * world / timed_region(args.warmup, args.steps, False), 2)
-        reduce_grads = True
+        reduce_grads = pair_group is not None
     elapsed = timed_region(args.warmup, args.steps, True)
     reduce_grads = False
 
@@ -336,8 +352,8 @@ def raster_run(args, dev, rank, world):
                        "num_rendered_mean": int(R_mean), "visible_mean": int(vis_mean),
                        "mean_tile_list": round(R_mean / (((W + 15) // 16) * ((H + 15) // 16)), 1),
                        "parallelism": "single GPU" if world == 1 else
-                       f"dp{world}: one view per rank + ONE fused fp32 gradient all-reduce per step over RCCL "
-                       f"({sum(p_.numel() for p_ in params) * 4 / 1e6:.1f} MB)"},
+                       f"{world // 2} rank pair(s), each one width-2 training step (one view per rank + ONE fused fp32 gradient "
+                       f"all-reduce of {sum(p_.numel() for p_ in params) * 4 / 1e6:.1f} MB per step over RCCL / xGMI)"},
             "replicas_value": replicas_value,
             "roofline": roofline,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
@@ -346,6 +362,86 @@ def raster_run(args, dev, rank, world):
         }
         return line
     return None
+
+
+def config4_run(args, dev, rank, world):
+    """BASELINE configs[3] (single-GPU half): the 3DGS optimisation loop and the ViewCrafter guided diffusion CO-RESIDENT on one
+    MI355X, alternating at the cadence of train_guidedvd.py (:83,101,431: one 25-frame guided DDIM-50 run every 260 iterations,
+    37 runs over 10 000 iterations; video resolution 320x448, :97-98).  Per round: `c4_iters` training iterations -- train view
+    and pseudo view, each rasterizer forward + 0.8 L1 + 0.2 (1 - SSIM) + backward (:334-372), one Adam step on all Gaussian
+    parameters -- then `c4_ddim_steps` guided DDIM steps (U-Net fwd + dgrad x2, 25 x VAE decode fwd + dgrad, guidance) with both
+    model sets resident.  Reports the measured times, the peak memory, and the projection to the full schedule next to the
+    reference's published 3-4 h on 2 x V100 (README.md:88) -- a derived comparison, stated as such."""
+    import numpy as np
+    import torch
+    assert world == 1, "config4 is the single-GPU co-residency harness"
+    import fused_loss
+    import synthetic as syn
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = syn.scene_c2(P=args.points, W=args.width, H=args.height, sh_degree=args.sh_degree)
+    W, H, P = args.width, args.height, args.points
+    t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev, requires_grad=rg)
+    means3D, opac = t(sc["means3D"], True), t(sc["opacities"], True)
+    scales, rots, shs = t(sc["scales"], True), t(sc["rotations"], True), t(sc["shs"], True)
+    bg, conf = t(sc["bg"]), torch.ones((P, 1), device=dev)
+    means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+    cams = [GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg,
+                                          scale_modifier=1.0, viewmatrix=t(c["viewmatrix"]), projmatrix=t(c["projmatrix"]),
+                                          sh_degree=args.sh_degree, campos=t(c["campos"]), prefiltered=False, debug=False,
+                                          confidence=conf) for c in sc["cameras"]]
+    gen = torch.Generator(device=dev).manual_seed(7)
+    gts = [torch.rand((3, H, W), device=dev, generator=gen) for _ in cams]
+    params = [means3D, opac, scales, rots, shs]
+    opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15)
+
+    def train_iter(i):
+        opt.zero_grad(set_to_none=True)
+        means2D.grad = None
+        for v in (i % len(cams), (i + 3) % len(cams)):       # train view + pseudo view, both feeding one backward
+            color, radii, depth, alpha = GaussianRasterizer(cams[v])(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
+                                                                     scales=scales, rotations=rots)
+            loss, _ = fused_loss.photometric_loss(color, gts[v], 0.2)
+            loss.backward()
+        opt.step()
+
+    cache = {}
+    a2 = argparse.Namespace(**vars(args))
+    a2.ddim_height, a2.ddim_width = 320, 448                 # the resolution train_guidedvd.py runs the video model at
+    for i in range(20):
+        train_iter(i)
+    ddim_run(a2, dev, rank, world, guided=True, steps=1, warm=1, cpu_leg_wanted=False, cache=cache)   # builds + warms the models
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    it_ms, step_ms = [], []
+    t_all = time.perf_counter()
+    for r in range(args.c4_rounds):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.c4_iters):
+            train_iter(r * args.c4_iters + i)
+        torch.cuda.synchronize()
+        it_ms.append(1e3 * (time.perf_counter() - t0) / args.c4_iters)
+        d = ddim_run(a2, dev, rank, world, guided=True, steps=args.c4_ddim_steps, warm=0, cpu_leg_wanted=False, cache=cache)
+        step_ms.append(d["ms_per_step"])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_all
+    it, st = float(np.mean(it_ms)), float(np.mean(step_ms))
+    full_s = 10000 * it * 1e-3 + 37 * 50 * st * 1e-3
+    return {"metric": "guidedvd_full_loop_projected_minutes", "value": round(full_s / 60.0, 2), "unit": "min", "n_gpus": 1,
+            "steps": args.c4_rounds, "warmup": 1, "ms_per_step": round(1e3 * wall / args.c4_rounds, 1), "higher_is_better": False,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 raster / f16 diffusion", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3], single-GPU half: raster training loop + guided diffusion co-resident, "
+                                   f"{args.c4_rounds} rounds of {args.c4_iters} iterations (2 views fwd+loss+bwd + Adam) + "
+                                   f"{args.c4_ddim_steps} guided DDIM steps (25 frames, 320x448)",
+                       "gaussians": P, "width": W, "height": H},
+            "train_iter_ms": round(it, 4), "train_iters_per_s": round(1e3 / it, 1), "guided_ddim_step_ms": round(st, 1),
+            "measured_wall_s": round(wall, 2), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "projection": {"schedule": "10 000 iterations + 37 diffusion runs x 50 guided steps (train_guidedvd.py:83,101,431)",
+                           "seconds": round(full_s, 1),
+                           "reference_published": "3-4 h on 2 x V100 (README.md:88)",
+                           "speedup_vs_3h": round(3 * 3600 / full_s, 1), "speedup_vs_4h": round(4 * 3600 / full_s, 1),
+                           "note": "derived: covers the hot path only (raster fwd/bwd + loss + Adam, guided sampler); DUSt3R, "
+                                   "densification, trajectory search and I/O of the reference loop are outside it"}}
 
 
 def _init_dist(dist, torch, local_rank):
@@ -358,7 +454,7 @@ def _init_dist(dist, torch, local_rank):
         dist.init_process_group(backend=backend)
 
 
-def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted):
+def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=None):
     """BASELINE configs[2]: ViewCrafter 25-frame DDIM (unguided: 2 U-Net forwards + fused update per step),
     random-init U-Net with the zero-init modules re-randomised (SURVEY 7 'random-init U-Net is degenerate'),
     fp16 weights/activations with fp32 GroupNorm statistics and fp32 sampler math, synthetic conditioning.
@@ -377,17 +473,26 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted):
 
     T, h, w = args.frames, args.ddim_height // 8, args.ddim_width // 8
     torch.manual_seed(0)
-    with torch.device(dev):
-        unet = UNetModel(**VIEWCRAFTER_UNET)
     g = torch.Generator(device=dev).manual_seed(0)
-    with torch.no_grad():
-        for p_ in unet.parameters():  # re-randomise zero-init modules, std 0.02
-            if float(p_.abs().max()) == 0.0:
-                p_.copy_(torch.randn(p_.shape, device=dev, generator=g) * 0.02)
-    unet = unet.half().eval().to_token_major().requires_grad_(False)
+    if cache is not None and "unet" in cache:   # models kept resident between calls (config-4 harness)
+        unet = cache["unet"]
+    else:
+        with torch.device(dev):
+            unet = UNetModel(**VIEWCRAFTER_UNET)
+        with torch.no_grad():
+            for p_ in unet.parameters():  # re-randomise zero-init modules, std 0.02
+                if float(p_.abs().max()) == 0.0:
+                    p_.copy_(torch.randn(p_.shape, device=dev, generator=g) * 0.02)
+        unet = unet.half().eval().to_token_major().requires_grad_(False)
+        if cache is not None:
+            cache["unet"] = unet
 
     vae = None
-    if guided:  # B3/B13: per-frame KL-VAE decode inside the step, random-init decoder (no checkpoints offline)
+    if guided and cache is not None and "vae" in cache:
+        from lvdm_amd.guidance import LossGuidance
+        from lvdm_amd.samplers import DDIMSamplerGuidance
+        vae = cache["vae"]
+    elif guided:  # B3/B13: per-frame KL-VAE decode inside the step, random-init decoder (no checkpoints offline)
         from lvdm_amd.guidance import LossGuidance
         from lvdm_amd.model import VIEWCRAFTER_VAE
         from lvdm_amd.samplers import DDIMSamplerGuidance
@@ -397,6 +502,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted):
         vae = vae.half().eval().to_token_major()   # token-major throughout: the MFMA convolutions' layout
         for p_ in list(unet.parameters()) + list(vae.parameters()):
             p_.requires_grad_(False)
+        if cache is not None:
+            cache["vae"] = vae
 
     class LD(DiffusionSchedule):
         def __init__(self):
