@@ -583,7 +583,6 @@ int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int co
     }
     const long long in_elems = (long long)N * a.Hin * a.Win * Cin, out_elems = (long long)N * H * W * Cout;
     if (in_elems >= (1LL << 31) || out_elems >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
-    if (is_bf16) return fail(-3, "gvd_conv_mfma: bf16 is not built (f16 only)");
     a.nchunks = (Cin + BK - 1) / BK;
     a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
     a.coef_per_n = coef_per_n;
@@ -594,8 +593,9 @@ int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int co
         const int tw = (mode >= 2 || tw32) ? 32 : 16, th = PIX / tw;
         a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
         grid.x = (unsigned)(a.tiles_x * a.tiles_y * N);
-        if (mode >= 2) e = launch_stride2<_Float16>(cfg, a, grid, stream);
-        else e = tw32 ? launch_cfg<_Float16, 1>(cfg, a, grid, stream) : launch_cfg<_Float16, 0>(cfg, a, grid, stream);
+        if (mode >= 2) e = is_bf16 ? launch_stride2<__bf16>(cfg, a, grid, stream) : launch_stride2<_Float16>(cfg, a, grid, stream);
+        else if (tw32) e = is_bf16 ? launch_cfg<__bf16, 1>(cfg, a, grid, stream) : launch_cfg<_Float16, 1>(cfg, a, grid, stream);
+        else e = is_bf16 ? launch_cfg<__bf16, 0>(cfg, a, grid, stream) : launch_cfg<_Float16, 0>(cfg, a, grid, stream);
     } else {
         int pb = PIX / N;
         if (pb < 1) return fail(-1, "gvd_conv_mfma: too many frames for one tile");
@@ -603,7 +603,7 @@ int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int co
         a.PB = pb;
         a.tiles_x = (W + pb - 1) / pb; a.tiles_y = 1;
         grid.x = (unsigned)a.tiles_x;
-        e = launch_cfg<_Float16, 2>(cfg, a, grid, stream);
+        e = is_bf16 ? launch_cfg<__bf16, 2>(cfg, a, grid, stream) : launch_cfg<_Float16, 2>(cfg, a, grid, stream);
     }
     if (e != hipSuccess) return fail(-2, "launch k_conv_mfma", e);
     return 0;

@@ -262,9 +262,7 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
     statistics span separately (frames for 2-D norms, 1 for the temporal ones).
     Returns (out, PartialStats | None): the statistics of `out` for a following GroupNorm with `stats_groups` groups."""
     on_dev = ops._require_device(x, "fused_conv")
-    if not on_dev or x.dtype not in (torch.float16,):
-        if on_dev and x.dtype == torch.bfloat16:
-            raise RuntimeError("fused_conv: the MFMA convolution is built for fp16 activations")
+    if not on_dev or x.dtype not in (torch.float16, torch.bfloat16):
         if on_dev and not ops._REFERENCE_MATH and x.dtype != torch.float32:
             raise RuntimeError(f"fused_conv: unsupported dtype {x.dtype}")
         n_stat = n_stat if n_stat is not None else (1 if mode == TEMPORAL else x.shape[0])

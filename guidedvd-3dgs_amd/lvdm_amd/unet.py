@@ -35,7 +35,7 @@ def _fused(t, module=None):
     """The hand-written MFMA convolution path (csrc/conv_mfma.hip) applies: fp16 activations on a ROCm device, inference
     (dropout inactive).  Everything else -- fp32 parity runs, the CPU reference form -- takes the module-by-module form below
     (torch convolutions)."""
-    return t.is_cuda and t.dtype == torch.float16 and not (module is not None and module.training)
+    return t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and not (module is not None and module.training)
 
 
 def zero_module(m):

@@ -15,7 +15,7 @@ from . import conv as mconv, ops
 def _fused(t, module=None):
     """fp16 activations on a ROCm device in inference mode take the hand-written MFMA convolutions (csrc/conv_mfma.hip) on
     token-major data; fp32 parity runs and the CPU reference form take the torch convolutions."""
-    return t.is_cuda and t.dtype == torch.float16 and not (module is not None and module.training)
+    return t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and not (module is not None and module.training)
 
 
 def _tok(x):

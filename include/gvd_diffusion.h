@@ -133,7 +133,7 @@ int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, i
  * stats: NULL, or fp64 accumulators [stats_replicas][Nstat][groups][2] (zeroed by the caller) that receive the sum and
  *        sum of squares of the ROUNDED outputs per (sample, group) -- Nstat = N in mode 0, 1 in mode 1 -- i.e. the first pass
  *        of the next GroupNorm, spread over `stats_replicas` copies to keep the atomics apart (block b adds to copy b % R).
- * Cin % 8 == 0.  Returns -3 for bf16 (not built). */
+ * Cin % 8 == 0.  16-bit element type: fp16 or bf16 (is_bf16), fp32 accumulation either way. */
 int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
                   const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
                   int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream);

@@ -1,0 +1,58 @@
+"""Condense the two rocprofv3 --pmc passes of run_diff_pmc.sh: per kernel (conv_mfma / attn_fwd) and grid, mean counters per launch,
+MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles from GRBM_GUI_ACTIVE (the measured clock)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+a_dir, b_dir, out = sys.argv[1:4]
+
+
+def rows_of(d):
+    fs = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+    return list(csv.DictReader(open(fs[0]))) if fs else []
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(set))
+dur = collections.defaultdict(dict)
+for rows in (rows_of(a_dir), rows_of(b_dir)):
+    for r in rows:
+        n = r["Kernel_Name"]
+        if "k_conv_mfma" not in n and "k_attn_fwd" not in n:
+            continue
+        key = ("conv" if "k_conv_mfma" in n else "attn") + " " + n.split("ConvArgs")[0][-40:] + f" grid={r['Grid_Size']}"
+        acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[key][r["Counter_Name"]].add(r["Dispatch_Id"])
+        if "Start_Timestamp" in r and r.get("End_Timestamp"):
+            dur[key][r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+res = {}
+with open(out + ".csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "mean_per_launch", "launches"])
+    for key in sorted(acc):
+        per = {c: acc[key][c] / max(1, len(cnt[key][c])) for c in acc[key]}
+        for c, v in sorted(per.items()):
+            w.writerow([key, c, round(v, 1), len(cnt[key][c])])
+        d_ns = sum(dur[key].values()) / max(1, len(dur[key])) if dur[key] else None
+        cyc = per.get("GRBM_GUI_ACTIVE")
+        entry = {"launches": len(cnt[key].get("SQ_WAVE_CYCLES", ())), "duration_us_in_counter_pass": round(d_ns / 1e3, 1) if d_ns else None}
+        if cyc and d_ns:
+            entry["clock_ghz"] = round(cyc / d_ns, 3)
+        if cyc and "SQ_VALU_MFMA_BUSY_CYCLES" in per:
+            entry["mfma_busy"] = round(per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)
+        if cyc and "SQ_ACTIVE_INST_VALU" in per:
+            entry["valu_active"] = round(per["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), 4)
+        if "SQ_WAVE_CYCLES" in per:
+            wc = per["SQ_WAVE_CYCLES"]
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+                if c in per:
+                    entry[c.lower() + "_frac_of_wave_cycles"] = round(per[c] / wc, 4)
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_WAVES"):
+            if c in per:
+                entry[c.lower()] = int(per[c])
+        res[key] = entry
+json.dump(res, open(out + ".json", "w"), indent=1)
+print(json.dumps(res, indent=1)[:6000])

@@ -223,10 +223,24 @@ def test_conv_input_gradients_match_autograd_of_the_fp32_form():
     assert _rel(gx3, gx3r) < 4e-3
 
 
-def test_conv_rejects_what_it_does_not_cover():
+def test_conv_bf16_and_rejections():
     from lvdm_amd import conv as C
     m = _conv_module(64, 64, 1)
     with pytest.raises(RuntimeError):
         C.fused_conv(torch.randn(1, 8, 8, 64), m)                       # CPU tensor: no CPU path
-    with pytest.raises(RuntimeError):
-        C.fused_conv(torch.randn(1, 8, 8, 64, device=DEV).bfloat16(), m)
+    # bf16 operands (8 significant bits): same kernel family, tolerance of the coarser rounding
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(2, 20, 32, 320, device=DEV, generator=g).bfloat16()
+    mb = _conv_module(320, 320, 2).bfloat16()
+    gn = nn.GroupNorm(32, 320).to(DEV).bfloat16()
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    y, part = C.fused_conv(x, mb, gn=gn, silu=True, stats_groups=32)
+    xa = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 32, gn.weight.float(), gn.bias.float(), gn.eps)).bfloat16().float()
+    ref = F.conv2d(xa, mb.weight.float(), mb.bias.float(), padding=1).permute(0, 2, 3, 1)
+    assert y.dtype == torch.bfloat16 and _rel(y, ref) < 1.5e-2, _rel(y, ref)
+    xt = torch.randn(25, 40, 320, device=DEV, generator=g).bfloat16()
+    m3 = _conv_module(320, 320, 9, three_d=True).bfloat16()
+    yt, _ = C.fused_conv(xt, m3, mode=C.TEMPORAL)
+    reft = F.conv3d(xt.float().permute(2, 0, 1)[None, ..., None], m3.weight.float(), m3.bias.float(), padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0)
+    assert _rel(yt, reft) < 1.5e-2

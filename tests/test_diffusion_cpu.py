@@ -315,3 +315,36 @@ def test_resampler_and_image_proj_match_reference():
     np.testing.assert_allclose(y.detach().numpy(), R["y"], rtol=1e-4, atol=1e-5 * np.abs(R["y"]).max())
     np.testing.assert_allclose(gx.numpy(), R["gx"], rtol=1e-4, atol=1e-5 * np.abs(R["gx"]).max())
     np.testing.assert_allclose(t.numpy(), R["t"], rtol=1e-4, atol=1e-5 * np.abs(R["t"]).max())
+
+
+def test_vgg_perceptual_loss_matches_reference_vggloss():
+    """SURVEY 8f N4 / the reference's `lpips_guidance`: lvdm_amd.vgg_loss.VggLoss against utils/vgg_loss.py (golden from the
+    reference module itself, tests/golden/make_golden_vgg.py), loss and input gradient, same state-dict keys; and the guidance
+    loss with the term switched on: recon + numel * vgg * 0.001 (viewcrafter_wrapper.py:157-159)."""
+    from lvdm_amd.guidance import LossGuidance
+    from lvdm_amd.vgg_loss import VggLoss
+    V = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vgg_loss_ref.npz"))
+    vl = fill_by_name(VggLoss(pretrained=False), std=0.035)
+    assert sorted(vl.state_dict().keys()) == list(V["keys"])
+    for tag in "ab":
+        x = torch.tensor(V[f"{tag}_x"], requires_grad=True)
+        m = torch.tensor(V[f"{tag}_mask"]) if f"{tag}_mask" in V.files else None
+        loss = vl(x, torch.tensor(V[f"{tag}_y"]), mask=m)
+        (gx,) = torch.autograd.grad(loss, x)
+        np.testing.assert_allclose(float(loss), float(V[f"{tag}_loss"]), rtol=1e-5)
+        np.testing.assert_allclose(gx.numpy(), V[f"{tag}_gx"], rtol=1e-4, atol=1e-5 * np.abs(V[f"{tag}_gx"]).max())
+    lg = LossGuidance(ddim_steps=50, recur_steps=1, device="cpu")
+    lg.lpips_guidance, lg.lpips_fn = True, vl
+    H, W = V["a_x"].shape[2:]
+    lg.set_hw(H, W)
+    lg.set_guidance_images(torch.tensor(V["a_y"]))
+    lg.set_guidance_masks(torch.tensor(V["a_mask"]))
+    D = torch.tensor(V["a_x"])[0][:, None] * 2 - 1                                  # [3, 1, H, W] in [-1, 1]
+    loss_dict, numel = lg(D, 10, 0, 1)
+    mask = torch.tensor(V["a_mask"]).expand(1, 3, H, W)
+    recon = (0.5 * (torch.tensor(V["a_x"]) - torch.tensor(V["a_y"])) ** 2 * mask).sum()
+    want = recon + mask.sum() * float(V["a_loss"]) * 0.001
+    assert abs(float(loss_dict["recon"]) - float(want)) < 2e-4 * abs(float(want)) and float(numel) == float(mask.sum())
+    # the guidance-weight schedule of scale_guidance_weight (viewcrafter_wrapper.py:88-94)
+    lg2 = LossGuidance(ddim_steps=50, recur_steps=1, device="cpu", scale_guidance_weight=True)
+    assert abs(lg2.guidance_weight_fn(0) - 0.01) < 1e-12 and abs(lg2.guidance_weight_fn(1250) - 0.1) < 1e-9 and lg2.guidance_weight_fn(9999) == 1.0
