@@ -36,6 +36,25 @@ def _vgg19_features():
     return layers
 
 
+class _ScaleGrad(torch.autograd.Function):
+    """Identity whose backward multiplies the gradient by a constant.  The per-block MSE divides by millions of elements, so the
+    gradients entering the fp16 feature chain are ~1e-7 -- below fp16's normal range.  The fp16 part of the backward therefore
+    runs on gradients scaled by GRAD_SCALE (applied where the fp32 loss hands over to the fp16 features, undone in fp32 where
+    the chain reaches the input image): plain loss scaling, local to this module."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+GRAD_SCALE = 2.0 ** 14
+
+
 class VggLoss(nn.Module):
     def __init__(self, device=None, resize=True, pretrained=True, weights=None):
         super().__init__()
@@ -74,6 +93,8 @@ class VggLoss(nn.Module):
         outs = []
         fused = x.is_cuda and not ops._REFERENCE_MATH
         if fused:
+            if x.requires_grad:
+                x = _ScaleGrad.apply(x, 1.0 / GRAD_SCALE)       # (fp32) undo the gradient scaling of the fp16 chain
             t = x.permute(0, 2, 3, 1).half().contiguous()      # token-major fp16 for the MFMA convolutions
         for bi, blk in enumerate(self.blocks):
             for m in blk:
@@ -89,7 +110,7 @@ class VggLoss(nn.Module):
                         t = F.max_pool2d(t.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()
                     else:
                         x = F.max_pool2d(x, 2, 2)
-            outs.append(t.float() if fused else x)
+            outs.append(_ScaleGrad.apply(t.float(), GRAD_SCALE) if (fused and t.requires_grad) else (t.float() if fused else x))
             if bi == self.loss_blocks[-1]:
                 break
         return outs

@@ -1,5 +1,7 @@
 """Condense the two rocprofv3 --pmc passes of run_diff_pmc.sh: per kernel (conv_mfma / attn_fwd) and grid, mean counters per launch,
-MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles from GRBM_GUI_ACTIVE (the measured clock)."""
+MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles).  Kernel cycles come from GRBM_GUI_ACTIVE, which rocprofv3
+reports SUMMED over the 8 XCDs (the raw value / duration would be a 12-16 "GHz" clock): cycles = GRBM_GUI_ACTIVE / 8, i.e. the
+clock the kernel actually ran at (1.5-2.1 GHz under MFMA load, not the 2.4 GHz the TFLOP/s peak assumes)."""
 import collections
 import csv
 import glob
@@ -38,6 +40,7 @@ with open(out + ".csv", "w", newline="") as f:
             w.writerow([key, c, round(v, 1), len(cnt[key][c])])
         d_ns = sum(dur[key].values()) / max(1, len(dur[key])) if dur[key] else None
         cyc = per.get("GRBM_GUI_ACTIVE")
+        cyc = cyc / 8.0 if cyc else cyc   # summed over the 8 XCDs
         entry = {"launches": len(cnt[key].get("SQ_WAVE_CYCLES", ())), "duration_us_in_counter_pass": round(d_ns / 1e3, 1) if d_ns else None}
         if cyc and d_ns:
             entry["clock_ghz"] = round(cyc / d_ns, 3)
