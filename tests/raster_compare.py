@@ -81,6 +81,49 @@ def rel_to_max(a, b):
     return float(np.abs(a - b).max()) / (s if s > 0 else 1.0)
 
 
+def rel_elementwise(a, b, floor_frac=1e-2):
+    """Largest |a-b| / |b| over the entries with |b| >= floor_frac * max|b| (element-wise relative error above a magnitude
+    floor; entries below the floor are covered by rel_to_max)."""
+    if b.size == 0:
+        return 0.0
+    s = float(np.abs(b).max())
+    if s == 0:
+        return 0.0
+    m = np.abs(b) >= floor_frac * s
+    return float((np.abs(a - b)[m] / np.abs(b)[m]).max()) if m.any() else 0.0
+
+
+def threshold_margin(st_o, py, px, upto):
+    """Why can `n_contrib` differ at a pixel between two fp32 implementations that agree to an ulp of exp()?  Only through one
+    of the blend loop's three comparisons (forward.cu:343-355: power > 0, alpha < 1/255, T (1 - alpha) < 1e-4) landing within
+    rounding of its threshold.  Replays the pixel's list in float64 from the ORACLE's state up to list position `upto` and
+    returns the smallest relative distance of any compared quantity to its threshold."""
+    W = st_o["W"] if "W" in st_o else st_o["color"].shape[-1]
+    gx = (W + 15) // 16
+    tile = (py // 16) * gx + (px // 16)
+    r0, r1 = (int(v) for v in st_o["ranges"][tile])
+    T, margin = 1.0, np.inf
+    for pos in range(r0, min(r1, r0 + upto + 1)):
+        g = int(st_o["point_list"][pos])
+        xy = st_o["means2D"][g].astype(np.float64)
+        con = st_o["conic_opacity"][g].astype(np.float64)
+        dx, dy = xy[0] - px, xy[1] - py
+        power = -0.5 * (con[0] * dx * dx + con[2] * dy * dy) - con[1] * dx * dy
+        margin = min(margin, abs(power) / max(1.0, abs(con[0] * dx * dx) + abs(con[2] * dy * dy)))
+        if power > 0:
+            continue
+        alpha = min(0.99, con[3] * np.exp(power))
+        margin = min(margin, abs(alpha - 1.0 / 255.0) * 255.0)
+        if alpha < 1.0 / 255.0:
+            continue
+        test_T = T * (1.0 - alpha)
+        margin = min(margin, abs(test_T - 1e-4) / 1e-4)
+        if test_T < 1e-4:
+            break
+        T = test_T
+    return float(margin)
+
+
 def compare(st_h, st_o, g_h=None, g_o=None, verbose=True):
     """Returns a dict of parity metrics (exact-match booleans and error magnitudes)."""
     P = st_o["P"]
@@ -107,6 +150,13 @@ def compare(st_h, st_o, g_h=None, g_o=None, verbose=True):
             rep["point_list_equal"] = bool(np.array_equal(st_h["point_list"].view(np.uint32), st_o["point_list"]))
         nc_h, nc_o = st_h["n_contrib"].view(np.uint32), st_o["n_contrib"]
         rep["n_contrib_mismatch_frac"] = float((nc_h != nc_o).mean())
+        # every mismatch must be a threshold straddle: the float64 replay of that pixel has a comparison within fp32 rounding
+        # (the transmittance is a product of up to a few hundred fp32 factors: 2e-4 relative) of its threshold
+        ys, xs = np.nonzero(nc_h != nc_o)
+        worst = 0.0
+        for py, px in list(zip(ys, xs))[:64]:
+            worst = max(worst, threshold_margin(st_o, int(py), int(px), int(max(nc_h[py, px], nc_o[py, px])) + 1))
+        rep["n_contrib_mismatch_worst_threshold_margin"] = worst
     for k in ("color", "depth", "alpha"):
         a, b = st_h[k], st_o[k]
         tol = 1e-4 * np.maximum(1.0, np.abs(b))
@@ -116,6 +166,7 @@ def compare(st_h, st_o, g_h=None, g_o=None, verbose=True):
     if g_h is not None:
         for k in g_h:
             rep["grad_" + k + "_relmax"] = rel_to_max(g_h[k], g_o[k])
+            rep["gradel_" + k] = rel_elementwise(g_h[k], g_o[k])
     if verbose:
         for k, v in rep.items():
             print(f"  {k:32s} {v}")

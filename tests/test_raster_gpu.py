@@ -19,7 +19,7 @@ import pytest
 import torch
 
 import synthetic as syn
-from raster_compare import compare, rel_to_max, run_hip, run_oracle
+from raster_compare import compare, rel_elementwise, rel_to_max, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +40,9 @@ def _check(rep, exact=EXACT, grad_tol=2e-3, img_outliers=0.0):
         if k in rep:
             assert rep[k] is True, (k, rep)
     assert rep.get("n_contrib_mismatch_frac", 0.0) <= img_outliers, rep
+    # n_contrib is exact except where one of the blend loop's comparisons sits within fp32 rounding of its threshold (the two
+    # sides differ by <= 1 ulp in exp()); every mismatching pixel is replayed in float64 and must show such a near-tie
+    assert rep.get("n_contrib_mismatch_worst_threshold_margin", 0.0) < 2e-4, rep
     for k in ("color", "depth", "alpha"):
         assert rep[k + "_outlier_frac"] <= img_outliers, (k, rep)
     for k, v in rep.items():
@@ -92,10 +95,12 @@ def test_c2_full_size_parity(cam_id):
     st_o, g_o = run_oracle(sc, cam, grads)
     st_h, g_h = run_hip(sc, cam, grads)
     _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, img_outliers=2e-5)
-    # backward kernels in isolation: same alpha image on both sides -> 1e-4
+    # backward kernels in isolation: same alpha image on both sides -> 1e-4 of the largest entry per tensor, and element-wise
+    # 5e-3 relative on every entry above 1 % of the largest (below that floor the per-tensor bound is the operative one)
     _, g_h2 = run_hip(sc, cam, grads, alpha_override=st_o["alpha"])
     for k in g_h2:
         assert rel_to_max(g_h2[k], g_o[k]) < 1e-4, k
+        assert rel_elementwise(g_h2[k], g_o[k]) < 5e-3, (k, rel_elementwise(g_h2[k], g_o[k]))
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
