@@ -265,6 +265,8 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
     if not on_dev or x.dtype not in (torch.float16, torch.bfloat16):
         if on_dev and not ops._REFERENCE_MATH and x.dtype != torch.float32:
             raise RuntimeError(f"fused_conv: unsupported dtype {x.dtype}")
+        if on_dev:
+            ops._torch_form("fused_conv", f"dtype {x.dtype}")
         n_stat = n_stat if n_stat is not None else (1 if mode == TEMPORAL else x.shape[0])
         return _reference(x, conv.weight, conv.bias, mode, upsample, gn, silu, add_nc, residual, n_stat), None
     if torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)):

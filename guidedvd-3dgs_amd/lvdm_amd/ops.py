@@ -65,6 +65,20 @@ def _require_device(t, what):
                        f"(tests may call ops.use_reference_math(True))")
 
 
+_WARNED = set()
+
+
+def _torch_form(op, why):
+    """A DEVICE tensor is about to take the plain-torch form of `op` instead of the hand-written kernel (fp32 activations of a
+    parity run, a head size the MFMA kernel does not cover, ...).  Never silent: one RuntimeWarning per (op, reason) and process,
+    so that a caller who merely forgot `.half()` sees that it is not running the product kernels."""
+    key = (op, why)
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(f"lvdm_amd.ops.{op}: {why} -> plain torch form, not the HIP kernel", RuntimeWarning, stacklevel=3)
+
+
 def _check(rc):
     if rc != 0:
         raise RuntimeError(f"gvd_diffusion error {rc}: {lib().gvd_diff_last_error().decode()}")
@@ -167,6 +181,8 @@ def attention(q, k, v, heads, frame_major=False):
             return _FlashAttention.apply(q, k, v, heads, frame_major)
         return _hip_attention_fwd(q, k, v, heads, frame_major)
     # fp32 tensors (parity tests) and head sizes the MFMA kernel does not cover (VAE mid-attention, d=512)
+    if on_dev:
+        _torch_form("attention", f"dtype {q.dtype}, head dim {d} (the MFMA kernel covers 16-bit inputs with 64-wide heads)")
     return attention_math(q, k, v, heads, frame_major)
 
 
@@ -316,6 +332,8 @@ def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=Fals
                 raise RuntimeError("lvdm_amd.ops.group_norm: only the input gradient is implemented (freeze the weights)")
             return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last, group, S_total)
         return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, group=group, S_total=S_total)
+    if on_dev:
+        _torch_form("group_norm", f"dtype {x.dtype}, C = {C} (the kernels cover 16-bit inputs with affine parameters, C % 8 == 0 token-major)")
     return group_norm_math(x, groups, weight, bias, eps, silu, channels_last, group)
 
 
@@ -393,6 +411,8 @@ def layer_norm(x, weight, bias, eps=1e-5):
             return _hip_layer_norm(x, weight, bias, eps)
         if not (weight.requires_grad or bias.requires_grad):   # guided sampler: input gradient only
             return _LayerNormFn.apply(x, weight, bias, eps)
+    if on_dev:
+        _torch_form("layer_norm", f"dtype {x.dtype} / weight {None if weight is None else weight.dtype}, C = {C}, or trainable affine")
     return F.layer_norm(x, (C,), weight, bias, eps)
 
 
@@ -409,6 +429,8 @@ def geglu(h):
         if torch.is_grad_enabled() and h.requires_grad:
             return _GegluFn.apply(h)
         return _hip_geglu(h.contiguous())
+    if on_dev:
+        _torch_form("geglu", f"dtype {h.dtype}, C = {C}")
     return geglu_math(h)
 
 

@@ -35,7 +35,10 @@ def _fused(t, module=None):
     """The hand-written MFMA convolution path (csrc/conv_mfma.hip) applies: fp16 activations on a ROCm device, inference
     (dropout inactive).  Everything else -- fp32 parity runs, the CPU reference form -- takes the module-by-module form below
     (torch convolutions)."""
-    return t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and not (module is not None and module.training)
+    ok = t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and not (module is not None and module.training)
+    if t.is_cuda and not ok:   # never silent: a device tensor is about to meet torch's convolutions instead of the MFMA kernel
+        ops._torch_form("convolution", f"dtype {t.dtype}{' in training mode' if (module is not None and module.training) else ''}")
+    return ok
 
 
 def zero_module(m):

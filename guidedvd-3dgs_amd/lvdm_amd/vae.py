@@ -15,7 +15,10 @@ from . import conv as mconv, ops
 def _fused(t, module=None):
     """fp16 activations on a ROCm device in inference mode take the hand-written MFMA convolutions (csrc/conv_mfma.hip) on
     token-major data; fp32 parity runs and the CPU reference form take the torch convolutions."""
-    return t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and not (module is not None and module.training)
+    ok = t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and not (module is not None and module.training)
+    if t.is_cuda and not ok:   # never silent: a device tensor is about to meet torch's convolutions instead of the MFMA kernel
+        ops._torch_form("convolution", f"dtype {t.dtype}{' in training mode' if (module is not None and module.training) else ''}")
+    return ok
 
 
 def _tok(x):
