@@ -44,34 +44,52 @@ __global__ void __launch_bounds__(256) k_attn_delta(const T* __restrict__ o, con
     delta[i] = s;
 }
 
-// Stage a 64-row x 64-channel tile of `src` (rows row0.., zero beyond n_rows) into LDS row-major and/or transposed.
-// Row-major: chunk c -> row c>>3, channels (c&7)*8 (coalesced 128-byte rows, ds_write_b128).
-// Transposed: chunk c -> row PAIR c&31, channels (c>>5)*8: two rows packed per dword, conflict-free ds_write_b32.
-template <typename T, int NT, bool ROWMAJOR, bool TRANSPOSED>
-__device__ __forceinline__ void stage_tile(const T* __restrict__ src, size_t rs, int row0, int n_rows, int tid,
-                                           T (*sRow)[LDS_ROW], T (*sTr)[LDS_ROW])
+// Staging of a 64-row x 64-channel tile of `src` (rows row0.., zero beyond n_rows) into LDS row-major and/or transposed, split
+// into a LOAD half (global -> registers) and a COMMIT half (registers -> LDS) so that the loads of tile i+1 are in flight
+// under the MFMAs of tile i.  256 threads.
+//   row-major:  chunk c = tid, tid + 256 -> row c>>3, channels (c&7)*8 (coalesced 128-byte rows, ds_write_b128)
+//   transposed: thread -> row PAIR tid&31, channels (tid>>5)*8: two rows packed per dword, conflict-free ds_write_b32
+// All loads are UNCONDITIONAL (rows past the end read the last valid row and are zeroed at commit time): a predicated
+// `ok ? load : 0` makes hipcc wait vmcnt(0) between the loads -- the first version of these kernels spent ~8 dependent L2 round
+// trips per tile in its (also un-pipelined) staging and ran the MFMAs 12 % of the time.
+template <typename T> struct TileRegs {
+    typename Tr<T>::vec8 r[2], t0, t1;
+};
+
+template <typename T, bool TRANSPOSED>
+__device__ __forceinline__ void tile_load(const T* __restrict__ src, size_t rs, int row0, int n_rows, int tid, TileRegs<T>& R)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int last = n_rows - 1;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int c = tid + i * 256, g = row0 + (c >> 3);
+        R.r[i] = *reinterpret_cast<const vec8*>(src + (size_t)(g < last ? g : last) * rs + (c & 7) * 8);
+    }
+    if (TRANSPOSED) {
+        const int g = row0 + 2 * (tid & 31), c8 = (tid >> 5) * 8;
+        R.t0 = *reinterpret_cast<const vec8*>(src + (size_t)(g < last ? g : last) * rs + c8);
+        R.t1 = *reinterpret_cast<const vec8*>(src + (size_t)(g + 1 < last ? g + 1 : last) * rs + c8);
+    }
+}
+
+template <typename T, bool TRANSPOSED>
+__device__ __forceinline__ void tile_commit(int row0, int n_rows, int tid, const TileRegs<T>& R, T (*sRow)[LDS_ROW], T (*sTr)[LDS_ROW])
 {
     typedef typename Tr<T>::vec8 vec8;
     typedef T T2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int c = tid; c < 512; c += NT) {
-        if (ROWMAJOR) {
-            const int row = c >> 3, c8 = (c & 7) * 8, g = row0 + row;
-            const vec8 x = (g < n_rows) ? *reinterpret_cast<const vec8*>(src + (size_t)g * rs + c8) : vec8{};
-            *reinterpret_cast<vec8*>(&sRow[row][c8]) = x;
-        }
+    for (int i = 0; i < 2; i++) {
+        const int c = tid + i * 256, row = c >> 3;
+        *reinterpret_cast<vec8*>(&sRow[row][(c & 7) * 8]) = (row0 + row < n_rows) ? R.r[i] : vec8{};
     }
     if (TRANSPOSED) {
+        const int kp = tid & 31, c8 = (tid >> 5) * 8, g = row0 + 2 * kp;
+        const vec8 x0 = (g < n_rows) ? R.t0 : vec8{}, x1 = (g + 1 < n_rows) ? R.t1 : vec8{};
 #pragma unroll
-        for (int c = tid; c < 256; c += NT) {
-            const int kp = c & 31, c8 = (c >> 5) * 8, g = row0 + 2 * kp;
-            const vec8 x0 = (g < n_rows) ? *reinterpret_cast<const vec8*>(src + (size_t)g * rs + c8) : vec8{};
-            const vec8 x1 = (g + 1 < n_rows) ? *reinterpret_cast<const vec8*>(src + (size_t)(g + 1) * rs + c8) : vec8{};
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const T2 pr = { x0[i], x1[i] };
-                *reinterpret_cast<T2*>(&sTr[c8 + i][2 * kp]) = pr;
-            }
+        for (int i = 0; i < 8; i++) {
+            const T2 pr = { x0[i], x1[i] };
+            *reinterpret_cast<T2*>(&sTr[c8 + i][2 * kp]) = pr;
         }
     }
 }
@@ -105,20 +123,33 @@ k_attn_bwd_dkv(const T* __restrict__ q, const T* __restrict__ k, const T* __rest
     vec8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-        kf[ks] = valid_k ? *reinterpret_cast<const vec8*>(k + kvoff + (size_t)key * krs + 16 * ks + 8 * hi) : vec8{};
-        vf[ks] = valid_k ? *reinterpret_cast<const vec8*>(v + kvoff + (size_t)key * krs + 16 * ks + 8 * hi) : vec8{};
+        const size_t kr = (size_t)(valid_k ? key : Nk - 1) * krs + 16 * ks + 8 * hi;   // unconditional load, zeroed below
+        kf[ks] = *reinterpret_cast<const vec8*>(k + kvoff + kr);
+        vf[ks] = *reinterpret_cast<const vec8*>(v + kvoff + kr);
+        if (!valid_k) { kf[ks] = vec8{}; vf[ks] = vec8{}; }
     }
     f16v dk0 = {}, dk1 = {}, dv0 = {}, dv1 = {};
 
+    TileRegs<T> rq, rg;
+    float rl = 0.f, rd = 0.f;
+    auto prefetch = [&](int qt) {
+        tile_load<T, true>(qb, rs, qt, Nq, tid, rq);
+        tile_load<T, true>(gb, rs, qt, Nq, tid, rg);
+        const int r = qt + (tid & 63) < Nq ? qt + (tid & 63) : Nq - 1;
+        rl = lse_b[r];
+        rd = delta_b[r];
+    };
+    prefetch(0);
     for (int qt = 0; qt < Nq; qt += 64) {
-        __syncthreads();
-        stage_tile<T, 256, true, true>(qb, rs, qt, Nq, tid, sQ, sQt);
-        stage_tile<T, 256, true, true>(gb, rs, qt, Nq, tid, sdO, sdOt);
+        __syncthreads();   // every wave is done with the previous tile
+        tile_commit<T, true>(qt, Nq, tid, rq, sQ, sQt);
+        tile_commit<T, true>(qt, Nq, tid, rg, sdO, sdOt);
         if (tid < 64) {
             const bool ok = qt + tid < Nq;
-            sLse[tid] = ok ? lse_b[qt + tid] : 3.0e38f;   // rows past the end: P = exp2(0 - huge) = 0
-            sDelta[tid] = ok ? delta_b[qt + tid] : 0.f;
+            sLse[tid] = ok ? rl : 3.0e38f;   // rows past the end: P = exp2(0 - huge) = 0
+            sDelta[tid] = ok ? rd : 0.f;
         }
+        if (qt + 64 < Nq) prefetch(qt + 64);   // in flight under this tile's MFMAs
         __syncthreads();
 #pragma unroll
         for (int sb = 0; sb < 2; sb++) {
@@ -208,17 +239,26 @@ k_attn_bwd_dq(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
     vec8 qf[4], gf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-        qf[ks] = valid_q ? *reinterpret_cast<const vec8*>(q + qoff + (size_t)query * rs + 16 * ks + 8 * hi) : vec8{};
-        gf[ks] = valid_q ? *reinterpret_cast<const vec8*>(d_o + qoff + (size_t)query * rs + 16 * ks + 8 * hi) : vec8{};
+        const size_t qr = (size_t)(valid_q ? query : Nq - 1) * rs + 16 * ks + 8 * hi;   // unconditional load, zeroed below
+        qf[ks] = *reinterpret_cast<const vec8*>(q + qoff + qr);
+        gf[ks] = *reinterpret_cast<const vec8*>(d_o + qoff + qr);
+        if (!valid_q) { qf[ks] = vec8{}; gf[ks] = vec8{}; }
     }
     const float L = valid_q ? lse[(size_t)bh * Nq + query] : 3.0e38f;
     const float Dl = valid_q ? delta[(size_t)bh * Nq + query] : 0.f;
     f16v dq0 = {}, dq1 = {};
 
+    TileRegs<T> rk, rv;
+    tile_load<T, true>(kb, krs, 0, Nk, tid, rk);
+    tile_load<T, false>(vb, krs, 0, Nk, tid, rv);
     for (int kt = 0; kt < Nk; kt += 64) {
-        __syncthreads();
-        stage_tile<T, 256, true, true>(kb, krs, kt, Nk, tid, sK, sKt);
-        stage_tile<T, 256, true, false>(vb, krs, kt, Nk, tid, sV, nullptr);
+        __syncthreads();   // every wave is done with the previous tile
+        tile_commit<T, true>(kt, Nk, tid, rk, sK, sKt);
+        tile_commit<T, false>(kt, Nk, tid, rv, sV, nullptr);
+        if (kt + 64 < Nk) {   // in flight under this tile's MFMAs
+            tile_load<T, true>(kb, krs, kt + 64, Nk, tid, rk);
+            tile_load<T, false>(vb, krs, kt + 64, Nk, tid, rv);
+        }
         __syncthreads();
 #pragma unroll
         for (int kbk = 0; kbk < 2; kbk++) {
