@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) k_attn_delta(const T* __restrict__ o, con
 //   transposed: thread -> row PAIR tid&31, channels (tid>>5)*8: two rows packed per dword, conflict-free ds_write_b32
 // All loads are UNCONDITIONAL (rows past the end read the last valid row and are zeroed at commit time): a predicated
 // `ok ? load : 0` makes hipcc wait vmcnt(0) between the loads -- the first version of these kernels spent ~8 dependent L2 round
-// trips per tile in its (also un-pipelined) staging and ran the MFMAs 12 % of the time.
+// trips per tile in its (also un-pipelined) staging and ran the MFMAs 12 % of the time.  (Double-buffering the LDS tiles on top,
+// one barrier per tile instead of two, measured within noise: 13.2 vs 12.9 ms at L0 -- not kept.)
 template <typename T> struct TileRegs {
     typename Tr<T>::vec8 r[2], t0, t1;
 };
