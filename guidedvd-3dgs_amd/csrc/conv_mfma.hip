@@ -522,18 +522,27 @@ const int CFG_PIX[5] = { 256, 128, 256, 256, 128 };
 void choose(int mode, int N, int H, int W, int Cout, int* cfg, int* tw32)
 {
     const long long pixels = (long long)N * H * W;
+    auto padded = [&](int pix, int tw) { const int th = pix / tw; return (long long)((H + th - 1) / th) * th * ((W + tw - 1) / tw) * tw; };
+    auto width32 = [&](int pix) { return padded(pix, 32) <= padded(pix, 16) ? 1 : 0; };
+    // workgroups a configuration launches (spatial: padded tiles per image; temporal: pixel tiles of PIX / N pixels)
+    auto groups = [&](int c) {
+        const int pix = CFG_PIX[c], bn = CFG_BN[c];
+        long long tiles;
+        if (mode == 1) { int pb = pix / N; pb = pb < 1 ? 1 : (pb > PB_MAX ? PB_MAX : pb); tiles = (W + pb - 1) / pb; }
+        else tiles = (mode >= 2 ? padded(pix, 32) : padded(pix, width32(pix) ? 32 : 16)) / pix * N;
+        return tiles * ((Cout + bn - 1) / bn);
+    };
     int c;
     if (mode >= 2) c = (Cout % 160 == 0) ? 1 : 4;          // stride 2
     else if (Cout <= 32) c = 3;
     else if (Cout % 160 == 0) c = (mode == 1 || pixels >= 40000) ? 0 : 1;
     else c = 2;
+    // small problems (the 9x16 level, the 72x128 VAE stage, the temporal form at 144 pixels): the big tiles launch fewer
+    // workgroups than the chip has CU slots (2 x 256) -- take the 128 x 128 tile when it at least fills one slot per CU better
+    if (mode < 2 && Cout >= 128 && c != 4 && groups(c) < 384 && groups(4) > groups(c)) c = 4;
     *cfg = c;
     *tw32 = 1;
-    if (mode == 0) {
-        const int pix = CFG_PIX[c];
-        auto padded = [&](int tw) { const int th = pix / tw; return (long long)((H + th - 1) / th) * th * ((W + tw - 1) / tw) * tw; };
-        *tw32 = padded(32) <= padded(16) ? 1 : 0;
-    }
+    if (mode == 0) *tw32 = width32(CFG_PIX[c]);
 }
 
 }  // namespace
