@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--instance-capacity", type=int, default=0,
                     help="raster: sync-free forward with this (Gaussian, tile) instance capacity (0 = reference behaviour)")
     ap.add_argument("--graph", action="store_true", help="ddim: replay the U-Net evaluations from a captured hipGraph")
+    ap.add_argument("--ae-frames", type=int, default=None, help="ddim_guided / config4: frames per VAE decoder forward/backward in the guided step (default 5; 1 = the reference's per-frame loop)")
     ap.add_argument("--batch-cfg", action="store_true", help="ddim: evaluate cond/uncond as one batch-2 U-Net call")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -512,10 +513,10 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
             self.first_stage_model = vae
             self.scale_factor = 0.18215
 
-        def differentiable_decode_first_stage(self, z, **kw):  # ddpm3d.py:646-675, perframe_ae, one frame at a time
+        def differentiable_decode_first_stage(self, z, **kw):  # ddpm3d.py:646-675 perframe_ae: same per-frame values, frames grouped (vae.py perframe)
             b, c, t, hh, ww = z.shape
             z2 = z.transpose(1, 2).reshape(b * t, c, hh, ww).half()
-            res = torch.cat([self.first_stage_model.decode(z2[i:i + 1] / self.scale_factor) for i in range(b * t)], 0)
+            res = self.first_stage_model.perframe(lambda zz: self.first_stage_model.decode(zz / self.scale_factor), z2)
             return res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
 
         @property
@@ -532,6 +533,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     sampler = DDIMSamplerGuidance(ld) if guided else DDIMSampler(ld)
     sampler.make_schedule(50, "uniform_trailing", 1.0)
     sampler.batch_cfg = bool(args.batch_cfg)
+    if guided and args.ae_frames:
+        sampler.decode_group = args.ae_frames
     sampler.graph_apply = bool(args.graph)
     plan = None
     if world > 1:

@@ -84,6 +84,7 @@ class LatentDiffusion(DDPM):
         self.noise_strength, self.loop_video, self.fps_condition_type = noise_strength, loop_video, fps_condition_type
         self.perframe_ae, self.logdir, self.rand_cond_frame = perframe_ae, logdir, rand_cond_frame
         self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
+        self.ae_frames_per_call = en_and_decode_n_samples_a_time   # frames per VAE call under perframe_ae; None = all (vae.py)
         self.scale_factor = scale_factor
         self.first_stage_model = self._frozen(instantiate_from_config(_node(first_stage_config)))
         self.cond_stage_model = self._frozen(instantiate_from_config(_node(cond_stage_config)))
@@ -171,8 +172,8 @@ class LatentDiffusion(DDPM):
         if not self.perframe_ae:
             res = self.get_first_stage_encoding(self.first_stage_model.encode(xd)).detach()
         else:
-            res = torch.cat([self.get_first_stage_encoding(self.first_stage_model.encode(xd[i:i + 1])).detach()
-                             for i in range(xd.shape[0])], dim=0)
+            res = self.first_stage_model.perframe(lambda xx: self.get_first_stage_encoding(self.first_stage_model.encode(xx)).detach(),
+                                                  xd, self.ae_frames_per_call, latent=False)
         res = res.to(x.dtype)
         if reshape_back:
             res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
@@ -188,7 +189,7 @@ class LatentDiffusion(DDPM):
         if not self.perframe_ae:
             res = self.first_stage_model.decode(zd, **kwargs)
         else:
-            res = torch.cat([self.first_stage_model.decode(zd[i:i + 1], **kwargs) for i in range(zd.shape[0])], dim=0)
+            res = self.first_stage_model.perframe(lambda zz: self.first_stage_model.decode(zz, **kwargs), zd, self.ae_frames_per_call)
         res = res.to(z.dtype)
         if reshape_back:
             res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)

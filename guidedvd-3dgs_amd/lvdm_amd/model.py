@@ -78,6 +78,7 @@ class LatentDiffusion(DiffusionSchedule):
         self.first_stage_model = AutoencoderKLDecoder(first_stage_config or VIEWCRAFTER_VAE)
         self.scale_factor = scale_factor
         self.perframe_ae = perframe_ae
+        self.ae_frames_per_call = None   # frames per VAE call under perframe_ae (vae.py: perframe); None = all
 
     @property
     def device(self):
@@ -99,8 +100,8 @@ class LatentDiffusion(DiffusionSchedule):
         if not self.perframe_ae:
             res = self.first_stage_model.decode(1. / self.scale_factor * z, **kwargs)
         else:
-            res = torch.cat([self.first_stage_model.decode(1. / self.scale_factor * z[i:i + 1], **kwargs)
-                             for i in range(z.shape[0])], dim=0)
+            res = self.first_stage_model.perframe(lambda zz: self.first_stage_model.decode(1. / self.scale_factor * zz, **kwargs),
+                                                  z, self.ae_frames_per_call)
         if reshape_back:
             res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
         return res
@@ -114,8 +115,8 @@ class LatentDiffusion(DiffusionSchedule):
         if not self.perframe_ae:
             res = self.scale_factor * self.first_stage_model.encode(x).sample()
         else:
-            res = torch.cat([self.scale_factor * self.first_stage_model.encode(x[i:i + 1]).sample()
-                             for i in range(x.shape[0])], dim=0)
+            res = self.first_stage_model.perframe(lambda xx: self.scale_factor * self.first_stage_model.encode(xx).sample(),
+                                                  x, self.ae_frames_per_call, latent=False)
         if reshape_back:
             res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
         return res.detach()

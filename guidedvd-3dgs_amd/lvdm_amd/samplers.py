@@ -193,6 +193,10 @@ class DDIMSamplerGuidance(DDIMSampler):
     """ddim_guidance.py: the guided step differentiates pred_x0 w.r.t. x_t through BOTH U-Net evaluations
     and back-propagates the per-frame decoder-space loss gradient (Algorithm 1, L11-L13 of the paper)."""
 
+    #: frames per VAE decoder forward/backward inside the guided step (1 = the reference's loop; each frame's saved decoder
+    #: activations are ~4 GB at 576x1024, so 5 adds ~16 GB to the step's peak and fills the chip on the 72x128 / 144x256 stages)
+    decode_group = 5
+
     def _grad_ctx(self):
         return torch.enable_grad()
 
@@ -246,17 +250,26 @@ class DDIMSamplerGuidance(DDIMSampler):
                 dir_xt = k["dir_coef"] * e_t
                 nz = self._randn(x.shape, x.device) if noise is None else noise
                 x_prev = k["sqrt_a_prev"] * pred_x0 + dir_xt + k["sigma_t"] * temperature * nz
-            # per-frame decode + loss gradient w.r.t. the (detached) x0 latent of that frame
+            # decode + loss gradient w.r.t. the (detached) x0 latent, frame by frame in the reference (ddim_guidance.py:
+            # 296-317) to bound memory; here `decode_group` frames share one decoder forward/backward.  A frame's loss
+            # depends on its own latent only (per-sample norms), so the gradient of the summed losses IS the per-frame
+            # gradients; the 1/numel factor stays after the backward, as in the reference, to keep the fp16 backward in range.
             n_frames = pred_x0.shape[2]
             grads, decoded = [], []
             f_lo, f_hi = (0, n_frames) if plan is None else plan.frame_owner_slices(n_frames)[:2]
-            for f in range(f_lo, f_hi):
-                z = pred_x0[:, :, f:f + 1].clone().detach().requires_grad_(True)
+            group = max(1, int(getattr(self, "decode_group", 1) or 1))
+            for f0 in range(f_lo, f_hi, group):
+                f1 = min(f0 + group, f_hi)
+                z = pred_x0[:, :, f0:f1].clone().detach().requires_grad_(True)
                 D = m.differentiable_decode_first_stage(z)
-                loss_dict, numel = loss_guidance_fn(D[0], index, f, f + 1)
-                g = torch.autograd.grad(outputs=loss_dict["recon"], inputs=z)[0]
+                total, numels = None, []
+                for j, f in enumerate(range(f0, f1)):
+                    loss_dict, numel = loss_guidance_fn(D[0][:, j:j + 1], index, f, f + 1)
+                    total = loss_dict["recon"] if total is None else total + loss_dict["recon"]
+                    numels.append(numel)
+                g = torch.autograd.grad(outputs=total, inputs=z)[0]
                 if not loss_guidance_fn.mean_loss:
-                    g = g / numel
+                    g = g / torch.stack([torch.as_tensor(n_, device=g.device, dtype=g.dtype) for n_ in numels]).view(1, 1, -1, 1, 1)
                 grads.append(g)
                 if getattr(loss_guidance_fn, "save_dir", None) is not None:
                     decoded.append(D.detach())

@@ -277,6 +277,7 @@ class AutoencoderKLDecoder(nn.Module):
             self.encoder = Encoder(**ddconfig)
             self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
         self.decoder = Decoder(**ddconfig)
+        self._ch, self._ch_mult = int(ddconfig["ch"]), [int(m) for m in ddconfig["ch_mult"]]
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
 
         self._token_major = False
@@ -299,3 +300,24 @@ class AutoencoderKLDecoder(nn.Module):
         if self._token_major:
             z = z.contiguous(memory_format=torch.channels_last)
         return self.decoder(self.post_quant_conv(z))
+
+    #: frames per decoder / encoder call under `perframe_ae` (None: as many as fit the bounds below)
+    PERFRAME_GROUP_MAX = 32
+
+    def _frames_that_fit(self, x, latent):
+        """The convolution kernels address with 32-bit element offsets: the largest feature map of one call (full
+        resolution x ch * ch_mult[1] channels) has to stay below 2^31 elements."""
+        full = x.shape[-2] * x.shape[-1] * ((2 ** (len(self._ch_mult) - 1)) ** 2 if latent else 1)
+        return max(1, min(self.PERFRAME_GROUP_MAX, (2 ** 31 - 1) // max(1, full * self._ch * max(self._ch_mult[:2]))))
+
+    def perframe(self, fn, x, frames_per_call=None, latent=True):
+        """`perframe_ae` (ddpm3d.py:630-667) bounds VAE memory by running one frame per call -- sized for 40/80 GB parts.
+        Every normalisation in the VAE is per sample, so frames grouped into one call produce the same per-frame values;
+        with 288 GB the 25-frame video goes through in a few calls (full waves of workgroups per launch instead of
+        25 x 1.1), and `frames_per_call` brings the bound back for callers that need it."""
+        k = self._frames_that_fit(x, latent)
+        if frames_per_call:
+            k = max(1, min(k, int(frames_per_call)))
+        if x.shape[0] <= k:
+            return fn(x)
+        return torch.cat([fn(x[i:i + k]) for i in range(0, x.shape[0], k)], dim=0)

@@ -124,7 +124,8 @@ class _Duck(torch.nn.Module):
         return self.model(x) * (1 + c["c_crossattn"][0].mean())
 
     def differentiable_decode_first_stage(self, z):
-        return torch.tanh(self.first_stage_model(z[:, :, 0]))[:, :, None]
+        # any number of frames, like ddpm3d.py:646-667 (the golden's duck decodes the single frame the reference loop hands it)
+        return torch.stack([torch.tanh(self.first_stage_model(z[:, :, j])) for j in range(z.shape[2])], dim=2)
 
 
 def _duck_inputs():
@@ -170,6 +171,12 @@ def test_guided_ddim_step_matches_reference(index):
     ref_xp, ref_p0 = G[f"guided{index}_xprev"], G[f"guided{index}_x0"]
     np.testing.assert_allclose(p0.numpy(), ref_p0, rtol=2e-5, atol=2e-6 * np.abs(ref_p0).max())
     np.testing.assert_allclose(xp.numpy(), ref_xp, rtol=1e-4, atol=1e-5 * np.abs(ref_xp).max())
+    # the frame grouping of the decoder pass is a pure re-association: one frame per decode (the reference's loop) gives the same step
+    s.decode_group = 1
+    xp1, _ = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                             guidance_rescale=0.7, loss_guidance_fn=lg, noise=torch.tensor(G["step_noise0"]),
+                             renoise=torch.tensor(G["step_noise1"]))
+    np.testing.assert_allclose(xp1.numpy(), xp.numpy(), rtol=1e-5, atol=1e-6 * np.abs(ref_xp).max())
 
 
 def test_sampler_api_end_to_end_and_rng_order():
