@@ -945,6 +945,13 @@ int gn_rows_per_block(int N, long long S)
     const long long r = ((long long)N * S + 1023) / 1024;
     return (int)(r < 4 ? 4 : (r > 128 ? 128 : r));
 }
+int gn_stat_rows(int N, long long S)
+{
+    // statistics kernels end in 2 G fp64 atomics per block onto N x 2 G addresses: beyond ~2048 blocks those same-address
+    // atomics, not the reads, set the time (576x1024x128 map: 4608 blocks 168 us, 1.8 TB/s) -- so long strips for large maps
+    const long long r = ((long long)N * S + 2047) / 2048;
+    return (int)(r < 4 ? 4 : (r > 8192 ? 8192 : r));
+}
 int gn_chunks(int C, int G, long long S)
 {
     const long long L = (long long)(C / G) * S;
@@ -966,7 +973,7 @@ int gvd_group_norm_stats(const void* x, double* stats, int N, int C, long long S
         if (is_bf16) hipLaunchKernelGGL(k_gn_stats_ncs<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, stats, L, chunks);
         else hipLaunchKernelGGL(k_gn_stats_ncs<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, stats, L, chunks);
     } else {
-        const int rows = gn_rows_per_block(N, S);
+        const int rows = gn_stat_rows(N, S);
         dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
         if (is_bf16) hipLaunchKernelGGL(k_gn_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, stats, C, G, S, rows);
         else hipLaunchKernelGGL(k_gn_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, stats, C, G, S, rows);
@@ -1022,7 +1029,7 @@ int gvd_group_norm_bwd_stats(const void* x, const void* dy, const float* gamma, 
         if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_stats_ncs<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, coef, gamma, scratch, C, G, S, silu, chunks);
         else hipLaunchKernelGGL(k_gn_bwd_stats_ncs<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, coef, gamma, scratch, C, G, S, silu, chunks);
     } else {
-        const int rows = gn_rows_per_block(N, S);
+        const int rows = gn_stat_rows(N, S);
         dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
         if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, (const __bf16*)dy, coef, gamma, scratch, C, G, S, silu, rows);
         else hipLaunchKernelGGL(k_gn_bwd_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, (const _Float16*)dy, coef, gamma, scratch, C, G, S, silu, rows);

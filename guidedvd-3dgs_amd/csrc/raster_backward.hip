@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
     __shared__ float4 s_co[256];
     __shared__ float4 s_cd[256];
     __shared__ uint32_t s_ord[256];
-    __shared__ float s_part[4][256][kNV];
+    constexpr int NVS = DA ? kNV : kNV - 1;   // value 9 (the depth term) is exactly 0 without a depth gradient: not stored.
+    __shared__ float s_part[4][256][NVS];     // 36 KiB instead of 40: the workgroup's LDS drops under a third of the CU's 160 KiB (3 resident workgroups)
     __shared__ uint32_t s_wcount[4];
     __shared__ uint4 s_wcount4[4];
     __shared__ __attribute__((aligned(4))) uint16_t s_list[4][260];  // per quadrant (= wave): slots of the entries that can reach it
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         {
             float4* z = reinterpret_cast<float4*>(&s_part[0][0][0]);
 #pragma unroll
-            for (int i = 0; i < (4 * 256 * kNV / 4) / 256; i++) z[i * 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < (4 * 256 * NVS / 4) / 256; i++) z[i * 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         const unsigned long long m = __ballot(keep);
@@ -228,7 +229,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         wave_reduce10(V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9);                \
         if ((lane & 31) == 31) {                                                                  \
             float* o = &s_part[w][sl##J][(lane >> 5) * 5];                                        \
-            o[0] = V##0; o[1] = V##1; o[2] = V##2; o[3] = V##3; o[4] = V##4;                      \
+            o[0] = V##0; o[1] = V##1; o[2] = V##2; o[3] = V##3;                                   \
+            if (DA || lane < 32) o[4] = V##4;                                                     \
         }
         {
 #pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
@@ -246,7 +248,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                     wave_reduce20(p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, q0, q1, q2, q3, q4, q5, q6, q7, q8, q9);
                     if ((lane & 15) == 15) {  // row 0: A[0..4], row 1: B[0..4], row 2: A[5..9], row 3: B[5..9]
                         float* o = &s_part[w][(lane & 16) ? sl1 : sl0][(lane >> 5) * 5];
-                        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3; o[4] = p4;
+                        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3;
+                        if (DA || lane < 32) o[4] = p4;
                     }
                 } else if (any0) {
                     GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
@@ -277,8 +280,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             const uint32_t g = (id ? a.point_offsets[id - 1] : 0u) + k;
             float o[kNV];
 #pragma unroll
-            for (int q = 0; q < kNV; q++)
+            for (int q = 0; q < NVS; q++)
                 o[q] = ((s_part[0][slot][q] + s_part[1][slot][q]) + s_part[2][slot][q]) + s_part[3][slot][q];
+            if (!DA) o[kNV - 1] = 0.f;
             float4* dst = reinterpret_cast<float4*>(a.partials + (size_t)g * kPartialStride);
             dst[0] = make_float4(o[0], o[1], o[2], o[3]);
             dst[1] = make_float4(o[4], o[5], o[6], o[7]);
