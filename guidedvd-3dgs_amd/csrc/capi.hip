@@ -186,14 +186,7 @@ int forward_stage1(const FwdIn& in, const gvd::Layout& L, char* geom, char* img,
         launch_preprocess(pa, L.bin_blocks, L.lds_hist != 0, stream);
     }
     AFTER_LAUNCH("preprocess");
-    uint32_t* tile_count = (uint32_t*)(geom + L.tile_count);
-    if (L.lds_hist) {
-        ProfScope ps("colscan", stream);
-        launch_colscan((uint32_t*)(geom + L.hist), tile_count, L.bin_blocks, L.T, stream);
-    } else {
-        tile_count = (uint32_t*)(geom + L.hist);
-    }
-    AFTER_LAUNCH("colscan");
+    uint32_t* tile_count = L.lds_hist ? (uint32_t*)(geom + L.tile_count) : (uint32_t*)(geom + L.hist);
     TileScanArgs ta{};
     ta.T = L.T; ta.B = L.bin_blocks; ta.gx = L.gx; ta.capacity = capacity;
     ta.tile_count = tile_count; ta.block_total = (uint32_t*)(geom + L.block_total);
@@ -204,6 +197,11 @@ int forward_stage1(const FwdIn& in, const gvd::Layout& L, char* geom, char* img,
     ta.tile_order = (uint32_t*)(img + L.tile_order);
     ta.d_status = d_status;
     ta.host_mirror = mirror;
+    if (L.lds_hist) {
+        ProfScope ps("colscan", stream);
+        launch_colscan((uint32_t*)(geom + L.hist), tile_count, L.bin_blocks, L.T, stream);
+    }
+    AFTER_LAUNCH("colscan");
     {
         ProfScope ps("tilescan", stream);
         launch_tilescan(ta, stream);
@@ -225,6 +223,7 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     sa.means2D = (const float*)(geom + L.means2D); sa.depths = (const float*)(geom + L.depths);
     sa.radii = radii; sa.cursor = (uint32_t*)(geom + L.cursor);
     sa.point_offsets = (uint32_t*)(geom + L.point_offsets); sa.bucket = (uint64_t*)(bin + L.bucket);
+    sa.partials = (float*)(bin + L.partials);   // zeroed here for the backward (no memset launch there)
     {
         ProfScope ps("scatter", stream);
         launch_scatter(sa, L.bin_blocks, L.lds_hist != 0, stream);
@@ -440,8 +439,7 @@ int gvd_raster_backward_conf(
     }
     const Layout L = make_layout(P, width, height, cap);
     if (!radii) radii = (const int*)(geom + L.internal_radii);
-    float* partials = (float*)(bin + L.partials);
-    HIP_TRY(hipMemsetAsync(partials, 0, (size_t)(cap > 0 ? cap : 1) * kPartialStride * 4, stream));
+    float* partials = (float*)(bin + L.partials);   // zeroed by the forward's k_scatter; k_render_bwd overwrites what it reaches
     RenderBwdArgs ra{};
     ra.W = width; ra.H = height; ra.gx = L.gx; ra.gy = L.gy; ra.capacity = cap;
     ra.ranges = (const uint32_t*)(img + L.ranges); ra.point_list = (const uint32_t*)(bin + L.point_list);

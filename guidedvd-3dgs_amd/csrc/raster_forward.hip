@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "raster_kernels.h"
+#include "raster_layout.h"
 #include "raster_math.h"
 
 namespace gvd {
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256) k_preprocess(PreprocessArgs a)
 // segments of ceil(B/64) rows need 2 + 2 trips of 8 loads in flight for B = 782 where 16 segments needed 7 + 7.
 // ------------------------------------------------------------------------------------------------
 constexpr int kColTiles = 16, kColSegs = 1024 / kColTiles;
-__global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_count, int B, int T)
+__device__ __forceinline__ void colscan_body(uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_count, int B, int T)
 {
     __shared__ uint32_t s_seg[kColSegs][kColTiles];
     const int tl = threadIdx.x % kColTiles, seg = threadIdx.x / kColTiles;
@@ -190,6 +191,11 @@ __global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, u
         }
         if (seg == kColSegs - 1) tile_count[t] = run;  // the last segment's running total is the column total
     }
+}
+
+__global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_count, int B, int T)
+{
+    colscan_body(hist, tile_count, B, T);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -231,7 +237,7 @@ __device__ __forceinline__ int xcd_region(int t, int gx)
     return ((tx >> 1) + 3 * (ty >> 1)) & 7;
 }
 
-__global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
+__device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
@@ -336,6 +342,12 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a)
     }
 }
 
+__global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a) { tilescan_body(a); }
+
+// (A merged k_colscan + k_tilescan launch -- the last column-scan workgroup to arrive, by an agent-scope fence and a
+// counter, runs the tile scan -- was measured at 61 us against 8.6 + 12.3 us for the two launches: on a multi-XCD part the
+// release/acquire pair is a write-back / invalidate of the XCDs' private L2s.  A kernel boundary is the cheaper hand-off.)
+
 // ------------------------------------------------------------------------------------------------
 // k_scatter
 // ------------------------------------------------------------------------------------------------
@@ -383,6 +395,15 @@ __global__ void __launch_bounds__(256) k_scatter(ScatterArgs a)
                 }
         }
         __syncthreads();
+    }
+    // The block's instances are the contiguous slots [chunk_base, carry) of the backward's partial-record array
+    // (Gaussian order): zero them here, coalesced and under this kernel's atomic latency, instead of a 21 MB memset
+    // launch at the head of every backward.  k_render_bwd overwrites the records of the instances it reaches.
+    if (a.partials) {
+        const uint32_t beg = min(a.chunk_base[blockIdx.x], a.capacity), end = min(carry, a.capacity);
+        float4* z = reinterpret_cast<float4*>(a.partials);
+        for (size_t i = (size_t)beg * (kPartialStride / 4) + tid; i < (size_t)end * (kPartialStride / 4); i += 256)
+            z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 

@@ -33,6 +33,7 @@ struct ScatterArgs {
     const int* radii;
     uint32_t *cursor, *point_offsets;
     uint64_t* bucket;
+    float* partials;   // backward's partial records (kPartialStride floats per instance), zeroed per block; NULL: leave alone
 };
 
 struct SortArgs {
