@@ -129,7 +129,8 @@ class CrossAttention(nn.Module):
         if context is None:
             k, v = self.to_k(x), self.to_v(x)
             if frame_major:  # x [b, T, pixels, C]: one T-long sequence per pixel, read in place
-                out = torch.stack([ops.attention(q[i], k[i], v[i], self.heads, frame_major=True) for i in range(x.shape[0])], 0)
+                outs = [ops.attention(q[i], k[i], v[i], self.heads, frame_major=True) for i in range(x.shape[0])]
+                out = outs[0][None] if len(outs) == 1 else torch.stack(outs, 0)   # b = 1 (the sampler's case): a view, not a copy
             else:
                 out = ops.attention(q, k, v, self.heads)
         else:
