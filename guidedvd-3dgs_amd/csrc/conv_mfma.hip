@@ -60,6 +60,12 @@ struct ConvArgs {
     int cpg, G, R;
     int PB;               // temporal: pixels per tile
     int coef_per_n;       // 1: coef is [N][Cin], 0: one [Cin] vector for all n (temporal, batch 1)
+    // Input-gradient launches whose OUTPUT is the gradient w.r.t. silu(GroupNorm(bx)): `stats` then receives the two sums the
+    // GroupNorm backward needs per (sample, group) instead of sum / sum of squares (see the epilogue).
+    const void* bx;        // the norm's input, layout of out (nullptr: forward statistics)
+    const float2* bcoef;   // the norm's forward affine (a, b) per (n, channel) ([Cout] for all n when !bcoef_per_n)
+    const float* bgamma;   // the norm's weight [Cout]
+    int bsilu, bcoef_per_n;
 };
 
 constexpr int BK = 32;          // input channels per chunk
@@ -85,6 +91,12 @@ template <int PIX> struct Geo<2, PIX> {   // temporal: rows = (t, p), one zero h
 };
 
 __device__ __forceinline__ float silu32(float f) { return f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * f)); }
+// d silu(z) / dz = s (1 + z (1 - s)), s = sigmoid(z)  (the form of k_gn_bwd_*: diffusion_kernels.hip silu_grad_f)
+__device__ __forceinline__ float silu_grad32(float z)
+{
+    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * z));
+    return sg * fmaf(z, 1.f - sg, 1.f);
+}
 
 // dynamic LDS of one workgroup: weights + patch double buffers during the main loop, fp32 output staging + statistics scratch
 // in the epilogue (the two phases alias)
@@ -336,6 +348,11 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     float ssum[8], ssq[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { ssum[j] = 0.f; ssq[j] = 0.f; }
+    // GroupNorm-backward statistics mode: the forward affine of this thread's 8 channels (needed through silu' only) is
+    // re-read per pixel row from L1 -- held in registers it would cost 16 VGPRs in every mode of the 256-register tiles
+    const T* __restrict__ bx = (const T*)a.bx;
+    const float4* __restrict__ bcp = (bx && a.bsilu && full_oct)
+        ? reinterpret_cast<const float4*>(a.bcoef + (a.bcoef_per_n ? (size_t)n * Cout : 0) + cout0) : nullptr;
 
     constexpr int NPASS = PIX / EP_PIX;
     for (int pass = 0; pass < NPASS; pass++) {
@@ -378,12 +395,34 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 if (full_oct) {
                     vec8 rv = vec8{};
                     if (res) rv = *reinterpret_cast<const vec8*>(res + off + cout0);
+                    if (bx) {   // wave-uniform (kernel argument): sums of dz and dz * x, dz = d_out * silu'(a x + b); gamma applied per column below
+                        const vec8 xv = *reinterpret_cast<const vec8*>(bx + off + cout0);
+                        float sg[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
-                        const float f = (float)o[j];
-                        ssum[j] += f;
-                        ssq[j] = fmaf(f, f, ssq[j]);
+                        for (int j = 0; j < 8; j++) sg[j] = 1.f;
+                        if (bcp) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const float4 ab = bcp[j];
+                                sg[2 * j] = silu_grad32(fmaf((float)xv[2 * j], ab.x, ab.y));
+                                sg[2 * j + 1] = silu_grad32(fmaf((float)xv[2 * j + 1], ab.z, ab.w));
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
+                            const float dz = (float)o[j] * sg[j];
+                            ssum[j] += dz;
+                            ssq[j] = fmaf(dz, (float)xv[j], ssq[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
+                            const float f = (float)o[j];
+                            ssum[j] += f;
+                            ssq[j] = fmaf(f, f, ssq[j]);
+                        }
                     }
                     *reinterpret_cast<vec8*>(out + off + cout0) = o;
                 } else {
@@ -417,6 +456,12 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         for (int c = tid; c < BN; c += 256) {   // per-channel totals into row 0 (column-private: no race)
             float s = 0.f, q = 0.f;
             for (int rr = 0; rr < EP_ROWS; rr++) { s += red[rr * BN + c]; q += red[(EP_ROWS + rr) * BN + c]; }
+            if (bx) {   // backward statistics carry the norm's weight: sum gamma dz, sum gamma dz x
+                const int cg = co_tile * BN + c;
+                const float gm = cg < Cout ? a.bgamma[cg] : 0.f;
+                s *= gm;
+                q *= gm;
+            }
             red[c] = s;
             red[EP_ROWS * BN + c] = q;
         }
@@ -560,11 +605,16 @@ int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block
     return 0;
 }
 
-int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
-                  const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
-                  int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream_)
+static int conv_launch(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
+                       const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
+                       int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream_,
+                       const void* bwd_x, const float* bwd_coef, int bwd_coef_per_n, const float* bwd_gamma, int bwd_silu)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (bwd_x) {
+        if (!stats || !bwd_gamma || (bwd_silu && !bwd_coef) || (Cout & 7) || mode > 1 || upsample || ((uintptr_t)bwd_x & 15) || ((uintptr_t)bwd_coef & 15))
+            return fail(-1, "gvd_conv_mfma_norm_bwd: needs stats, gamma (and the forward affine with SiLU), Cout % 8 == 0, a stride-1 mode, aligned pointers");
+    }
     if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || mode < 0 || mode > 3)
         return fail(-1, "gvd_conv_mfma: bad arguments");
     if ((Cin & 7) || (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)residual) & 15))
@@ -595,6 +645,8 @@ int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int co
     a.nchunks = (Cin + BK - 1) / BK;
     a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
     a.coef_per_n = coef_per_n;
+    a.bx = bwd_x; a.bcoef = reinterpret_cast<const float2*>(bwd_coef); a.bgamma = bwd_gamma; a.bsilu = bwd_silu ? 1 : 0;
+    a.bcoef_per_n = bwd_coef_per_n;
     dim3 grid;
     grid.y = (Cout + BN - 1) / BN;
     hipError_t e;
@@ -615,6 +667,33 @@ int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int co
         e = is_bf16 ? launch_cfg<__bf16, 2>(cfg, a, grid, stream) : launch_cfg<_Float16, 2>(cfg, a, grid, stream);
     }
     if (e != hipSuccess) return fail(-2, "launch k_conv_mfma", e);
+    return 0;
+}
+
+int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
+                  const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
+                  int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream)
+{
+    return conv_launch(x, w_packed, coef, coef_per_n, bias, add_nc, residual, out, stats, stats_replicas, groups, mode, N, H, W,
+                       H_in, W_in, Cin, Cout, upsample, silu, is_bf16, stream, nullptr, nullptr, 0, nullptr, 0);
+}
+
+int gvd_conv_mfma_norm_bwd(const void* g, const void* w_packed_bwd, void* d_act, double* bwd_stats, int stats_replicas, int groups,
+                           int mode, int N, int H, int W, int Cin, int Cout, const void* norm_x, const float* norm_coef,
+                           int norm_coef_per_n, const float* norm_gamma, int norm_silu, int is_bf16, void* stream)
+{
+    return conv_launch(g, w_packed_bwd, nullptr, 0, nullptr, nullptr, nullptr, d_act, bwd_stats, stats_replicas, groups, mode, N, H, W,
+                       0, 0, Cin, Cout, 0, 0, is_bf16, stream, norm_x, norm_coef, norm_coef_per_n, norm_gamma, norm_silu);
+}
+
+int gvd_group_norm_merge(double* stats, const double* partial, int replicas, int merge, int N, int G, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!stats || !partial || replicas <= 0 || merge <= 0 || N <= 0 || G <= 0) return fail(-1, "gvd_group_norm_merge: bad arguments");
+    const int total = N * G * 2;
+    hipLaunchKernelGGL(k_gn_merge, dim3((total + 3) / 4), dim3(256), 0, stream, partial, stats, replicas, N * merge, merge, G, total);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_gn_merge", e);
     return 0;
 }
 

@@ -129,13 +129,25 @@ def norm_state(gn, x=None, partial=None, n_stat=None, merge=1, group=None, S_tot
 
 
 def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, silu=False, bias=None, add_nc=None,
-            residual=None, stats_groups=0, upsample=0, H_in=0, W_in=0):
+            residual=None, stats_groups=0, upsample=0, H_in=0, W_in=0, norm_bwd=None):
+    """One launch of the convolution kernel.  norm_bwd = (norm_x, NormState, silu): this is an input-gradient launch whose
+    output is the gradient w.r.t. silu?(GroupNorm(norm_x)); the returned sums are then the GroupNorm-BACKWARD statistics
+    (gvd_conv_mfma_norm_bwd) instead of the forward ones."""
     P = ctypes.c_void_p
     out = torch.empty((N, W, Cout) if mode == TEMPORAL else (N, H, W, Cout), dtype=x.dtype, device=x.device)
     sums = None
     if stats_groups:
         n_stat = 1 if mode == TEMPORAL else N
         sums = torch.zeros(STATS_REPLICAS, n_stat, stats_groups, 2, dtype=torch.float64, device=x.device)
+    if norm_bwd is not None:
+        nx, ns, nsilu = norm_bwd
+        with ops._on(x.device):
+            rc = ops.lib().gvd_conv_mfma_norm_bwd(P(x.data_ptr()), P(wpk.data_ptr()), P(out.data_ptr()), P(sums.data_ptr()),
+                                                  STATS_REPLICAS, stats_groups, mode, N, H, W, Cin, Cout, P(nx.data_ptr()),
+                                                  P(ns.coef_ptr), 0 if mode == TEMPORAL else 1, P(ns.gamma32.data_ptr()),
+                                                  int(bool(nsilu)), 1 if x.dtype == torch.bfloat16 else 0, P(ops._stream()))
+        ops._check(rc)
+        return out, PartialStats(sums, STATS_REPLICAS, sums.shape[1], stats_groups, 0)
     with ops._on(x.device):
         rc = ops.lib().gvd_conv_mfma(P(x.data_ptr()), P(wpk.data_ptr()), P(coef_ptr), coef_per_n,
                                      P(bias.data_ptr() if bias is not None else None),
@@ -149,6 +161,35 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
         S = N * W if mode == TEMPORAL else H * W
         return out, PartialStats(sums, STATS_REPLICAS, sums.shape[1], stats_groups, S)
     return out, None
+
+
+FUSE_NORM_BACKWARD_STATS = True   # False: separate statistics pass (k_gn_bwd_stats_*), for A/B runs and tests
+
+
+def _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cg, Cn):
+    """gx = d/dx of conv(act(GroupNorm(x))) given g = d/d(conv output): the input-gradient convolution with the GroupNorm-backward
+    statistics in its epilogue (gvd_conv_mfma_norm_bwd), the replica merge, (sharded norms: a 2 G-double all-reduce) and the apply pass."""
+    P, LL = ctypes.c_void_p, ctypes.c_longlong
+    x = x.contiguous()
+    dev, bf = x.device, 1 if x.dtype == torch.bfloat16 else 0
+    gx = torch.empty_like(x)
+    n_stat = 1 if mode == TEMPORAL else N
+    if n_stat != ns.N:
+        raise RuntimeError(f"fused_conv backward: norm state spans {ns.N} samples, the convolution {n_stat}")
+    d_act, partial = _launch(g, wT, Cn, mode, N, H, W, Cg, stats_groups=ns.G, norm_bwd=(x, ns, silu))
+    part = partial.sums
+    scratch = torch.empty(2 * ns.N * ns.G + ns.N * ns.C, dtype=torch.float64, device=dev)
+    S = x.numel() // (ns.N * ns.C)
+    L, st = ops.lib(), P(ops._stream())
+    with ops._on(dev):
+        ops._check(L.gvd_group_norm_merge(P(scratch.data_ptr()), P(part.data_ptr()), STATS_REPLICAS, 1, ns.N, ns.G, st))
+        if ns.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(scratch[:2 * ns.N * ns.G], group=ns.group)
+        ops._check(L.gvd_group_norm_bwd_apply(P(x.data_ptr()), P(d_act.data_ptr()), P(gx.data_ptr()), P(ns.buf.data_ptr()),
+                                              P(scratch.data_ptr()), ns.N, ns.C, LL(S), LL(ns.S if ns.group is not None else S), ns.G,
+                                              ctypes.c_float(ns.eps), int(bool(silu)), 1, bf, st))
+    return gx
 
 
 def _geometry(x, mode, upsample):
@@ -218,7 +259,12 @@ class _FusedConvFn(torch.autograd.Function):
                     d_act = d_act[:, :H_in, :W_in].contiguous()
             else:
                 BN, _, _ = config(mode, N, H, W, Cout + pad, Cin)
-                d_act, _ = _launch(g, packed(weight, BN, True, pad, gout.dtype), Cin, mode, N, H, W, Cout + pad)
+                wT = packed(weight, BN, True, pad, gout.dtype)
+                if ns is not None and not upsample and FUSE_NORM_BACKWARD_STATS:
+                    # the GroupNorm-backward statistics come out of the input-gradient convolution's epilogue
+                    gx = _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cout + pad, Cin)
+                    return gx, (gout if has_res else None), None, None, None, None, None, None, None, None
+                d_act, _ = _launch(g, wT, Cin, mode, N, H, W, Cout + pad)
             if upsample:   # nearest x2 backward: each input pixel fed a 2x2 block
                 d_act = d_act.reshape(N, H // 2, 2, W // 2, 2, Cin).sum(dim=(2, 4))
             if ns is None:

@@ -138,6 +138,23 @@ int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int co
                   const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
                   int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream);
 
+/* The input gradient of a convolution whose input was silu?(GroupNorm(x)) -- the autograd backward of the fused
+ * `GroupNorm32 -> SiLU -> conv` pair of ResBlock / TemporalConvBlock / the VAE resnet blocks (openaimodel3d.py:259-268, 152-156,
+ * ae_modules.py:90-128) inside ddim_guidance.py:318-345.  d_act = conv(g, w_packed_bwd) exactly as gvd_conv_mfma computes it
+ * (mode 0 | 1; Cin = channels of g, Cout = channels of the norm), AND the epilogue accumulates, from the rounded d_act and the
+ * norm's input `norm_x` (layout of d_act), the two per-(sample, group) sums gvd_group_norm_bwd_apply needs:
+ *   bwd_stats[r][n][g] += ( sum gamma_c dz ,  sum gamma_c dz x ),   dz = d_act * (norm_silu ? silu'(a x + b) : 1)
+ * -- the statistics pass of the GroupNorm backward (two full reads of x and d_act) disappears.  norm_coef: the norm's forward
+ * affine (a, b) [N][Cout] (norm_coef_per_n = 1) or [Cout] (0), NULL allowed without SiLU; norm_gamma fp32 [Cout].
+ * bwd_stats: fp64 [stats_replicas][Nstat][groups][2], zeroed by the caller; merge the replicas with gvd_group_norm_merge into
+ * the first 2 N G doubles of the scratch gvd_group_norm_bwd_apply takes.  Cout % 8 == 0. */
+int gvd_conv_mfma_norm_bwd(const void* g, const void* w_packed_bwd, void* d_act, double* bwd_stats, int stats_replicas, int groups,
+                           int mode, int N, int H, int W, int Cin, int Cout, const void* norm_x, const float* norm_coef,
+                           int norm_coef_per_n, const float* norm_gamma, int norm_silu, int is_bf16, void* stream);
+
+/* stats[n][g][0..1] = sum over replicas r and m < merge of partial[r][n*merge + m][g][0..1]  (N outputs). */
+int gvd_group_norm_merge(double* stats, const double* partial, int replicas, int merge, int N, int G, void* stream);
+
 /* Tile configuration gvd_conv_mfma uses for a problem: BN = output channels per workgroup (the packing granule of
  * w_packed), pixels per workgroup tile, tile width (16 | 32; 0 in mode 1). */
 int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block_n, int* tile_pixels, int* tile_width);

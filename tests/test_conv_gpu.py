@@ -223,6 +223,43 @@ def test_conv_input_gradients_match_autograd_of_the_fp32_form():
     assert _rel(gx3, gx3r) < 4e-3
 
 
+@pytest.mark.parametrize("mode,shape,C,Cout,silu,dtype", [
+    ("spatial", (3, 18, 32), 320, 640, True, torch.float16), ("spatial", (2, 9, 16), 128, 128, False, torch.float16),
+    ("spatial", (2, 20, 24), 160, 320, True, torch.bfloat16), ("temporal", (25, 50), 320, 320, True, torch.float16),
+    ("temporal", (7, 33), 64, 128, False, torch.float16)])
+def test_norm_backward_statistics_from_the_dgrad_epilogue(mode, shape, C, Cout, silu, dtype):
+    """gvd_conv_mfma_norm_bwd: the GroupNorm-backward sums accumulated in the input-gradient convolution's epilogue give the
+    same input gradient as the separate statistics pass (k_gn_bwd_stats_*) -- both sum the same rounded d_act in fp32 partials
+    and fp64 totals, so they agree to the 16-bit rounding of dx -- and both match fp32 autograd of the same expression."""
+    from lvdm_amd import conv as C_
+    g = torch.Generator(device=DEV).manual_seed(314)
+    x = (torch.randn(*shape, C, device=DEV, generator=g) * 1.3 + 0.3).to(dtype).requires_grad_(True)
+    m = _conv_module(C, Cout, 5, three_d=(mode == "temporal"))
+    gn = nn.GroupNorm(32, C).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, device=DEV, generator=g) * 0.5 + 1.0)
+        gn.bias.copy_(torch.randn(C, device=DEV, generator=g) * 0.3)
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    cmode = C_.TEMPORAL if mode == "temporal" else C_.SPATIAL
+    outs = {}
+    for fuse in (True, False):
+        C_.FUSE_NORM_BACKWARD_STATS = fuse
+        try:
+            y, _ = C_.fused_conv(x, m, mode=cmode, gn=gn, silu=silu)
+            gy = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7)).to(dtype)
+            (outs[fuse],) = torch.autograd.grad(y, [x], gy)
+        finally:
+            C_.FUSE_NORM_BACKWARD_STATS = True
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 3e-3
+    assert _rel(outs[True], outs[False]) < tol, _rel(outs[True], outs[False])
+    xf = x.detach().float().requires_grad_(True)
+    n_stat = 1 if mode == "temporal" else shape[0]
+    yr = C_._reference(xf, m.weight.float(), m.bias.float(), cmode, False, gn, silu, None, None, n_stat)
+    (gr,) = torch.autograd.grad(yr, [xf], gy.float())
+    assert _rel(outs[True], gr) < (4e-2 if dtype == torch.bfloat16 else 6e-3), _rel(outs[True], gr)
+
+
 def test_conv_bf16_and_rejections():
     from lvdm_amd import conv as C
     m = _conv_module(64, 64, 1)
