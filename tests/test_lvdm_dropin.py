@@ -193,3 +193,61 @@ def test_small_model_runs_the_reference_call_sequence_end_to_end():
     finally:
         ops.use_reference_math(False)
     assert out.shape == (1, 1, 3, T, H, W) and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_small_model_on_the_device_matches_its_cpu_reference_form_with_guidance():
+    """The same miniature class tree, built once, driven through `image_guided_synthesis` with the GUIDED lvdm sampler twice:
+    on the CPU with the reference formulation of every operator (fp32) and on the GPU through the product path
+    (`_prepare_native`: fp16 token-major U-Net and VAE, MFMA convolutions with fused norms, flash attention at the 64-wide heads,
+    grouped VAE decode + backward inside the step).  Same noise (drawn on the CPU generator), so the two videos agree to the
+    accumulated fp16 rounding of 3 guided steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    from lvdm_amd import ops, pipeline, samplers
+    from lvdm_amd.guidance import LossGuidance
+    from lvdm_amd.model import instantiate_from_config
+    from fill_by_name import fill_by_name
+    clip = dict(embed_dim=32, text_width=32, text_layers=2, text_heads=2, vocab=64, ctx=77,
+                vision_cfg=dict(width=48, layers=2, heads=2, patch=8, image=32))
+    node = _yaml_model_node(clip, unet_over=dict(model_channels=64, num_head_channels=64, context_dim=32, channel_mult=[1, 2],
+                                                 attention_resolutions=[2, 1], num_res_blocks=1, use_checkpoint=False),
+                            vae_over=dict(ch=32, ch_mult=[1, 2], num_res_blocks=1, resolution=32))
+    node["params"]["image_proj_stage_config"]["params"].update(dim=32, depth=1, dim_head=16, heads=2, num_queries=2, embedding_dim=48,
+                                                              output_dim=32, video_length=3)
+    torch.manual_seed(0)
+    model = instantiate_from_config(node)
+    fill_by_name(model.model, std=0.05)
+    fill_by_name(model.first_stage_model, std=0.05)
+    model.eval()
+    T, H, W = 3, 32, 48
+    g = torch.Generator().manual_seed(11)
+    videos = torch.rand(1, 3, T, H, W, generator=g) * 2 - 1
+    tokens = torch.randint(0, 64, (1, 77), generator=g)
+    glc = model.get_learned_conditioning
+    model.get_learned_conditioning = lambda prompts: glc(tokens.to(model.device).expand(len(prompts), -1))
+
+    def run(dev):
+        model.to(dev)
+        lg = LossGuidance(ddim_steps=3, recur_steps=1)
+        lg.set_hw(H, W)
+        lg.set_guidance_images((videos[0].permute(1, 0, 2, 3) * 0.5).to(dev))      # [T, 3, H, W]
+        lg.set_guidance_masks(torch.ones(T, 1, H, W, device=dev))
+        torch.manual_seed(5)
+        samplers.DDIMSampler.noise_device = "cpu"   # the draws of both runs come from the CPU generator
+        try:
+            return pipeline.image_guided_synthesis(model, ["a room"], videos.to(dev), [1, 4, T, H // 2, W // 2], 1, 3, 1.0, 7.5, None,
+                                                   10, True, False, "uniform_trailing", 0.7, [0], lg, False).float().cpu()
+        finally:
+            samplers.DDIMSampler.noise_device = "device"
+
+    ops.use_reference_math(True)
+    try:
+        ref = run("cpu")
+    finally:
+        ops.use_reference_math(False)
+    out = run("cuda:0")
+    assert next(model.model.diffusion_model.parameters()).dtype == torch.float16      # converted once by _prepare_native
+    assert out.shape == ref.shape == (1, 1, 3, T, H, W) and torch.isfinite(out).all()
+    err = float((out - ref).abs().max() / ref.abs().max())
+    assert err < 5e-2, err
