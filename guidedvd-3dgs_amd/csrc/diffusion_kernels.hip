@@ -23,6 +23,10 @@
 #ifndef GVD_ATTN_QMAJOR
 #define GVD_ATTN_QMAJOR 0
 #endif
+// (Measured, not kept: online softmax + P V per 32-key HALF of a tile, so that a wave's own softmax VALU of half 0 issues under
+//  the S MFMAs of half 1 and the P V MFMAs of half 0 under the softmax of half 1: 723 against 734 TFLOP/s at L0 on the same box.
+//  Per 64-key tile and wave the loop issues ~240 VALU + 64 v_exp against 32 MFMAs -- ~1650 VALU cycles, 1024 MFMA cycles -- and
+//  sits at 57 % / 35 % of the two pipes: dependency stalls with two resident waves per SIMD at 252 VGPRs, not issue order.)
 #ifndef GVD_ATTN_HOIST
 #define GVD_ATTN_HOIST 0   // 1 = pin the clustered LDS fragment reads with sched_barrier (measured 774 vs 788 TFLOP/s: off)
 #endif
