@@ -43,10 +43,11 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--workload", choices=["all", "raster", "ddim", "ddim_guided", "config4"], default="all",
+    ap.add_argument("--workload", choices=["all", "raster", "ddim", "ddim_guided", "config4", "pipeline"], default="all",
                     help="all = raster line + `ddim` object (default, the driver's line); raster = BASELINE configs[1] only; "
                          "ddim / ddim_guided = configs[2] as a line of its own; config4 = BASELINE configs[3]: the raster training "
-                         "loop and the guided diffusion co-resident on one GPU at the train_guidedvd.py cadence")
+                         "loop and the guided diffusion co-resident on one GPU at the train_guidedvd.py cadence; pipeline = one whole "
+                         "ViewCrafter inference call (viewcrafter.py:92-112) through the drop-in lvdm class tree: seconds per 25-frame video")
     ap.add_argument("--c4-iters", type=int, default=260, help="config4: raster training iterations between diffusion runs")
     ap.add_argument("--c4-ddim-steps", type=int, default=6, help="config4: timed guided DDIM steps per diffusion run (of 50)")
     ap.add_argument("--c4-rounds", type=int, default=2, help="config4: (iterations, diffusion run) rounds")
@@ -61,6 +62,8 @@ def main():
     ap.add_argument("--instance-capacity", type=int, default=0,
                     help="raster: sync-free forward with this (Gaussian, tile) instance capacity (0 = reference behaviour)")
     ap.add_argument("--graph", action="store_true", help="ddim: replay the U-Net evaluations from a captured hipGraph")
+    ap.add_argument("--pipeline-ddim-steps", type=int, default=50, help="pipeline: DDIM steps per video")
+    ap.add_argument("--pipeline-videos", type=int, default=1, help="pipeline: timed videos")
     ap.add_argument("--ae-frames", type=int, default=None, help="ddim_guided / config4: frames per VAE decoder forward/backward in the guided step (default 5; 1 = the reference's per-frame loop)")
     ap.add_argument("--batch-cfg", action="store_true", help="ddim: evaluate cond/uncond as one batch-2 U-Net call")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -89,6 +92,8 @@ def main():
     try:
         if args.workload == "config4":
             line = config4_run(args, dev, rank, world)
+        elif args.workload == "pipeline":
+            line = pipeline_run(args, dev, rank, world)
         elif args.workload in ("ddim", "ddim_guided"):
             line = ddim_run(args, dev, rank, world, guided=args.workload == "ddim_guided", steps=min(args.steps, 50),
                             warm=min(args.warmup, 5), cpu_leg_wanted=not args.no_cpu_baseline)
@@ -443,6 +448,66 @@ def config4_run(args, dev, rank, world):
                            "speedup_vs_3h": round(3 * 3600 / full_s, 1), "speedup_vs_4h": round(4 * 3600 / full_s, 1),
                            "note": "derived: covers the hot path only (raster fwd/bwd + loss + Adam, guided sampler); DUSt3R, "
                                    "densification, trajectory search and I/O of the reference loop are outside it"}}
+
+
+def pipeline_run(args, dev, rank, world):
+    """One whole ViewCrafter inference call as the reference drives it (viewcrafter.py:92-112 -> diffusion_utils.py:118-223):
+    CLIP ViT-H/14 image tower + Resampler on the conditioning frame (cond and uncond), text tower, KL-VAE encode of the 25
+    rendered frames, DDIM-50 (unguided, CFG 7.5, rescale 0.7, eta 1), KL-VAE decode of the 25 frames at 576x1024 -- through the
+    drop-in `lvdm` class tree built from the mapping of configs/inference_pvd_1024.yaml (2.6 B parameters, random init, no
+    checkpoints offline; zero-init modules re-randomised).  The ViewCrafter README quotes this call at ~120 s on an A100
+    (third_party/ViewCrafter/README.md:116-118); a step = one whole video."""
+    import argparse as _ap
+    import torch
+    assert world == 1, "pipeline is a single-GPU workload"
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_lvdm_dropin import _yaml_model_node           # the yaml's `model:` node as a plain mapping
+    from lvdm_amd import pipeline
+    from lvdm_amd.model import instantiate_from_config
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = instantiate_from_config(_yaml_model_node())
+    model = model.to(dev)                     # as viewcrafter.py:331 does: the schedule tables are built on the host
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for p_ in model.model.parameters():   # re-randomise zero-init modules, std 0.02 (a fresh U-Net is degenerate)
+            if float(p_.abs().max()) == 0.0:
+                p_.copy_(torch.randn(p_.shape, device=dev, generator=g) * 0.02)
+    model.eval()
+    T, H, W = args.frames, args.ddim_height, args.ddim_width
+    tokens = torch.zeros(1, 77, dtype=torch.long, device=dev)
+    tokens[0, 0], tokens[0, 1:8], tokens[0, 8] = 49406, torch.arange(320, 327, device=dev), 49407   # a short caption's ids
+    glc = model.get_learned_conditioning
+    model.get_learned_conditioning = lambda prompts: glc(tokens.expand(len(prompts), -1))   # no BPE vocabulary offline
+    opts = _ap.Namespace(prompt="Rotating view of a scene", n_samples=1, ddim_steps=args.pipeline_ddim_steps, ddim_eta=1.0,
+                         unconditional_guidance_scale=7.5, cfg_img=None, frame_stride=10, text_input=True, multiple_cond_cfg=False,
+                         timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    renders = torch.rand(T, H, W, 3, device=dev, generator=g)
+    noise_shape = [1, 4, T, H // 8, W // 8]
+
+    def one():
+        return pipeline.run_diffusion(model, renders, noise_shape, opts, loss_guidance_fn=None, no_guidance=True)
+
+    one_warm = _ap.Namespace(**vars(opts))
+    one_warm.ddim_steps = 2
+    pipeline.run_diffusion(model, renders, noise_shape, one_warm, None, True)       # warm-up: kernels, tuning tables, allocator
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    times = []
+    for _ in range(max(1, args.pipeline_videos)):
+        t0 = time.perf_counter()
+        video = one()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    assert video.shape == (T, H, W, 3) and torch.isfinite(video).all()
+    sec = sum(times) / len(times)
+    return {"metric": "viewcrafter_seconds_per_video", "value": round(sec, 2), "unit": "s", "n_gpus": 1, "steps": len(times),
+            "warmup": 1, "ms_per_step": round(1e3 * sec, 1), "higher_is_better": False, "scaling": "weak",
+            "vs_baseline": round(120.0 / sec, 2), "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"whole ViewCrafter inference call, {T} frames {H}x{W}, DDIM-{opts.ddim_steps}, CFG 7.5: CLIP image + text "
+                                   "towers, Resampler, VAE encode, sampler, VAE decode (lvdm drop-in class tree, random init)",
+                       "baseline_note": "vs_baseline = 120 s (ViewCrafter README, A100, third_party/ViewCrafter/README.md:116-118) / value"},
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
 
 
 def _init_dist(dist, torch, local_rank):
