@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "raster_kernels.h"
 #include "raster_layout.h"
@@ -172,7 +173,11 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         const float pw##J = gauss_power(con##J.x, con##J.y, con##J.z, DX, DY);                    \
         const float G = __expf(pw##J);                                                            \
         const float ALPHA = fminf(0.99f, con##J.w * G);                                           \
-        const bool ACT = (s_ord[sl##J] < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);
+        const bool ACT = (s_ord[sl##J] < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);  \
+        /* wave-level "any lane active": the AND of the three compares' lane masks (ballot of a plain compare IS its SGPR   \
+           mask; __any / ballot of the combined bool goes through v_cndmask 0/1 + v_cmp_ne) */                            \
+        const bool any##J = (__builtin_amdgcn_ballot_w64(s_ord[sl##J] < last_contributor) &                               \
+                             __builtin_amdgcn_ballot_w64(!(pw##J > 0.0f)) & __builtin_amdgcn_ballot_w64(!(ALPHA < 1.0f / 255.0f))) != 0ull;
 // Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the value the next
 // active entry would have formed (pushing (last_alpha=0, .) is the identity: fmaf(1, acc, 0*c) == acc
 // bit-exactly) and all ten terms are exactly 0 -- no per-variable selects needed.
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                 dL_dopa = fmaf(1.f - acc_a, dLa, dL_dopa);                                        \
             }                                                                                     \
             dL_dopa *= T;                                                                         \
-            if (has_bg) { /* (-T_final / (1 - alpha)) * (bg . dL_dpix): quotient refined by one residual step */ \
+            if (BG) { /* (-T_final / (1 - alpha)) * (bg . dL_dpix): quotient refined by one residual step */ \
                 float qb = nTf * rinv;                                                            \
                 qb = fmaf(fmaf(-one_m_a, qb, nTf), rinv, qb);                                     \
                 dL_dopa = fmaf(qb, bg_dot, dL_dopa);                                              \
@@ -232,8 +237,11 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             o[0] = V##0; o[1] = V##1; o[2] = V##2; o[3] = V##3;                                   \
             if (DA || lane < 32) o[4] = V##4;                                                     \
         }
-        {
+        // The walk is instantiated twice, with and without the background term (6 VALU instructions per entry that are
+        // exactly zero for the black background of train_guidedvd.py:301): one wave-uniform branch per batch picks.
+        auto walk = [&](auto bg_tag) {
 #pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
+            constexpr bool BG = decltype(bg_tag)::value;
             uint32_t j = 0;
             uint32_t pair = my_list[0];   // slots of entries j, j+1 (prefetched one trip ahead; the list is padded)
             for (; j + 2 <= n; j += 2) {
@@ -241,7 +249,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                 pair = my_list[(j >> 1) + 1];
                 GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
                 GVD_BWD_GEOM(1, dx1, dy1, G1, alpha1, act1)
-                const bool any0 = __any(act0), any1 = __any(act1);
                 if (any0 && any1) {
                     GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
                     GVD_BWD_TERMS(1, dx1, dy1, G1, alpha1, act1, q)
@@ -262,12 +269,14 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
             if (j < n) {
                 const uint32_t sl0 = pair & 0xffffu;
                 GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
-                if (__any(act0)) {
+                if (any0) {
                     GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
                     GVD_BWD_STORE10(0, p)
                 }
             }
-        }
+        };
+        if (has_bg) walk(std::true_type{});
+        else walk(std::false_type{});
 #undef GVD_BWD_STORE10
 #undef GVD_BWD_GEOM
 #undef GVD_BWD_TERMS

@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         }
         uint32_t j = 0;
         for (; j + 4 <= n; j += 4) {
-            if (__all(T == 0.0f)) break;  // wave-uniform: this quadrant is finished
+            if (__builtin_amdgcn_ballot_w64(T != 0.0f) == 0ull) break;  // wave-uniform: this quadrant is finished
             const float2 xy0 = s_xy[j], xy1 = s_xy[j + 1], xy2 = s_xy[j + 2], xy3 = s_xy[j + 3];
             const float4 co0 = s_co[j], co1 = s_co[j + 1], co2 = s_co[j + 2], co3 = s_co[j + 3];
             const float4 cd0 = s_cd[j], cd1 = s_cd[j + 1], cd2 = s_cd[j + 2], cd3 = s_cd[j + 3];
