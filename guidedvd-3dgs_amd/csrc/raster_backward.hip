@@ -30,10 +30,10 @@ constexpr int kNV = 10;  // reduced values per (Gaussian, tile)
 template <bool DA>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 {
-    __shared__ float2 s_xy[256];
-    __shared__ float4 s_co[256];
+    // per staged entry one 32-byte record {x, y, list position (bits), -, conic a b c, opacity}: one address (slot << 5) and two
+    // 16-byte reads per entry in the walk instead of three arrays with three strides
+    __shared__ float4 s_rec[2 * 256];
     __shared__ float4 s_cd[256];
-    __shared__ uint32_t s_ord[256];
     constexpr int NVS = DA ? kNV : kNV - 1;   // value 9 (the depth term) is exactly 0 without a depth gradient: not stored.
     __shared__ float s_part[4][256][NVS];     // 36 KiB instead of 40: the workgroup's LDS drops under a third of the CU's 160 KiB (3 resident workgroups)
     __shared__ uint32_t s_wcount[4];
@@ -141,10 +141,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         }
         const uint32_t slot = wbase + (uint32_t)__popcll(m & below);
         if (keep) {
-            s_xy[slot] = xy;
-            s_co[slot] = co;
+            s_rec[2 * slot] = make_float4(xy.x, xy.y, __uint_as_float(ord), 0.f);
+            s_rec[2 * slot + 1] = co;
             s_cd[slot] = cd;
-            s_ord[slot] = ord;
             if (smask & 1u) s_list[0][base.x + (uint32_t)__popcll(m0 & below)] = (uint16_t)slot;
             if (smask & 2u) s_list[1][base.y + (uint32_t)__popcll(m1 & below)] = (uint16_t)slot;
             if (smask & 4u) s_list[2][base.z + (uint32_t)__popcll(m2 & below)] = (uint16_t)slot;
@@ -167,16 +166,17 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 // doubled the dL_dscales error and was rejected.
 #define GVD_BWD_RCP(D) ([&] { const float r0_ = __builtin_amdgcn_rcpf(D); return fmaf(fmaf(-(D), r0_, 1.0f), r0_, r0_); }())
 #define GVD_BWD_GEOM(J, DX, DY, G, ALPHA, ACT)                                                    \
-        const float2 gxy##J = s_xy[sl##J];                                                        \
-        const float4 con##J = s_co[sl##J];                                                        \
+        const float4 gxy##J = s_rec[2 * sl##J];                                                   \
+        const float4 con##J = s_rec[2 * sl##J + 1];                                               \
+        const uint32_t ord##J = __float_as_uint(gxy##J.z);                                        \
         const float DX = gxy##J.x - pixfx, DY = gxy##J.y - pixfy;                                 \
         const float pw##J = gauss_power(con##J.x, con##J.y, con##J.z, DX, DY);                    \
         const float G = __expf(pw##J);                                                            \
         const float ALPHA = fminf(0.99f, con##J.w * G);                                           \
-        const bool ACT = (s_ord[sl##J] < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);  \
+        const bool ACT = (ord##J < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);  \
         /* wave-level "any lane active": the AND of the three compares' lane masks (ballot of a plain compare IS its SGPR   \
            mask; __any / ballot of the combined bool goes through v_cndmask 0/1 + v_cmp_ne) */                            \
-        const bool any##J = (__builtin_amdgcn_ballot_w64(s_ord[sl##J] < last_contributor) &                               \
+        const bool any##J = (__builtin_amdgcn_ballot_w64(ord##J < last_contributor) &                                     \
                              __builtin_amdgcn_ballot_w64(!(pw##J > 0.0f)) & __builtin_amdgcn_ballot_w64(!(ALPHA < 1.0f / 255.0f))) != 0ull;
 // Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the value the next
 // active entry would have formed (pushing (last_alpha=0, .) is the identity: fmaf(1, acc, 0*c) == acc
