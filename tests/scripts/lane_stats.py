@@ -31,6 +31,7 @@ xy, co, ncon = v["means2D"], v["conic_opacity"], v["n_contrib"].long()
 tot_pairs = act_pairs = 0
 steps = {16: 0, 8: 0, 4: 0, 2: 0}
 rect84 = rect48 = bbox4 = bbox4q = 0
+steps_8x8 = steps_pair84 = steps_pair48 = steps_quad44 = 0   # wave steps: one list per quadrant / max over its 2 halves / its 4 blocks
 fwd_live = 0
 yy, xx = torch.meshgrid(torch.arange(16, device=dev), torch.arange(16, device=dev), indexing="ij")
 for tile in range(gx * gy):
@@ -58,6 +59,14 @@ for tile in range(gx * gy):
     A = act.reshape(n, 16, 16)
     for bs in steps:
         steps[bs] += int(A.reshape(n, 16 // bs, bs, 16 // bs, bs).any(dim=4).any(dim=2).sum())
+    q88 = A.reshape(n, 2, 8, 2, 8).any(dim=4).any(dim=2).sum(dim=0)                      # [2, 2] list length per quadrant
+    h84 = A.reshape(n, 2, 2, 4, 2, 8).any(dim=5).any(dim=3).sum(dim=0)                   # [qy, half, qx]: 8 wide x 4 high halves
+    h48 = A.reshape(n, 2, 8, 2, 2, 4).any(dim=5).any(dim=2).sum(dim=0)                   # [qy, qx, half]: 4 wide x 8 high halves
+    b44 = A.reshape(n, 2, 2, 4, 2, 2, 4).any(dim=6).any(dim=3).sum(dim=0)                # [qy, sy, qx, sx]
+    steps_8x8 += int(q88.sum())
+    steps_pair84 += int(h84.max(dim=1).values.sum())
+    steps_pair48 += int(h48.max(dim=2).values.sum())
+    steps_quad44 += int(b44.permute(0, 2, 1, 3).reshape(2, 2, 4).max(dim=2).values.sum())
     rect84 += int(A.reshape(n, 4, 4, 2, 8).any(dim=4).any(dim=2).sum())   # blocks 8 wide x 4 high
     rect48 += int(A.reshape(n, 2, 8, 4, 4).any(dim=4).any(dim=2).sum())
     # bounding box of the alpha >= 1/255 ellipse (q <= tau = log(255 o)): half extents sqrt(2 tau C / det), sqrt(2 tau A / det)
@@ -81,5 +90,7 @@ for tile in range(gx * gy):
     bbox4q += int(bbq.sum())
 print(f"R={R}  list pairs (R*256)={tot_pairs/1e6:.1f} M   active pairs={act_pairs/1e6:.2f} M ({act_pairs/tot_pairs:.3f})")
 print(f"  perfect 8x4: {rect84/1e6:.3f} M  4x8: {rect48/1e6:.3f} M   bbox 4x4: {bbox4/1e6:.3f} M   bbox & exact-8x8: {bbox4q/1e6:.3f} M")
+print(f"  WAVE steps with perfect culls: one list per 8x8 quadrant {steps_8x8/1e6:.3f} M | two 8x4 halves, max {steps_pair84/1e6:.3f} M | "
+      f"two 4x8 halves, max {steps_pair48/1e6:.3f} M | four 4x4 blocks, max {steps_quad44/1e6:.3f} M")
 for bs, s in steps.items():
     print(f"  perfect cull at {bs}x{bs}: {s/1e6:.3f} M (entry, block) steps = {s*bs*bs/1e6:.1f} M lane slots, useful {act_pairs/(s*bs*bs):.3f}")
