@@ -27,6 +27,9 @@
 //  the S MFMAs of half 1 and the P V MFMAs of half 0 under the softmax of half 1: 723 against 734 TFLOP/s at L0 on the same box.
 //  Per 64-key tile and wave the loop issues ~240 VALU + 64 v_exp against 32 MFMAs -- ~1650 VALU cycles, 1024 MFMA cycles -- and
 //  sits at 57 % / 35 % of the two pipes: dependency stalls with two resident waves per SIMD at 252 VGPRs, not issue order.)
+#ifndef GVD_ATTN_OPTIMISTIC
+#define GVD_ATTN_OPTIMISTIC 1   // 1 = P formed with the stale running max, the row sum as overflow detector (see the tile body)
+#endif
 #ifndef GVD_ATTN_HOIST
 #define GVD_ATTN_HOIST 0   // 1 = pin the clustered LDS fragment reads with sched_barrier (measured 774 vs 788 TFLOP/s: off)
 #endif
@@ -143,36 +146,48 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 
         // ---- S^T = K Q^T : two 32-key blocks per query block; each K fragment read feeds QB MFMAs ----
         f16v s0[QB], s1[QB];
+        auto scores = [&](auto lean_tag) {
+            // lean (the rare recomputation): K fragments loaded per 16-channel step, two registers sets live instead of eight
+            constexpr bool LEAN = decltype(lean_tag)::value;
 #pragma unroll
-        for (int qi = 0; qi < QB; qi++) { s0[qi] = f16v{}; s1[qi] = f16v{}; }
-        vec8 ka[4][2];
+            for (int qi = 0; qi < QB; qi++) { s0[qi] = f16v{}; s1[qi] = f16v{}; }
+            vec8 ka[4][2];
+            if (!LEAN) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {   // all eight K fragments in flight before the first MFMA needs one
-            ka[ks][0] = *reinterpret_cast<const vec8*>(&sK[col][16 * ks + 8 * hi]);
-            ka[ks][1] = *reinterpret_cast<const vec8*>(&sK[32 + col][16 * ks + 8 * hi]);
-        }
+                for (int ks = 0; ks < 4; ks++) {   // all eight K fragments in flight before the first MFMA needs one
+                    ka[ks][0] = *reinterpret_cast<const vec8*>(&sK[col][16 * ks + 8 * hi]);
+                    ka[ks][1] = *reinterpret_cast<const vec8*>(&sK[32 + col][16 * ks + 8 * hi]);
+                }
+            }
 #if GVD_ATTN_HOIST
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-#if GVD_ATTN_QMAJOR
-#pragma unroll
-        for (int qi = 0; qi < QB; qi++) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                s0[qi] = Tr<T>::mfma(ka[ks][0], qf[qi][ks], s0[qi]);
-                s1[qi] = Tr<T>::mfma(ka[ks][1], qf[qi][ks], s1[qi]);
-            }
-        }
-#else
+                if (LEAN) {
+                    ka[ks][0] = *reinterpret_cast<const vec8*>(&sK[col][16 * ks + 8 * hi]);
+                    ka[ks][1] = *reinterpret_cast<const vec8*>(&sK[32 + col][16 * ks + 8 * hi]);
+                }
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-            for (int qi = 0; qi < QB; qi++) {
-                s0[qi] = Tr<T>::mfma(ka[ks][0], qf[qi][ks], s0[qi]);
-                s1[qi] = Tr<T>::mfma(ka[ks][1], qf[qi][ks], s1[qi]);
+                for (int qi = 0; qi < QB; qi++) {
+                    s0[qi] = Tr<T>::mfma(ka[ks][0], qf[qi][ks], s0[qi]);
+                    s1[qi] = Tr<T>::mfma(ka[ks][1], qf[qi][ks], s1[qi]);
+                }
+                if (LEAN) __builtin_amdgcn_sched_barrier(0);   // keep the next step's loads behind this step's MFMAs
             }
-        }
-#endif
+            if (TAIL) {
+#pragma unroll
+                for (int qi = 0; qi < QB; qi++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (kt + krow >= Nk) s0[qi][r] = -3.0e38f;
+                        if (kt + 32 + krow >= Nk) s1[qi][r] = -3.0e38f;
+                    }
+                }
+            }
+        };
+        scores(std::false_type{});
         // the V^T fragments of this tile are requested now and land under the softmax arithmetic
         vec8 va[2][2][2];
 #pragma unroll
@@ -187,26 +202,72 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         __builtin_amdgcn_sched_barrier(0);
 #endif
         // ---- online softmax over this lane's 32 scores (+ the other half's 32); the 1/sqrt(d)*log2(e) scale is
-        //      folded into the exp2 argument (one fma per score) ----
-        //      Lazy rescaling: the running max m is only raised (and O, l rescaled -- 32 accumulator registers per query
-        //      block, a VALU -> MFMA hazard on every one) when some query's tile max exceeds it by more than 2^8;
-        //      otherwise the stale m is kept and P = exp2(s*c - m) <= 256, exact in the softmax ratio because O and l
-        //      share the same m, and well inside the 16-bit operand range.  After the first tiles this is the cold path.
+        //      folded into the exp2 argument (one fma per score).  The running max m is LAZY: O and l share it, so any m gives
+        //      the exact softmax ratio as long as P = exp2(s*c - m) stays inside the 16-bit operand range; raising m costs a
+        //      rescale of 32 accumulator registers per query block (a VALU -> MFMA hazard on every one) and is the cold path. ----
         unsigned pk0[QB][8], pk1[QB][8];
+        // P = exp2(s*c - m): packed fp32 fma / add (v_pk_*), rounded to 16 bit right away (the MFMA operand type); returns the
+        // query's sum of P over the tile's 64 keys
+        auto exp_block = [&](int qi) {
+            const f16v& t0 = s0[qi];
+            const f16v& t1 = s1[qi];
+            const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m[qi], -m[qi] };
+            f2 rs2 = { 0.f, 0.f };
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                f2 a0 = { t0[2 * j], t0[2 * j + 1] }, a1 = { t1[2 * j], t1[2 * j + 1] };
+                a0 = __builtin_elementwise_fma(a0, c2, nm2);
+                a1 = __builtin_elementwise_fma(a1, c2, nm2);
+                const f2 p0 = exp2_pair(a0), p1 = exp2_pair(a1);
+                rs2 += p0 + p1;
+                pk0[qi][j] = Tr<T>::pack2(p0.x, p0.y);
+                pk1[qi][j] = Tr<T>::pack2(p1.x, p1.y);
+            }
+            const float rowsum = rs2.x + rs2.y;
+            return rowsum + __shfl_xor(rowsum, 32, 64);
+        };
+#if GVD_ATTN_OPTIMISTIC
+        // OPTIMISTIC softmax: P is formed with the running m WITHOUT looking at the tile's maximum (32 v_max3 + the exchange per
+        // query block: ~15 % of the loop's VALU work).  The row sum is the overflow detector: sum(P) <= 2^15 bounds every
+        // P <= 2^15 (P >= 0), inside the 16-bit operand range and exact in the softmax ratio because O and l share m.  A tile
+        // whose sum is larger (always the first one: m starts at -1e30 and P is inf) takes the exact path: maxima, m raised,
+        // O and l rescaled, P recomputed.
+        float rsum[QB];
+        bool redo = false;
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++) {
+            rsum[qi] = exp_block(qi);
+            redo |= !(rsum[qi] <= 32768.0f);   // also true for inf / NaN
+        }
+        if (__any(redo)) {
+            scores(std::true_type{});   // the scores were consumed by the optimistic pass (keeping them live costs 64 registers): recompute, K is still in LDS
+#pragma unroll
+            for (int qi = 0; qi < QB; qi++) {
+                const f16v& t0 = s0[qi];
+                const f16v& t1 = s1[qi];
+                float mt = max3f(t0[0], t1[0], t0[1]);
+                mt = max3f(mt, t1[1], t0[2]);
+#pragma unroll
+                for (int r = 3; r < 16; r += 2) { mt = max3f(mt, t0[r], t1[r - 1]); mt = max3f(mt, t1[r], r + 1 < 16 ? t0[r + 1] : mt); }
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                const float m_new = fmaxf(m[qi], mt * scale_log2e);
+                const float alpha = __builtin_amdgcn_exp2f(m[qi] - m_new);
+                l[qi] *= alpha;
+                m[qi] = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { o0[qi][r] *= alpha; o1[qi][r] *= alpha; }
+                rsum[qi] = exp_block(qi);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++) l[qi] += rsum[qi];
+#else
         float m_cand[QB];
         bool grow = false;
 #pragma unroll
         for (int qi = 0; qi < QB; qi++) {
-            f16v& t0 = s0[qi];
-            f16v& t1 = s1[qi];
-            if (TAIL) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (kt + krow >= Nk) t0[r] = -3.0e38f;
-                    if (kt + 32 + krow >= Nk) t1[r] = -3.0e38f;
-                }
-            }
+            const f16v& t0 = s0[qi];
+            const f16v& t1 = s1[qi];
             float mt = max3f(t0[0], t1[0], t0[1]);
             mt = max3f(mt, t1[1], t0[2]);
 #pragma unroll
@@ -226,26 +287,8 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
             }
         }
 #pragma unroll
-        for (int qi = 0; qi < QB; qi++) {
-            const f16v& t0 = s0[qi];
-            const f16v& t1 = s1[qi];
-            // P = exp2(s*c - m): packed fp32 fma / add (v_pk_*), rounded to 16 bit right away (the MFMA operand type)
-            const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m[qi], -m[qi] };
-            f2 rs2 = { 0.f, 0.f };
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                f2 a0 = { t0[2 * j], t0[2 * j + 1] }, a1 = { t1[2 * j], t1[2 * j + 1] };
-                a0 = __builtin_elementwise_fma(a0, c2, nm2);
-                a1 = __builtin_elementwise_fma(a1, c2, nm2);
-                const f2 p0 = exp2_pair(a0), p1 = exp2_pair(a1);
-                rs2 += p0 + p1;
-                pk0[qi][j] = Tr<T>::pack2(p0.x, p0.y);
-                pk1[qi][j] = Tr<T>::pack2(p1.x, p1.y);
-            }
-            float rowsum = rs2.x + rs2.y;
-            rowsum += __shfl_xor(rowsum, 32, 64);
-            l[qi] += rowsum;
-        }
+        for (int qi = 0; qi < QB; qi++) l[qi] += exp_block(qi);
+#endif
 
         // ---- O^T += V^T P^T : P^T fragments via permlane32_swap of the packed pairs; each V^T read feeds QB MFMAs ----
 #pragma unroll
