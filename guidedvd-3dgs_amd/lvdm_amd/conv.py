@@ -11,6 +11,7 @@ No CPU path: on CPU tensors `fused_conv` raises unless `ops.use_reference_math(T
 in which case it evaluates the same expression with torch ops (the reference's own formulation).
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -163,7 +164,7 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
     return out, None
 
 
-FUSE_NORM_BACKWARD_STATS = True   # False: separate statistics pass (k_gn_bwd_stats_*), for A/B runs and tests
+FUSE_NORM_BACKWARD_STATS = os.environ.get("GVD_FUSE_NORM_BWD", "1") == "1"   # 0: separate statistics pass (k_gn_bwd_stats_*), for A/B runs and tests
 
 
 def _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cg, Cn):

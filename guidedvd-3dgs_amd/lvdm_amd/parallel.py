@@ -57,6 +57,7 @@ class FrameShard:
         """All frames from every rank's local slice (no autograd; sampler-level tensors).  Slices are padded to the
         largest count so the all-gather is equal-sized on every backend."""
         dim = dim % x_local.dim()
+        x_local = x_local.contiguous()   # one (row-major) layout on every rank: what comes back is replicated, strides included
         cmax = max(self.counts)
         pad = cmax - x_local.shape[dim]
         if pad:
@@ -64,7 +65,7 @@ class FrameShard:
             shp[dim] = pad
             x_local = torch.cat([x_local, x_local.new_zeros(shp)], dim=dim)
         parts = [torch.empty_like(x_local) for _ in range(self.world)]
-        dist.all_gather(parts, x_local.contiguous(), group=self.group)
+        dist.all_gather(parts, x_local, group=self.group)
         return torch.cat([p.narrow(dim, 0, c) for p, c in zip(parts, self.counts)], dim=dim)
 
 
@@ -245,7 +246,11 @@ class ParallelPlan:
         """sum over branches of J(e_branch -> x)^T g_branch for the FULL x (replicated result).  g_* are the full
         [b, 4, T, h, w] cotangents of e_cond / e_uncond (identical on every rank)."""
         g = {0: g_cond, 1: g_uncond}
-        total = torch.zeros_like(like)
+        # A fresh ROW-MAJOR buffer, not zeros_like(like): an all-reduce sums storage elements, and `like` (an autograd
+        # gradient) can carry a permuted-dense layout on one rank and the standard one on another -- e.g. the rank whose frame
+        # slice needed no padding in FrameShard.gather keeps the U-Net's channels-last strides.  Found by the 4-rank
+        # (cfg 2 x frames 2) dry run on the device: two of the four ranks summed mismatched elements.
+        total = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
         for i, x_loc, e_loc in graphs:
             # every rank of the frame group runs this backward together: the reversed all-to-alls route the
             # cotangents of other ranks' frames through the temporal layers into this rank's x_loc

@@ -197,7 +197,10 @@ def _gpu_worker(rank, world, port, q, cfg=2):
         torch.manual_seed(0)
         ld = fill_by_name(LatentDiffusion(SMALL_UNET, SMALL_VAE), std=0.08).eval().to(dev)
         ld.model.diffusion_model.half().to_token_major()
-        ld.first_stage_model.half()
+        # token-major VAE, as the product path runs it: its latent gradient comes back channels-last, so the collectives meet the
+        # rank-dependent strides they meet in production (an un-padded frame shard keeps them through FrameShard.gather, a padded
+        # one does not)
+        ld.first_stage_model.half().to_token_major()
         ld.requires_grad_(False)
         orig_apply = ld.apply_model
         ld.apply_model = lambda x, t, c, **kw: orig_apply(x.half(), t, {k: [v.half() for v in vs] for k, vs in c.items()}, **kw)
@@ -241,16 +244,18 @@ def _gpu_worker(rank, world, port, q, cfg=2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [2, 1])
-def test_two_ranks_on_one_gpu_with_hip_kernels(cfg):
-    """cfg=2: CFG pair; cfg=1: two frame shards (5 frames -> 3 + 2: all-to-all re-sharding around the temporal layers,
-    two-phase GroupNorm with a real cross-rank reduction, distributed backward).  f16 on the device: the result differs
-    from the single-process one by f16 rounding of a different summation order only: 1e-2 of the tensor's max; the
-    guidance term is non-zero."""
+@pytest.mark.parametrize("world,cfg", [(2, 2), (2, 1), (4, 2)])
+def test_ranks_on_one_gpu_with_hip_kernels(world, cfg):
+    """(2, 2): CFG pair; (2, 1): two frame shards (5 frames -> 3 + 2: all-to-all re-sharding around the temporal layers,
+    two-phase GroupNorm with a real cross-rank reduction, distributed backward); (4, 2): both at once -- the layout in which
+    the reduced U-Net input gradient once had rank-dependent strides (the un-padded frame shard kept the U-Net's channels-last
+    layout) and the CFG-pair all-reduce summed mismatched elements.  f16 on the device: the result differs from the
+    single-process one by f16 rounding of a different summation order only: 1e-2 of the tensor's max; the guidance term is
+    non-zero."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q, cfg)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, cfg)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
