@@ -38,7 +38,16 @@ def check(name, t, replicated=False):
 
 
 P = parallel.ParallelPlan
-_ecg, _ig, _gwf = P.eval_cfg_with_graph, P.input_gradient, P.gather_world_frames
+_ecg, _ig, _gwf, _ec = P.eval_cfg_with_graph, P.input_gradient, P.gather_world_frames, P.eval_cfg
+
+
+def ec(self, model, x, t, cond, uncond, **kw):
+    check("x into the U-Net (plain step)", x, True)
+    e_c, e_u = _ec(self, model, x, t, cond, uncond, **kw)
+    check("e_cond (plain step)", e_c, True)
+    check("e_uncond (plain step)", e_u, True)
+    return e_c, e_u
+
 
 
 def ecg(self, model, x, t, cond, uncond, **kw):
@@ -81,7 +90,7 @@ def gwf(self, g_local, n_frames):
     return out
 
 
-P.eval_cfg_with_graph, P.input_gradient, P.gather_world_frames = ecg, ig, gwf
+P.eval_cfg_with_graph, P.input_gradient, P.gather_world_frames, P.eval_cfg = ecg, ig, gwf, ec
 try:
     bench.main()
 finally:
