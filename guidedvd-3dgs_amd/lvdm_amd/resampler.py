@@ -19,66 +19,75 @@ from . import ops
 
 
 class _LayerNorm(nn.LayerNorm):
-    def forward(self, x):
-        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+    """nn.LayerNorm parameters, HIP row kernel on 16-bit activations."""
+
+    def forward(self, t):
+        return ops.layer_norm(t, self.weight, self.bias, self.eps)
+
+
+def _linear(n_in, n_out, bias=True):
+    return nn.Linear(n_in, n_out, bias=bias)
 
 
 class ImageProjModel(nn.Module):
+    """One CLIP embedding -> `clip_extra_context_tokens` context tokens (keys: proj, norm)."""
+
     def __init__(self, cross_attention_dim=1024, clip_embeddings_dim=1024, clip_extra_context_tokens=4):
         super().__init__()
-        self.cross_attention_dim = cross_attention_dim
-        self.clip_extra_context_tokens = clip_extra_context_tokens
-        self.proj = nn.Linear(clip_embeddings_dim, clip_extra_context_tokens * cross_attention_dim)
-        self.norm = _LayerNorm(cross_attention_dim)
+        self.cross_attention_dim, self.clip_extra_context_tokens = cross_attention_dim, clip_extra_context_tokens
+        self.add_module("proj", _linear(clip_embeddings_dim, clip_extra_context_tokens * cross_attention_dim))
+        self.add_module("norm", _LayerNorm(cross_attention_dim))
 
     def forward(self, image_embeds):
-        tokens = self.proj(image_embeds.to(self.proj.weight.dtype))
-        return self.norm(tokens.reshape(-1, self.clip_extra_context_tokens, self.cross_attention_dim))
+        wide = self.proj(image_embeds.to(self.proj.weight.dtype))
+        return self.norm(wide.view(-1, self.clip_extra_context_tokens, self.cross_attention_dim))
 
 
 def FeedForward(dim, mult=4):
-    inner = int(dim * mult)
-    return nn.Sequential(_LayerNorm(dim), nn.Linear(dim, inner, bias=False), nn.GELU(), nn.Linear(inner, dim, bias=False))
+    """Sequential indices 0 (norm), 1 and 3 (bias-free Linears) carry the parameters; 2 is the GELU."""
+    hidden = int(dim * mult)
+    stack = [_LayerNorm(dim), _linear(dim, hidden, False), nn.GELU(), _linear(hidden, dim, False)]
+    return nn.Sequential(*stack)
 
 
 class PerceiverAttention(nn.Module):
+    """Latent queries attend over [image tokens ; latents]; keys norm1, norm2, to_q, to_kv (k | v stacked), to_out."""
+
     def __init__(self, *, dim, dim_head=64, heads=8):
         super().__init__()
-        self.dim_head, self.heads = dim_head, heads
-        inner = dim_head * heads
-        self.norm1 = _LayerNorm(dim)
-        self.norm2 = _LayerNorm(dim)
-        self.to_q = nn.Linear(dim, inner, bias=False)
-        self.to_kv = nn.Linear(dim, inner * 2, bias=False)
-        self.to_out = nn.Linear(inner, dim, bias=False)
+        width = heads * dim_head
+        self.heads, self.dim_head = heads, dim_head
+        for name, module in (("norm1", _LayerNorm(dim)), ("norm2", _LayerNorm(dim)), ("to_q", _linear(dim, width, False)),
+                             ("to_kv", _linear(dim, 2 * width, False)), ("to_out", _linear(width, dim, False))):
+            self.add_module(name, module)
 
     def forward(self, x, latents):
         """x: image tokens [b, n1, D]; latents: query tokens [b, n2, D] -> [b, n2, D]."""
-        x = self.norm1(x)
-        latents = self.norm2(latents)
-        q = self.to_q(latents)
-        k, v = self.to_kv(torch.cat((x, latents), dim=-2)).chunk(2, dim=-1)
-        return self.to_out(ops.attention(q, k, v, self.heads))
+        image_tokens, queries = self.norm1(x), self.norm2(latents)
+        keys, values = self.to_kv(torch.cat([image_tokens, queries], dim=1)).split(self.heads * self.dim_head, dim=-1)
+        return self.to_out(ops.attention(self.to_q(queries), keys, values, self.heads))
 
 
 class Resampler(nn.Module):
+    """`depth` x (PerceiverAttention, FeedForward) over `num_queries` learned tokens per frame (keys: latents, proj_in, proj_out,
+    norm_out, layers.<i>.<0|1>.*)."""
+
     def __init__(self, dim=1024, depth=8, dim_head=64, heads=16, num_queries=8, embedding_dim=768, output_dim=1024,
                  ff_mult=4, video_length=None):
         super().__init__()
-        self.num_queries = num_queries            # per frame
-        self.video_length = video_length
-        total = num_queries * video_length if video_length is not None else num_queries
-        self.latents = nn.Parameter(torch.randn(1, total, dim) / dim ** 0.5)
-        self.proj_in = nn.Linear(embedding_dim, dim)
-        self.proj_out = nn.Linear(dim, output_dim)
+        self.num_queries, self.video_length = num_queries, video_length
+        n_tokens = num_queries * (video_length if video_length is not None else 1)
+        self.latents = nn.Parameter(torch.randn(1, n_tokens, dim) * dim ** -0.5)
+        self.proj_in, self.proj_out = _linear(embedding_dim, dim), _linear(dim, output_dim)
         self.norm_out = _LayerNorm(output_dim)
-        self.layers = nn.ModuleList([nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads),
-                                                    FeedForward(dim=dim, mult=ff_mult)]) for _ in range(depth)])
+        self.layers = nn.ModuleList()
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads), FeedForward(dim, ff_mult)]))
 
     def forward(self, x):
-        latents = self.latents.expand(x.size(0), -1, -1)
-        x = self.proj_in(x)
-        for attn, ff in self.layers:
-            latents = attn(x, latents) + latents
-            latents = ff(latents) + latents
-        return self.norm_out(self.proj_out(latents))      # b, (frames * queries), output_dim
+        tokens = self.proj_in(x)
+        state = self.latents.expand(tokens.shape[0], -1, -1)
+        for attend, feed_forward in self.layers:
+            state = state + attend(tokens, state)
+            state = state + feed_forward(state)
+        return self.norm_out(self.proj_out(state))      # [b, frames * queries, output_dim]
