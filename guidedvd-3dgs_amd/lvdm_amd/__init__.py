@@ -10,7 +10,7 @@
     ops        hot operators; HIP kernels (csrc/*.hip) on ROCm devices, no silent CPU fallback
 
 Importing this package changes no process-wide state.  `configure_tuning()` is the explicit opt-in for the recorded
-library-solution choices (hipBLASLt via PyTorch TunableOp, MIOpen find results for the few convolutions still routed to it).
+library-solution choices (hipBLASLt via PyTorch TunableOp for the Linear layers; MIOpen find results for the little that still reaches it).
 """
 import os as _os
 import shutil as _shutil
@@ -39,8 +39,10 @@ def configure_tuning(tunableop=True, miopen_db=True, cache_dir=None):
       * hipBLASLt / rocBLAS solutions for the U-Net's Linear shapes through PyTorch TunableOp (reading only: tuning stays off
         unless the caller turned it on; a file written by another PyTorch / hipBLASLt build fails TunableOp's validators and
         is ignored);
-      * MIOpen find-db entries for the stride-2 Downsample convolutions (everything 3x3 stride-1 runs the package's own MFMA
-        kernel) and `PYTORCH_MIOPEN_SUGGEST_NHWC=1` so that token-major tensors reach MIOpen's NHWC kernels un-transposed.
+      * MIOpen find-db entries and `PYTORCH_MIOPEN_SUGGEST_NHWC=1` (token-major tensors reach MIOpen's NHWC kernels
+        un-transposed) for what still reaches MIOpen: on the 16-bit product path only the CLIP patch embedding, once per
+        video -- every 3x3 / stride-2 / upsampling / temporal convolution of the U-Net and the VAE runs the package's own MFMA
+        kernel -- plus the fp32 torch-form branches that `ops` warns about.
 
     Writable copies live in a per-user, per-rank cache directory (default `$XDG_CACHE_HOME/guidedvd_amd/rank<LOCAL_RANK>`),
     never in the source tree; variables the caller already exported are left alone.  Returns the cache directory."""
