@@ -29,6 +29,15 @@ template <> struct Tr<_Float16> {
         h2 p = { (_Float16)lo, (_Float16)hi };
         return __builtin_bit_cast(unsigned, p);
     }
+    // acc + lo + hi of a packed pair: v_dot2_f32_f16 against (1, 1) -- one plain VALU op for two values, and the sum is over the
+    // ROUNDED values the MFMA consumes
+    static constexpr bool kHasDot2 = true;
+    static __device__ __forceinline__ float add_pair(unsigned packed, float acc)
+    {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 ones = { (_Float16)1.0f, (_Float16)1.0f };
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, packed), ones, acc, false);
+    }
 };
 template <> struct Tr<__bf16> {
     typedef b8 vec8;
@@ -39,6 +48,8 @@ template <> struct Tr<__bf16> {
         b2 p = { (__bf16)lo, (__bf16)hi };
         return __builtin_bit_cast(unsigned, p);
     }
+    static constexpr bool kHasDot2 = false;   // bf16: the row sum stays in packed fp32 adds
+    static __device__ __forceinline__ float add_pair(unsigned, float acc) { return acc; }
 };
 
 constexpr int KV_TILE = 64;   // keys per iteration

@@ -213,17 +213,19 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
             const f16v& t1 = s1[qi];
             const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m[qi], -m[qi] };
             f2 rs2 = { 0.f, 0.f };
+            float rsa = 0.f, rsb = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 f2 a0 = { t0[2 * j], t0[2 * j + 1] }, a1 = { t1[2 * j], t1[2 * j + 1] };
                 a0 = __builtin_elementwise_fma(a0, c2, nm2);
                 a1 = __builtin_elementwise_fma(a1, c2, nm2);
                 const f2 p0 = exp2_pair(a0), p1 = exp2_pair(a1);
-                rs2 += p0 + p1;
                 pk0[qi][j] = Tr<T>::pack2(p0.x, p0.y);
                 pk1[qi][j] = Tr<T>::pack2(p1.x, p1.y);
+                if (Tr<T>::kHasDot2) { rsa = Tr<T>::add_pair(pk0[qi][j], rsa); rsb = Tr<T>::add_pair(pk1[qi][j], rsb); }
+                else rs2 += p0 + p1;
             }
-            const float rowsum = rs2.x + rs2.y;
+            const float rowsum = Tr<T>::kHasDot2 ? rsa + rsb : rs2.x + rs2.y;
             return rowsum + __shfl_xor(rowsum, 32, 64);
         };
 #if GVD_ATTN_OPTIMISTIC

@@ -13,8 +13,11 @@ dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 q, k, v = (torch.randn(25, 9216, 320, device=dev, generator=g).half() for _ in range(3))
 for _ in range(3):
-    ops._hip_attention_fwd(q, k, v, 5, False, want_lse=False)
-del q, k, v
+    o, lse = ops._hip_attention_fwd(q, k, v, 5, False, want_lse=True)
+go = torch.randn_like(o)
+for _ in range(2):   # the guided step's backward pair (k_attn_bwd_dkv, k_attn_bwd_dq)
+    ops._hip_attention_bwd(q, k, v, o, go, lse, 5, False)
+del q, k, v, o, go, lse
 
 
 def conv_case(N, H, W, Cin, Cout, prologue):

@@ -23,9 +23,10 @@ dur = collections.defaultdict(dict)
 for rows in (rows_of(a_dir), rows_of(b_dir)):
     for r in rows:
         n = r["Kernel_Name"]
-        if "k_conv_mfma" not in n and "k_attn_fwd" not in n:
+        if "k_conv_mfma" not in n and "k_attn_fwd" not in n and "k_attn_bwd" not in n:
             continue
-        key = ("conv" if "k_conv_mfma" in n else "attn") + " " + n.split("ConvArgs")[0][-40:] + f" grid={r['Grid_Size']}"
+        kind = "conv" if "k_conv_mfma" in n else ("attn_bwd_dkv" if "bwd_dkv" in n else ("attn_bwd_dq" if "bwd_dq" in n else "attn"))
+        key = kind + " " + n.split("ConvArgs")[0][-40:] + f" grid={r['Grid_Size']}"
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[key][r["Counter_Name"]].add(r["Dispatch_Id"])
         if "Start_Timestamp" in r and r.get("End_Timestamp"):
