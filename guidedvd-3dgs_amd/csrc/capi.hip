@@ -113,6 +113,8 @@ struct SpecHint { int P, W, H; uint32_t r_max, list_max; };
 std::mutex g_spec_mu;
 std::vector<SpecHint> g_hints;
 std::atomic<int> g_spec_opt_in{0};
+// gvd_raster_expect_backward: per host thread; 1 (default) = every forward prepares its binning chunk for a backward
+thread_local int t_expect_backward = 1;
 
 bool spec_enabled()
 {
@@ -223,7 +225,8 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     sa.means2D = (const float*)(geom + L.means2D); sa.depths = (const float*)(geom + L.depths);
     sa.radii = radii; sa.cursor = (uint32_t*)(geom + L.cursor);
     sa.point_offsets = (uint32_t*)(geom + L.point_offsets); sa.bucket = (uint64_t*)(bin + L.bucket);
-    sa.partials = (float*)(bin + L.partials);   // zeroed here for the backward (no memset launch there)
+    // zeroed here for the backward (no memset launch there) -- unless the caller announced that none will follow
+    sa.partials = t_expect_backward ? (float*)(bin + L.partials) : nullptr;
     {
         ProfScope ps("scatter", stream);
         launch_scatter(sa, L.bin_blocks, L.lds_hist != 0, stream);
@@ -307,6 +310,7 @@ uint32_t gvd_raster_binning_capacity(size_t binning_chunk_bytes)
 }
 
 void gvd_raster_set_speculation(int on) { g_spec_opt_in.store(on ? 1 : 0, std::memory_order_relaxed); }
+void gvd_raster_expect_backward(int yes) { t_expect_backward = yes ? 1 : 0; }
 
 int gvd_raster_forward(
     gvd_alloc_fn geometry_alloc, void* geometry_user, gvd_alloc_fn binning_alloc, void* binning_user,

@@ -485,9 +485,10 @@ __global__ void __launch_bounds__(256) k_gn_stats_nsc(const T* __restrict__ x, d
                                                       int rows_per_block)
 {
     typedef typename Tr<T>::vec8 vec8;
-    extern __shared__ float sh_g[];  // [G][2]
+    extern __shared__ double sh_g[];  // [G][2]; fp64: a block's strip is up to 8192 rows x cpg channels per group (a thread's
+                                      // own fp32 partial spans <= rows / rstep of them)
     const int n = blockIdx.y, cpg = C / G, oct = C / 8;
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.0;
     __syncthreads();
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
@@ -506,12 +507,12 @@ __global__ void __launch_bounds__(256) k_gn_stats_nsc(const T* __restrict__ x, d
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int g = (o * 8 + k) / cpg;
-            atomicAdd(&sh_g[2 * g], s[k]);
-            atomicAdd(&sh_g[2 * g + 1], q[k]);
+            atomicAdd(&sh_g[2 * g], (double)s[k]);
+            atomicAdd(&sh_g[2 * g + 1], (double)q[k]);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[(long long)n * 2 * G + i], (double)sh_g[i]);
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[(long long)n * 2 * G + i], sh_g[i]);
 }
 
 // NSC apply: same lane map as the statistics kernel -- a thread keeps the (a, b) pairs of its channel octet in registers and
@@ -615,9 +616,10 @@ __global__ void __launch_bounds__(256) k_gn_bwd_stats_nsc(const T* __restrict__ 
                                                           int C, int G, long long S, int silu, int rows_per_block)
 {
     typedef typename Tr<T>::vec8 vec8;
-    extern __shared__ float sh_g[];  // [G][2]
+    extern __shared__ double sh_g[];  // [G][2]; fp64: a block's strip is up to 8192 rows x cpg channels per group (a thread's
+                                      // own fp32 partial spans <= rows / rstep of them)
     const int n = blockIdx.y, cpg = C / G, oct = C / 8;
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.0;
     __syncthreads();
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
@@ -644,12 +646,12 @@ __global__ void __launch_bounds__(256) k_gn_bwd_stats_nsc(const T* __restrict__ 
         for (int k = 0; k < 8; k++) {
             const int c = o * 8 + k;
             const float gm = gamma[c];
-            atomicAdd(&sh_g[2 * (c / cpg)], gm * s1[k]);
-            atomicAdd(&sh_g[2 * (c / cpg) + 1], gm * s2[k]);
+            atomicAdd(&sh_g[2 * (c / cpg)], (double)(gm * s1[k]));
+            atomicAdd(&sh_g[2 * (c / cpg) + 1], (double)(gm * s2[k]));
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&bstats[(long long)n * 2 * G + i], (double)sh_g[i]);
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&bstats[(long long)n * 2 * G + i], sh_g[i]);
 }
 
 __global__ void __launch_bounds__(256) k_gn_bwd_coef(const double* __restrict__ stats, const double* __restrict__ bstats,
@@ -1024,8 +1026,8 @@ int gvd_group_norm_stats(const void* x, double* stats, int N, int C, long long S
     } else {
         const int rows = gn_stat_rows(N, S);
         dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
-        if (is_bf16) hipLaunchKernelGGL(k_gn_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, stats, C, G, S, rows);
-        else hipLaunchKernelGGL(k_gn_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, stats, C, G, S, rows);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 16, stream, (const __bf16*)x, stats, C, G, S, rows);
+        else hipLaunchKernelGGL(k_gn_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 16, stream, (const _Float16*)x, stats, C, G, S, rows);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_stats_*", e);
@@ -1080,8 +1082,8 @@ int gvd_group_norm_bwd_stats(const void* x, const void* dy, const float* gamma, 
     } else {
         const int rows = gn_stat_rows(N, S);
         dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
-        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 8, stream, (const __bf16*)x, (const __bf16*)dy, coef, gamma, scratch, C, G, S, silu, rows);
-        else hipLaunchKernelGGL(k_gn_bwd_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 8, stream, (const _Float16*)x, (const _Float16*)dy, coef, gamma, scratch, C, G, S, silu, rows);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 16, stream, (const __bf16*)x, (const __bf16*)dy, coef, gamma, scratch, C, G, S, silu, rows);
+        else hipLaunchKernelGGL(k_gn_bwd_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 16, stream, (const _Float16*)x, (const _Float16*)dy, coef, gamma, scratch, C, G, S, silu, rows);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_bwd_stats_*", e);

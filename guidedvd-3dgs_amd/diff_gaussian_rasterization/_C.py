@@ -62,6 +62,7 @@ def lib():
         L.gvd_raster_binning_capacity.restype = ctypes.c_uint32
         L.gvd_raster_binning_capacity.argtypes = [ctypes.c_size_t]
         L.gvd_raster_set_speculation.argtypes = [_I]
+        L.gvd_raster_expect_backward.argtypes = [_I]
         # this binding hands the binning chunk's size to backward, so the forward may lay it out speculatively (gvd_raster.h)
         L.gvd_raster_set_speculation(1)
         L.gvd_raster_mark_visible.restype = _I
@@ -181,7 +182,9 @@ def _chunks(dev):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, expect_backward=True):
+    """expect_backward (MI355X addition, keyword only in spirit): False = no rasterize_gaussians_backward will be run on the
+    returned buffers (no-grad render) -> the forward skips preparing the backward's partial records (gvd_raster.h)."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = means3D.device
@@ -189,6 +192,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a ROCm device; got " + str(dev))
     L = lib()
     P, H, W = means3D.size(0), int(image_height), int(image_width)
+    eb = 1 if expect_backward else 0
+    if getattr(_TLS, "expect_backward", 1) != eb:   # per-thread, sticky on the native side: only touch it on a change
+        L.gvd_raster_expect_backward(eb)
+        _TLS.expect_backward = eb
     with _on(dev):
         f = lambda t, n: _dev_f32(t, n, dev)
         bg, m3, col, opa, sc, rot, cov, vm, pm, shs, cam = (

@@ -68,9 +68,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width,
                        sh, s.sh_degree, s.campos, s.prefiltered, s.debug)
+        # no input wants a gradient (torch.no_grad() / evaluation renders): autograd will never call backward on these
+        # buffers, so the forward need not prepare the backward's partial records (gvd_raster.h: gvd_raster_expect_backward)
+        fwd = functools.partial(_C.rasterize_gaussians, expect_backward=any(ctx.needs_input_grad[:8]))
         (num_rendered, color, depth, alpha, radii,
-         geom_buf, binning_buf, img_buf) = _call_native(_C.rasterize_gaussians, native_args, s.debug,
-                                                        "snapshot_fw.dump", "forward")
+         geom_buf, binning_buf, img_buf) = _call_native(fwd, native_args, s.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,

@@ -169,11 +169,11 @@ class LatentDiffusion(DDPM):
             b, _, t, _, _ = x.shape
             x = x.transpose(1, 2).reshape(b * t, x.shape[1], x.shape[3], x.shape[4])
         xd = x.to(self._fs_dtype())
-        if not self.perframe_ae:
-            res = self.get_first_stage_encoding(self.first_stage_model.encode(xd)).detach()
-        else:
-            res = self.first_stage_model.perframe(lambda xx: self.get_first_stage_encoding(self.first_stage_model.encode(xx)).detach(),
-                                                  xd, self.ae_frames_per_call, latent=False)
+        # perframe_ae=False (one call for all b*t frames in the reference) takes the chunked route too: every VAE norm is per
+        # sample, so the values are the same, and the MFMA convolutions index with 32-bit offsets (25 x 576 x 1024 x 256
+        # elements in one call would exceed them); only perframe_ae=True honours the caller's frames-per-call bound
+        res = self.first_stage_model.perframe(lambda xx: self.get_first_stage_encoding(self.first_stage_model.encode(xx)).detach(),
+                                              xd, self.ae_frames_per_call if self.perframe_ae else None, latent=False)
         res = res.to(x.dtype)
         if reshape_back:
             res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)
@@ -186,10 +186,8 @@ class LatentDiffusion(DDPM):
             b, _, t, _, _ = z.shape
             z = z.transpose(1, 2).reshape(b * t, z.shape[1], z.shape[3], z.shape[4])
         zd = (1. / self.scale_factor * z).to(self._fs_dtype())
-        if not self.perframe_ae:
-            res = self.first_stage_model.decode(zd, **kwargs)
-        else:
-            res = self.first_stage_model.perframe(lambda zz: self.first_stage_model.decode(zz, **kwargs), zd, self.ae_frames_per_call)
+        res = self.first_stage_model.perframe(lambda zz: self.first_stage_model.decode(zz, **kwargs), zd,
+                                              self.ae_frames_per_call if self.perframe_ae else None)   # (see encode_first_stage)
         res = res.to(z.dtype)
         if reshape_back:
             res = res.reshape(b, t, *res.shape[1:]).transpose(1, 2)

@@ -49,10 +49,25 @@ def _taps(weight):
     return weight.reshape(weight.shape[0], weight.shape[1], -1)
 
 
+def invalidate_packed(module_or_weight):
+    """Drop the cached MFMA images.  The cache is keyed on (tensor._version, data_ptr): in-place autograd-visible updates
+    (`p.copy_`, `p.mul_`, optimizer steps, load_state_dict) bump the version and re-pack by themselves; writes THROUGH `.data`
+    (`p.data.copy_(ema)`, EMA swaps) do not -- call this after them."""
+    ws = module_or_weight.parameters() if isinstance(module_or_weight, torch.nn.Module) else [module_or_weight]
+    for w in ws:
+        for attr in ("_gvd_packed", "_gvd_f32", "_gvd_gemm"):
+            if hasattr(w, attr):
+                try:
+                    delattr(w, attr)
+                except AttributeError:
+                    pass
+
+
 def packed(weight, BN, backward=False, cin_pad=0, dtype=None):
     """Packed image of a conv weight in `dtype` (the activations' 16-bit type; fp32 master weights under autocast are cast
-    here, once), cached on the parameter until it is modified.  backward: the input-gradient operator (Cout <-> Cin
-    transposed, taps flipped).  cin_pad: zero input channels appended (Cin not a multiple of 8)."""
+    here, once), cached on the parameter until it is modified (see invalidate_packed for `.data` writes).  backward: the
+    input-gradient operator (Cout <-> Cin transposed, taps flipped).  cin_pad: zero input channels appended (Cin not a
+    multiple of 8)."""
     dtype = dtype or weight.dtype
     key = (BN, backward, cin_pad, dtype, weight.device)
     cache = getattr(weight, "_gvd_packed", None)
@@ -318,6 +333,9 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
         return _reference(x, conv.weight, conv.bias, mode, upsample, gn, silu, add_nc, residual, n_stat), None
     if torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)):
         raise RuntimeError("fused_conv: only the input gradient is implemented (freeze the weights)")
+    if torch.is_grad_enabled() and add_nc is not None and add_nc.requires_grad:
+        raise RuntimeError("fused_conv: no gradient is produced for add_nc (the ResBlock's timestep / fs embedding term); detach it "
+                           "or differentiate w.r.t. x only, as the guided sampler does")
     ns = None
     if gn is not None:
         n_stat = n_stat if n_stat is not None else (1 if mode == TEMPORAL else x.shape[0])

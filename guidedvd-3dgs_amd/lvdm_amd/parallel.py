@@ -70,6 +70,7 @@ class FrameShard:
 
 
 _ACTIVE = None
+_PLANS_BUILT = 0   # ParallelPlan objects constructed by this process (decorrelates their noise streams)
 
 
 def active():
@@ -168,9 +169,14 @@ class ParallelPlan:
         self.shard = FrameShard(self.frame_group, n_frames)
         self._world_shards = {}
         # The latent x is replicated: every rank must draw the same x_T / per-step noise whatever its own RNG state is.
-        # One seed, chosen by rank 0, broadcast once; the samplers draw from plan.generator(device).
-        import random
-        seed = [random.SystemRandom().randrange(1 << 62) if rank == 0 else 0]
+        # One seed broadcast from rank 0; the samplers draw from plan.generator(device).  The seed is rank 0's torch seed
+        # (torch.manual_seed / seed_everything, as the reference's ViewCrafter driver sets it -- viewcrafter_wrapper.py:253-262),
+        # so user seeding governs the multi-GPU run exactly as it governs the single-GPU one: the first plan of a process draws
+        # the very stream a seeded single-GPU sampler draws from the device's global generator.  Later plans of the same
+        # process get a different (still seed-determined) stream.  `reseed()` is the explicit override.
+        global _PLANS_BUILT
+        seed = [(torch.initial_seed() + _PLANS_BUILT * 0x9E3779B97F4A7C15) % (1 << 63) if rank == 0 else 0]
+        _PLANS_BUILT += 1
         dist.broadcast_object_list(seed, src=0)
         self.seed = int(seed[0])
         self._generators = {}
@@ -184,7 +190,8 @@ class ParallelPlan:
         return g
 
     def reseed(self, seed):
-        """Restart the replicated noise stream (call with the same value on every rank, e.g. for reproducible runs)."""
+        """Restart the replicated noise stream with an explicit seed (call with the same value on every rank).  Not needed for
+        reproducibility: the default stream already follows rank 0's torch.manual_seed."""
         self.seed = int(seed)
         self._generators = {}
 

@@ -93,6 +93,16 @@ int gvd_raster_forward(
  * (binning_chunk_bytes).  Nothing is keyed on chunk addresses: chunks may be cloned, offloaded and restored freely.
  * gvd_raster_binning_capacity inverts gvd_raster_binning_bytes (0xffffffff if `bytes` is not a chunk size). */
 void gvd_raster_set_speculation(int on);
+
+/* Forward -> backward contract of the binning chunk (MI355X addition).  The backward's per-instance partial records live in
+ * the binning chunk and are ZEROED BY THE FORWARD (its scatter kernel writes capacity x 48 bytes under its own latency, instead
+ * of a memset launch at the head of every backward).  gvd_raster_backward(_conf) therefore requires the binning chunk exactly as
+ * the forward left it -- bytes may be copied / offloaded / restored, but not modified -- and consumes it: a second backward on
+ * the same chunk needs a fresh forward.  A caller that will NOT run a backward on the chunks of its next forwards (no-grad /
+ * evaluation renders) may say so with gvd_raster_expect_backward(0): the zeroing stores are skipped (~21 MB per render at
+ * 200k Gaussians) and a backward on such a chunk is undefined.  Per host thread, sticky until changed; default 1 (the
+ * reference's contract: any forward may be followed by a backward). */
+void gvd_raster_expect_backward(int yes);
 uint32_t gvd_raster_binning_capacity(size_t binning_chunk_bytes);
 
 /* Sync-free variant (MI355X addition; no reference counterpart): the caller supplies the
@@ -131,7 +141,8 @@ int gvd_raster_forward_capped(
  *   dL_dmean2D[P,3] dL_dconic[P,4] dL_dopacity[P] dL_dcolor[P,3] dL_ddepth[P]
  *   dL_dmean3D[P,3] dL_dcov3D[P,6] dL_dsh[P,M,3] dL_dscale[P,3] dL_drot[P,4]
  * Per-Gaussian sums are formed without float atomics (per-instance partials reduced in a
- * fixed order), so results are run-to-run deterministic.  Returns GVD_OK or < 0. */
+ * fixed order), so results are run-to-run deterministic.  The binning chunk must be as the forward left it (see
+ * gvd_raster_expect_backward).  Returns GVD_OK or < 0. */
 int gvd_raster_backward(
     int P, int D, int M, int R,
     const float* background,

@@ -104,6 +104,17 @@ def _worker(rank, world, cfg, port, q):
         sr.parallel = plan
         for _ in range(3):
             plan.check_replicated(sr._randn((1, 4, T, HL, WL), torch.device("cpu")), "sampler noise under a plan")
+        # user seeding governs (advisor finding, round 2): the first plan of a process draws the stream a seeded single-process
+        # sampler draws from the global generator -- rank 0's torch.manual_seed (here the 0 of _build()) -- and a later plan
+        # follows rank 0's seed too, whatever the other ranks were seeded with
+        assert plan.seed == 0, plan.seed
+        first = torch.randn((1, 4, T, HL, WL), generator=torch.Generator().manual_seed(plan.seed))
+        torch.manual_seed(0)
+        assert torch.equal(first, torch.randn((1, 4, T, HL, WL)))
+        torch.manual_seed(777 + 13 * rank)
+        plan2 = parallel.ParallelPlan(T, cfg=cfg)
+        assert plan2.seed == (777 + 0x9E3779B97F4A7C15) % (1 << 63), plan2.seed
+        plan2.check_replicated(torch.randn((5, 7), generator=plan2.generator("cpu")), "second plan's noise")
         # the guidance term must actually be exercised: guided != plain
         moved = float((ref["guided_xprev"] - ref["plain_xprev"]).abs().max())
         q.put((rank, errs, moved, (plan.cfg, plan.F, plan.cfg_rank, plan.frame_rank, plan.shard.counts)))

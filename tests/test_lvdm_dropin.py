@@ -61,34 +61,7 @@ def test_reference_import_strings_resolve_to_the_native_package(module, name):
     assert os.path.realpath(pkg.__file__).startswith(os.path.realpath(os.path.join(HERE, "..", "guidedvd-3dgs_amd")))
 
 
-def _yaml_model_node(clip_cfg=None, unet_over=None, vae_over=None):
-    """configs/inference_pvd_1024.yaml:4-110 as the nested mapping OmegaConf hands to instantiate_from_config."""
-    unet = dict(in_channels=8, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
-                channel_mult=[1, 2, 4, 4], dropout=0.1, num_head_channels=64, transformer_depth=1, context_dim=1024,
-                use_linear=True, use_checkpoint=True, temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
-                use_relative_position=False, use_causal_attention=False, temporal_length=16, addition_attention=True,
-                image_cross_attention=True, default_fs=10, fs_condition=True)
-    unet.update(unet_over or {})
-    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
-              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
-    dd.update(vae_over or {})
-    extra = {} if clip_cfg is None else {"model_cfg": clip_cfg}
-    return {"target": "lvdm.models.ddpm3d.VIPLatentDiffusion", "params": dict(
-        rescale_betas_zero_snr=True, parameterization="v", linear_start=0.00085, linear_end=0.012, num_timesteps_cond=1,
-        log_every_t=200, timesteps=1000, first_stage_key="video", cond_stage_key="caption", cond_stage_trainable=False,
-        image_proj_model_trainable=False, conditioning_key="hybrid", image_size=[72, 128], channels=4, scale_by_std=False,
-        scale_factor=0.18215, use_ema=False, uncond_prob=0.05, uncond_type="empty_seq", rand_cond_frame=True,
-        use_dynamic_rescale=True, base_scale=0.3, fps_condition_type="fps", perframe_ae=True, loop_video="Flase",
-        unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": unet},
-        first_stage_config={"target": "lvdm.models.autoencoder.AutoencoderKL",
-                            "params": dict(embed_dim=4, monitor="val/rec_loss", ddconfig=dd, lossconfig={"target": "torch.nn.Identity"})},
-        cond_stage_config={"target": "lvdm.modules.encoders.condition.FrozenOpenCLIPEmbedder",
-                           "params": dict(freeze=True, layer="penultimate", **extra)},
-        img_cond_stage_config={"target": "lvdm.modules.encoders.condition.FrozenOpenCLIPImageEmbedderV2",
-                               "params": dict(freeze=True, **({} if clip_cfg is None else {"model_cfg": clip_cfg}))},
-        image_proj_stage_config={"target": "lvdm.modules.encoders.resampler.Resampler",
-                                 "params": dict(dim=1024, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280,
-                                                output_dim=1024, ff_mult=4, video_length=16)})}
+from lvdm_amd.model import viewcrafter_yaml_node as _yaml_model_node  # noqa: E402  (the yaml's `model:` node as a plain mapping)
 
 
 # persistent buffers of DDPM.register_schedule + LatentDiffusion (ddpm3d.py:145-171,527): part of the checkpoint's state dict

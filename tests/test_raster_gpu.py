@@ -35,11 +35,13 @@ def _grads(H, W, seed, depth_alpha=True):
     return gC, np.zeros((H, W)), np.zeros((H, W))
 
 
-def _check(rep, exact=EXACT, grad_tol=2e-3, img_outliers=0.0):
+def _check(rep, exact=EXACT, grad_tol=2e-3, n_contrib_outliers=0.0, img_outliers=0.0):
+    """n_contrib_outliers: fraction of pixels whose last-contributor index may differ (each one proven a near-tie below);
+    img_outliers: fraction of pixels whose colour / depth / alpha may differ by more than 1e-4 -- 0 unless a test says why."""
     for k in exact:
         if k in rep:
             assert rep[k] is True, (k, rep)
-    assert rep.get("n_contrib_mismatch_frac", 0.0) <= img_outliers, rep
+    assert rep.get("n_contrib_mismatch_frac", 0.0) <= n_contrib_outliers, rep
     # n_contrib is exact except where one of the blend loop's comparisons sits within fp32 rounding of its threshold (the two
     # sides differ by <= 1 ulp in exp()); every mismatching pixel is replayed in float64 and must show such a near-tie
     assert rep.get("n_contrib_mismatch_worst_threshold_margin", 0.0) < 2e-4, rep
@@ -94,7 +96,8 @@ def test_c2_full_size_parity(cam_id):
     grads = _grads(H, W, 11 + cam_id)
     st_o, g_o = run_oracle(sc, cam, grads)
     st_h, g_h = run_hip(sc, cam, grads)
-    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, img_outliers=2e-5)
+    # images: no slack (measured <= 4e-7 at this size); n_contrib: <= 2e-5 of the pixels, each replayed in float64 by compare()
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, n_contrib_outliers=2e-5)
     # backward kernels in isolation: same alpha image on both sides -> 1e-4 of the largest entry per tensor, and element-wise
     # 5e-3 relative on every entry above 1 % of the largest (below that floor the per-tensor bound is the operative one)
     _, g_h2 = run_hip(sc, cam, grads, alpha_override=st_o["alpha"])
@@ -176,7 +179,10 @@ def test_long_tile_lists_exercise_lds_and_global_sort(P, expect_max):
     lens = st_o["ranges"][:, 1] - st_o["ranges"][:, 0]
     assert lens.max() > expect_max
     st_h, g_h = run_hip(sc, cam, grads, debug=True)
-    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, img_outliers=2e-3)
+    # 16k-entry lists of opacity-0.02 splats: alpha sits right at the 1/255 skip threshold for a large share of the (pixel,
+    # entry) pairs, so 1-ulp exp() differences do flip single contributions (|delta| <= alpha T c ~ 4e-3): the one scene built to
+    # provoke it keeps an image allowance; every n_contrib mismatch is still proven a near-tie
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, n_contrib_outliers=2e-3, img_outliers=2e-3)
 
 
 def test_huge_splats_many_tiles():
@@ -188,7 +194,7 @@ def test_huge_splats_many_tiles():
     st_o, g_o = run_oracle(sc, cam, grads)
     assert st_o["tiles_touched"].max() == 1200
     st_h, g_h = run_hip(sc, cam, grads, debug=True)
-    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, img_outliers=1e-5)
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, n_contrib_outliers=1e-5)
 
 
 def test_operator_autograd_confidence_and_determinism():
@@ -225,6 +231,43 @@ def test_operator_autograd_confidence_and_determinism():
     for k in ("m", "o", "s", "r"):
         assert torch.allclose(gc[k], g1[k] * conf, rtol=1e-6, atol=0), k
     assert torch.allclose(gc["sh"], g1["sh"] * conf[..., None], rtol=1e-6, atol=0)
+
+
+def test_no_grad_renders_skip_the_backward_preparation_and_do_not_disturb_training_renders():
+    """gvd_raster_expect_backward (advisor finding, round 2): a no-grad render does not zero the backward's partial records; the
+    images are the same bits, and a training render (forward + backward) interleaved with no-grad renders -- same thread, the
+    native flag is sticky -- gives the same gradients as without them."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = _tiny(31, P=800)
+    cam = sc["cameras"][0]
+    H, W, P = 70, 100, 800
+    t = lambda a, rg=False: torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=rg)
+    s = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], t(sc["bg"]), 1.0, t(cam["viewmatrix"]),
+                                      t(cam["projmatrix"]), 3, t(cam["campos"]), False, False, torch.ones(P, 1, device=dev))
+    gC = torch.randn(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+
+    def train():
+        lv = dict(means3D=t(sc["means3D"], True), opacities=t(sc["opacities"], True), scales=t(sc["scales"], True),
+                  rotations=t(sc["rotations"], True), shs=t(sc["shs"], True), means2D=torch.zeros(P, 3, device=dev, requires_grad=True))
+        color, _, depth, alpha = GaussianRasterizer(s)(**lv)
+        torch.autograd.backward([color], [gC])
+        return color.detach().clone(), {k: v.grad.clone() for k, v in lv.items()}
+
+    def infer():
+        with torch.no_grad():
+            color, _, _, _ = GaussianRasterizer(s)(means3D=t(sc["means3D"]), means2D=torch.zeros(P, 3, device=dev),
+                                                    opacities=t(sc["opacities"]), shs=t(sc["shs"]), scales=t(sc["scales"]),
+                                                    rotations=t(sc["rotations"]))
+        return color.clone()
+
+    c_ref, g_ref = train()
+    for _ in range(3):
+        assert torch.equal(infer(), c_ref)          # same bits without the preparation
+        c, g = train()                              # ... and the next training render prepares its own chunk again
+        assert torch.equal(c, c_ref)
+        for k in g_ref:
+            assert torch.equal(g[k], g_ref[k]), k
 
 
 def test_mark_visible_matches_oracle(oracle):
