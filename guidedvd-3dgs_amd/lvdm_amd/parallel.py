@@ -144,42 +144,60 @@ def pixels_to_frames(t, shard, P):
 
 
 class ParallelPlan:
-    """cfg x frames layout of an initialised default process group."""
+    """cfg x frames layout over an initialised default process group, or over a SUB-GROUP of it.
 
-    def __init__(self, n_frames, cfg=None, world=None, rank=None):
-        world = dist.get_world_size() if world is None else world
-        rank = dist.get_rank() if rank is None else rank
+    ranks: the global ranks the plan spans, in plan order (default: every rank of the default group).  The constructor is
+    COLLECTIVE OVER THE DEFAULT GROUP -- `dist.new_group` must be called by every process, members or not -- so a process that
+    is not in `ranks` constructs the plan too and gets `.member == False` (it must not call anything else on it).  This is
+    what lets a node be split into a diffusion group and a raster group (guided_schedule.Roles: BASELINE configs[3] / [4])."""
+
+    def __init__(self, n_frames, cfg=None, world=None, rank=None, ranks=None):
+        g_world, g_rank = dist.get_world_size(), dist.get_rank()
+        if ranks is None:
+            ranks = list(range(g_world if world is None else world))
+        ranks = [int(r) for r in ranks]
+        if len(set(ranks)) != len(ranks) or min(ranks) < 0 or max(ranks) >= g_world:
+            raise ValueError(f"ParallelPlan: bad rank list {ranks} for a default group of {g_world}")
+        world = len(ranks)
+        if rank is None:
+            rank = ranks.index(g_rank) if g_rank in ranks else -1
+        self.ranks, self.member = ranks, rank >= 0
         if cfg is None:
             cfg = 2 if world % 2 == 0 else 1
         if world % cfg:
             raise ValueError(f"world {world} is not a multiple of the CFG degree {cfg}")
         F = world // cfg
         self.world, self.rank, self.cfg, self.F = world, rank, cfg, F
-        self.cfg_rank, self.frame_rank = rank // F, rank % F
-        # every rank must create every group, in the same order
+        self.cfg_rank, self.frame_rank = (rank // F, rank % F) if self.member else (-1, -1)
+        # every rank of the default group must create every group, in the same order
+        self.world_group = dist.group.WORLD if ranks == list(range(g_world)) else dist.new_group(ranks)
         self.frame_group = self.cfg_group = None
         for c in range(cfg):
-            g = dist.new_group([c * F + f for f in range(F)])
+            g = dist.new_group([ranks[c * F + f] for f in range(F)])
             if c == self.cfg_rank:
                 self.frame_group = g
         for f in range(F):
-            g = dist.new_group([c * F + f for c in range(cfg)])
+            g = dist.new_group([ranks[c * F + f] for c in range(cfg)])
             if f == self.frame_rank:
                 self.cfg_group = g
-        self.shard = FrameShard(self.frame_group, n_frames)
         self._world_shards = {}
-        # The latent x is replicated: every rank must draw the same x_T / per-step noise whatever its own RNG state is.
-        # One seed broadcast from rank 0; the samplers draw from plan.generator(device).  The seed is rank 0's torch seed
-        # (torch.manual_seed / seed_everything, as the reference's ViewCrafter driver sets it -- viewcrafter_wrapper.py:253-262),
-        # so user seeding governs the multi-GPU run exactly as it governs the single-GPU one: the first plan of a process draws
-        # the very stream a seeded single-GPU sampler draws from the device's global generator.  Later plans of the same
-        # process get a different (still seed-determined) stream.  `reseed()` is the explicit override.
-        global _PLANS_BUILT
-        seed = [(torch.initial_seed() + _PLANS_BUILT * 0x9E3779B97F4A7C15) % (1 << 63) if rank == 0 else 0]
-        _PLANS_BUILT += 1
-        dist.broadcast_object_list(seed, src=0)
-        self.seed = int(seed[0])
         self._generators = {}
+        global _PLANS_BUILT
+        n_built, _PLANS_BUILT = _PLANS_BUILT, _PLANS_BUILT + 1
+        if not self.member:
+            self.shard, self.seed = None, None
+            return
+        self.shard = FrameShard(self.frame_group, n_frames)
+        # The latent x is replicated: every rank must draw the same x_T / per-step noise whatever its own RNG state is.
+        # One seed broadcast from the plan's first rank; the samplers draw from plan.generator(device).  The seed is that
+        # rank's torch seed (torch.manual_seed / seed_everything, as the reference's ViewCrafter driver sets it --
+        # viewcrafter_wrapper.py:253-262), so user seeding governs the multi-GPU run exactly as it governs the single-GPU one:
+        # the first plan of a process draws the very stream a seeded single-GPU sampler draws from the device's global
+        # generator.  Later plans of the same process get a different (still seed-determined) stream.  `reseed()` is the
+        # explicit override.
+        seed = [(torch.initial_seed() + n_built * 0x9E3779B97F4A7C15) % (1 << 63) if rank == 0 else 0]
+        dist.broadcast_object_list(seed, src=ranks[0], group=self.world_group)
+        self.seed = int(seed[0])
 
     def generator(self, device):
         """The replicated-draw generator for `device` (same stream of numbers on every rank)."""
@@ -199,8 +217,8 @@ class ParallelPlan:
         """Debug aid: raise if `x` differs across ranks (one tiny all-reduce of a checksum)."""
         s = x.detach().double().sum().reshape(1)
         lo, hi = s.clone(), s.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.world_group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.world_group)
         if float(hi - lo) != 0.0:
             raise RuntimeError(f"{what} is not replicated across ranks (checksum spread {float(hi - lo):.3e})")
 
@@ -278,5 +296,5 @@ class ParallelPlan:
         """[b, 4, my frames, h, w] per-frame gradients of `frame_owner_slices` -> all frames, on every rank."""
         ws = self._world_shards.get(n_frames)
         if ws is None:
-            ws = self._world_shards[n_frames] = FrameShard(dist.group.WORLD, n_frames)
+            ws = self._world_shards[n_frames] = FrameShard(self.world_group, n_frames)
         return ws.gather(g_local, 2)

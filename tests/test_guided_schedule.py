@@ -1,0 +1,361 @@
+"""BASELINE configs[3] / [4]: the raster group || diffusion group schedule (guidedvd-3dgs_amd/guided_schedule.py).
+
+CPU (gloo): the hand-off protocol, the role layouts (1 + 1, both roles on both ranks, 4 + 4 with the diffusion group frame-sharded
+4-way and the guidance renders view-sharded 4-way) and the `deliver_after` semantics must reproduce the single-process run of the
+same schedule.  The raster side is a tiny torch stand-in there (the product rasterizer has no CPU path, by design); the diffusion
+side is the miniature U-Net + VAE of test_ddim_parallel_gloo.py under the explicit reference math.
+
+GPU (`-m gpu`): (a) co-residency -- the real rasterizer's training loop with the full-size 1.44 B-parameter U-Net + VAE resident and a
+guided diffusion run at 320x448 in between must leave the Gaussians BIT-IDENTICAL to the standalone loop; (b) two ranks on the one GPU
+(gloo carrying the hand-offs): raster rank || diffusion rank with the HIP kernels on both sides against the single-process run.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(ROOT, "guidedvd-3dgs_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from test_ddim_parallel_gloo import HL, SMALL_UNET, SMALL_VAE, T, WL, _free_port   # noqa: E402
+
+H_IMG, W_IMG = 12, 10          # toy raster resolution
+N_TRAIN = 3
+TOTAL, CADENCE = 7, 3          # runs are triggered at the end of iterations 1, 4, 7
+
+
+class ToyRaster:
+    """CPU stand-in for the raster side: `n_views` images parameterised by a tensor, plain SGD towards fixed targets and, once
+    frames exist, towards the generated frames.  Deterministic; what is under test is the schedule, not the rasterizer."""
+
+    def __init__(self, roles):
+        import guided_schedule as gs
+        self.gs, self.roles = gs, roles
+        g = torch.Generator().manual_seed(11)
+        self.scene = torch.randn(T, 3, H_IMG, W_IMG, generator=g).requires_grad_(True)
+        self.targets = torch.rand(N_TRAIN, 3, H_IMG, W_IMG, generator=g)
+        self.pseudo, self.consumed = [], []
+
+    def spec(self):
+        return self.gs.PacketSpec(T, H_IMG, W_IMG, 2 * HL, 2 * WL)
+
+    def train_step(self, it):
+        v = it % N_TRAIN
+        loss = (torch.sigmoid(self.scene[v]) - self.targets[v]).abs().mean()
+        if self.pseudo:
+            i, gt = self.pseudo[(it * 7) % len(self.pseudo)]
+            loss = loss + (torch.sigmoid(self.scene[i]) - gt).abs().mean()
+        (g,) = torch.autograd.grad(loss, self.scene)
+        with torch.no_grad():
+            self.scene -= 0.5 * g
+
+    def render_guidance(self, it):
+        import multiview
+        import torch.nn.functional as F
+
+        def fn(i):
+            img = torch.sigmoid(self.scene[i].detach())
+            return img, img.mean(0, keepdim=True) + 1.0, (img.sum(0, keepdim=True) / 3.0)
+        group = self.roles.raster_group
+        if group is None:
+            out = torch.stack([torch.cat(fn(i), 0) for i in range(T)], 0)
+        else:
+            out = multiview.render_views_sharded(fn, list(range(T)), group=group)
+        images, depths, alpha = out[:, :3], out[:, 3:4], out[:, 4:5]
+        cond = F.interpolate(images, size=(2 * HL, 2 * WL), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
+        return self.gs.GuidancePacket(images, 1.0 - (alpha < 0.5).float(), depths, cond, iteration=it, view=it % N_TRAIN)
+
+    def consume_video(self, it0, video, pkt):
+        import torch.nn.functional as F
+        fr = F.interpolate(video, size=(H_IMG, W_IMG), mode="bilinear", align_corners=False)
+        self.pseudo = [(i, fr[i]) for i in range(1, T)]
+        self.consumed.append(it0)
+
+
+def _mini_diffusion(plan):
+    import guided_schedule as gs
+    from fill_by_name import fill_by_name
+    from lvdm_amd import ops
+    from lvdm_amd.model import LatentDiffusion
+    ops.use_reference_math(True)
+    torch.manual_seed(0)
+    ld = LatentDiffusion(SMALL_UNET, SMALL_VAE).eval()
+    fill_by_name(ld.model, std=0.08)                # (the networks only: the schedule buffers keep the real DDPM tables)
+    fill_by_name(ld.first_stage_model, std=0.08)
+    g = torch.Generator().manual_seed(5)
+    cond = {"c_crossattn": [torch.randn(1, 77 + 16, 64, generator=g)], "c_concat": [torch.randn(1, 4, T, HL, WL, generator=g) * 0.2]}
+    uc = {"c_crossattn": [torch.randn(1, 77 + 16, 64, generator=g)], "c_concat": cond["c_concat"]}
+    return gs.GuidedDiffusionRunner(ld, cond, uc, [1, 4, T, HL, WL], (2 * HL, 2 * WL), "cpu", ddim_steps=2, plan=plan, seed=321)
+
+
+def _run_schedule(roles, plan, deliver_after):
+    import guided_schedule as gs
+    raster = ToyRaster(roles) if roles.is_raster else None
+    diffusion = _mini_diffusion(plan) if roles.is_diffusion else None
+    spec = ToyRaster.spec(raster) if raster is not None else gs.PacketSpec(T, H_IMG, W_IMG, 2 * HL, 2 * WL)
+    sched = gs.GuidedSchedule(roles, spec, (T, 3, 2 * HL, 2 * WL), "cpu", cadence=CADENCE, deliver_after=deliver_after)
+    sched.run(TOTAL, raster=raster, diffusion=diffusion)
+    out = {"events": sched.events}
+    if raster is not None:
+        out["scene"] = raster.scene.detach().clone()
+        out["consumed"] = raster.consumed
+        out["frames"] = torch.stack([f for _, f in raster.pseudo]) if raster.pseudo else None
+    return out
+
+
+def _single(deliver_after):
+    import guided_schedule as gs
+    return _run_schedule(gs.Roles.split(world=1), None, deliver_after)
+
+
+def _worker(rank, world, port, layout, cfg, deliver_after, q):
+    try:
+        import torch.distributed as dist
+        import guided_schedule as gs
+        from lvdm_amd import parallel
+        torch.set_num_threads(2)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        roles = gs.Roles.split(layout)
+        plan = parallel.ParallelPlan(T, cfg=cfg, ranks=roles.diffusion_ranks)    # collective over the default group
+        assert plan.member == roles.is_diffusion
+        out = _run_schedule(roles, plan if roles.is_diffusion else None, deliver_after)
+        out["role"] = (roles.is_raster, roles.is_diffusion, roles.describe())
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"exception": traceback.format_exc()}))
+        raise
+
+
+def _launch(world, layout, cfg, deliver_after):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, layout, cfg, deliver_after, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for _, out in res:
+        assert "exception" not in out, out["exception"]
+    for p in procs:
+        assert p.exitcode == 0
+    return dict(res)
+
+
+def test_packet_round_trip_and_trigger_iterations():
+    import guided_schedule as gs
+    spec = gs.PacketSpec(4, 6, 5, 8, 7)
+    g = torch.Generator().manual_seed(0)
+    pkt = gs.GuidancePacket(torch.rand(4, 3, 6, 5, generator=g), torch.rand(4, 1, 6, 5, generator=g), torch.rand(4, 1, 6, 5, generator=g),
+                            torch.rand(4, 8, 7, 3, generator=g), iteration=9361, view=5)
+    back = gs.GuidancePacket.unpack(pkt.pack(spec), spec)
+    assert spec.bytes() == 4 * (4 * 5 * 30 + 4 * 8 * 7 * 3 + 2)
+    for k in ("images", "masks", "depths", "cond"):
+        assert torch.equal(getattr(back, k), getattr(pkt, k))
+    assert (back.iteration, back.view) == (9361, 5)
+    sched = gs.GuidedSchedule(gs.Roles.split(world=1), spec, (4, 3, 8, 7), "cpu", cadence=260, end_sample=9500)
+    trig = sched.triggers(10000)
+    assert trig[:3] == [1, 261, 521] and trig[-1] == 9361 and len(trig) == 37      # train_guidedvd.py:431: 37 runs per scene
+    with pytest.raises(ValueError):
+        gs.GuidedSchedule(gs.Roles.split(world=1), spec, (4, 3, 8, 7), "cpu", cadence=3, deliver_after=4)
+
+
+def test_single_process_schedule_semantics():
+    """D = 0 is the reference's blocking order (frames of the run at iteration i are in the stack for iteration i + 1); D = 2
+    delays their use by exactly two iterations and nothing else."""
+    a, b = _single(0), _single(2)
+    assert a["events"] == [("trigger", 1), ("deliver", 1), ("trigger", 4), ("deliver", 4), ("trigger", 7), ("deliver", 7)]
+    assert b["events"] == [("trigger", 1), ("deliver", 1), ("trigger", 4), ("deliver", 4), ("trigger", 7), ("deliver", 7)]
+    assert a["consumed"] == b["consumed"] == [1, 4, 7]
+    assert not torch.equal(a["scene"], b["scene"])       # the delay is visible in the optimisation ...
+    assert float((a["scene"] - b["scene"]).abs().max()) < 0.5
+
+
+@pytest.mark.parametrize("world,layout,cfg,deliver_after", [(2, "disjoint", 1, 0), (2, "disjoint", 1, 2), (2, "shared", 2, 1),
+                                                            (8, "disjoint", 1, 2)])
+def test_layouts_reproduce_the_single_process_run(world, layout, cfg, deliver_after):
+    """(2, disjoint): BASELINE configs[3] second half -- raster rank || diffusion rank.  (2, shared): both ranks hold both roles
+    (diffusion as a CFG pair, raster replicated).  (8, disjoint): configs[4] -- ranks 0-3 rasterize (guidance renders sharded per
+    view, one all-gather), ranks 4-7 diffuse (4 frame shards), raster leader -> diffusion group and diffusion leader -> raster
+    group hand-offs.  Results equal the single-process run of the same schedule up to summation order -- sharded diffusion, and the workers'
+    2 CPU threads against the parent's -- through two guided DDIM steps (measured 3e-5; bar 2e-4 of the frames' [0, 1] range);
+    replicas of the raster group are bit-identical to each other."""
+    ref = _single(deliver_after)
+    res = _launch(world, layout, cfg, deliver_after)
+    rasters = [r for r in sorted(res) if res[r]["role"][0]]
+    assert rasters, res
+    for r in rasters:
+        out = res[r]
+        assert [e for e in out["events"] if e[0] != "generate"] == ref["events"], (r, out["events"])
+        assert out["consumed"] == ref["consumed"]
+        assert float((out["frames"] - ref["frames"]).abs().max()) < 2e-4, (r, float((out["frames"] - ref["frames"]).abs().max()))
+        assert float((out["scene"] - ref["scene"]).abs().max()) < 2e-4
+        assert torch.equal(out["scene"], res[rasters[0]]["scene"])    # no gradient exchange needed: replicas stay identical
+    diff_only = [r for r in sorted(res) if res[r]["role"][1] and not res[r]["role"][0]]
+    for r in diff_only:
+        assert res[r]["events"] == [("generate", 1), ("generate", 4), ("generate", 7)]
+    if layout == "disjoint":
+        assert len(rasters) == world // 2 and len(diff_only) == world // 2
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------------------------------------
+def _gpu_scene(P=60_000):
+    import synthetic as syn
+    sc = syn.scene_c2(P=P, W=640, H=480)
+    traj = syn.scene_c2(P=8, W=640, H=480, n_cams=25)["cameras"]     # 25 ring cameras: the trajectory of one diffusion run
+    return sc, traj
+
+
+@pytest.mark.gpu
+def test_config4_co_residency_leaves_the_raster_loop_bit_identical():
+    """BASELINE configs[3], first half, small: 20 training iterations (train view + loss + backward + Adam; 640x480) with the
+    full-size ViewCrafter U-Net (1.44 B parameters) and KL-VAE resident on the same GPU and ONE guided diffusion run (25 frames,
+    320x448, 2 guided DDIM steps + the final decode) executed after iteration 1.  The frames are delivered after the last
+    iteration (deliver_after = 19), so the 20 training steps must be exactly those of the standalone loop: every optimised tensor
+    bit-identical.  Also: finite latents / frames, guidance consumed, peak memory reported."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    import guided_schedule as gs
+    dev = torch.device("cuda:0")
+    sc, traj = _gpu_scene()
+    roles = gs.Roles.split(world=1)
+
+    def loop(with_diffusion):
+        raster = gs.RasterTrainer(sc, traj, dev, roles, cond_hw=(320, 448))
+        sched = gs.GuidedSchedule(roles, raster.spec(), (25, 3, 320, 448), dev, cadence=20 if with_diffusion else 1000, end_sample=2,
+                                  deliver_after=19 if with_diffusion else 0)
+        diffusion = None
+        if with_diffusion:
+            ld = gs.synthetic_latent_diffusion(dev)
+            g = torch.Generator(device=dev).manual_seed(0)
+            cond = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g)],
+                    "c_concat": [torch.randn(1, 4, 25, 40, 56, device=dev, generator=g) * 0.18]}
+            uc = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g)], "c_concat": cond["c_concat"]}
+            diffusion = gs.GuidedDiffusionRunner(ld, cond, uc, [1, 4, 25, 40, 56], (320, 448), dev, ddim_steps=2)
+        else:
+            class _Never:
+                def generate(self, pkt):
+                    raise AssertionError("no run is triggered in the standalone loop")
+            diffusion = _Never()
+            sched.triggers = lambda total: []
+        torch.cuda.reset_peak_memory_stats()
+        sched.run(20, raster=raster, diffusion=diffusion)
+        return raster, diffusion, sched, torch.cuda.max_memory_allocated() / 2 ** 30
+
+    r0, _, _, mem0 = loop(False)
+    r1, d1, s1, mem1 = loop(True)
+    assert s1.events == [("trigger", 1), ("deliver", 1)] and r1.runs_consumed == [1]
+    st0, st1 = r0.state(), r1.state()
+    for k in st0:
+        assert torch.equal(st0[k], st1[k]), k                      # co-residency does not perturb the raster path
+    assert torch.isfinite(d1.last_latent).all() and d1.last_latent.shape == (1, 4, 25, 40, 56)
+    assert len(r1.pseudo) == 24 and all(torch.isfinite(f).all() and f.shape == (3, 480, 640) for _, f in r1.pseudo)
+    fr = torch.stack([f for _, f in r1.pseudo])
+    assert 0.0 <= float(fr.min()) and float(fr.max()) <= 1.0 and float(fr.std()) > 1e-3
+    print(f"config4 co-residency: peak {mem1:.1f} GiB with both model sets resident ({mem0:.2f} GiB raster alone); "
+          f"phases {dict((k, round(v, 3)) for k, v in s1.times.items())}")
+    assert mem1 < 120.0
+
+
+def _gpu_worker(rank, world, port, deliver_after, q):
+    try:
+        import torch.distributed as dist
+        import guided_schedule as gs
+        from fill_by_name import fill_by_name
+        from lvdm_amd import parallel
+        from lvdm_amd.model import LatentDiffusion
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        if world > 1:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        roles = gs.Roles.split("disjoint")
+        plan = parallel.ParallelPlan(T, cfg=1, ranks=roles.diffusion_ranks) if world > 1 else None
+        raster = diffusion = None
+        sc, traj = _gpu_scene(P=20_000)
+        traj = traj[:T]
+        if roles.is_raster:
+            raster = gs.RasterTrainer(sc, traj, dev, roles, cond_hw=(2 * HL, 2 * WL), lr=1e-3)
+        if roles.is_diffusion:
+            torch.manual_seed(0)
+            ld = LatentDiffusion(SMALL_UNET, SMALL_VAE).eval()
+            fill_by_name(ld.model, std=0.08)
+            fill_by_name(ld.first_stage_model, std=0.08)
+            ld = ld.to(dev)
+            ld.model.diffusion_model.half().to_token_major()
+            ld.first_stage_model.half().to_token_major()
+            ld.requires_grad_(False)
+            am, dc = ld.apply_model, ld.decode_core
+            ld.apply_model = lambda x, t, c, **kw: am(x.half(), t, {k: [v.half() for v in vs] for k, vs in c.items()}, **kw)
+            ld.decode_core = lambda z, **kw: dc(z.half(), **kw)
+            g = torch.Generator().manual_seed(5)
+            mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+            cond = {"c_crossattn": [mk(1, 93, 64)], "c_concat": [mk(1, 4, T, HL, WL) * 0.2]}
+            uc = {"c_crossattn": [mk(1, 93, 64)], "c_concat": cond["c_concat"]}
+            diffusion = gs.GuidedDiffusionRunner(ld, cond, uc, [1, 4, T, HL, WL], (2 * HL, 2 * WL), dev, ddim_steps=3,
+                                                 plan=plan if (plan is not None and plan.member) else None, seed=77)
+        spec = gs.PacketSpec(T, 480, 640, 2 * HL, 2 * WL)
+        sched = gs.GuidedSchedule(roles, spec, (T, 3, 2 * HL, 2 * WL), dev, cadence=4, deliver_after=deliver_after)
+        sched.run(9, raster=raster, diffusion=diffusion)
+        out = {"events": sched.events, "role": (roles.is_raster, roles.is_diffusion)}
+        if raster is not None:
+            out["state"] = {k: v.cpu() for k, v in raster.state().items()}
+            out["frames"] = torch.stack([f for _, f in raster.pseudo]).cpu()
+        q.put((rank, out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"exception": traceback.format_exc()}))
+        raise
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deliver_after", [0, 3])
+def test_raster_rank_and_diffusion_rank_on_one_gpu_match_the_single_process_run(deliver_after):
+    """BASELINE configs[3], second half, on the one GPU the test box has: rank 0 = the real rasterizer's training loop + guidance
+    renders, rank 1 = the guided sampler on the HIP kernels (fp16 miniature U-Net + VAE), gloo carrying the two hand-offs.  Against
+    the same schedule in ONE process: identical event order; the generated frames agree to fp16-kernel reproducibility (the
+    kernels are deterministic; the statistics' fp64 atomics are not ordered) and the Gaussians to what those frames imply."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    ctx = mp.get_context("spawn")
+
+    def run(world):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, deliver_after, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=900) for _ in procs]
+        for p in procs:
+            p.join(timeout=120)
+        for _, out in res:
+            assert "exception" not in out, out["exception"]
+        return dict(res)
+
+    ref = run(1)[0]
+    two = run(2)
+    assert two[0]["role"] == (True, False) and two[1]["role"] == (False, True)
+    assert two[0]["events"] == ref["events"] == [("trigger", 1), ("deliver", 1), ("trigger", 5), ("deliver", 5), ("trigger", 9), ("deliver", 9)]
+    assert two[1]["events"] == [("generate", 1), ("generate", 5), ("generate", 9)]
+    err = float((two[0]["frames"] - ref["frames"]).abs().max())
+    assert err < 2e-3, err
+    for k, v in ref["state"].items():
+        scale = float(v.abs().max())
+        assert float((two[0]["state"][k] - v).abs().max()) <= 1e-3 * scale, k
