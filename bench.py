@@ -742,10 +742,10 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     ev_attn, ev_conv = [], []
     orig_attn, orig_conv = ops._hip_attention_fwd, mconv._launch
 
-    def timed_attn(q, k, v, heads, frame_major=False, want_lse=False):
+    def timed_attn(q, k, v, heads, frame_major=False, want_lse=False, **kw):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        o = orig_attn(q, k, v, heads, frame_major, want_lse)
+        o = orig_attn(q, k, v, heads, frame_major, want_lse, **kw)
         b.record()
         nb, nq, nk = (q.shape[1], q.shape[0], k.shape[0]) if frame_major else (q.shape[0], q.shape[1], k.shape[1])
         ev_attn.append((a, b, 4.0 * nb * heads * nq * nk * 64))

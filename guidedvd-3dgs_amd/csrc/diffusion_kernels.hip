@@ -52,8 +52,9 @@ namespace {
 
 template <typename T, int WAVES, int QB>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2)))
-k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out, float* __restrict__ lse,
-           int H, int Nq, int Nk, float scale_log2e, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs)
+k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* out, float* __restrict__ lse,
+           int H, int Nq, int Nk, float scale_log2e, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
+           long long o_bs, long long o_rs, const T* accum, float accum_scale)   // (accum may alias out)
 {
     // QB = query blocks (of 32) per wave.  QB = 2 halves the LDS reads and K/V staging per flop (every A operand feeds
     // two MFMAs) and gives the wave two independent softmax chains to interleave with the matrix pipe.
@@ -71,7 +72,8 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     const T* qb = q + (size_t)b * q_bs + (size_t)h * 64;
     const T* kb = k + (size_t)b * kv_bs + (size_t)h * 64;
     const T* vb = v + (size_t)b * kv_bs + (size_t)h * 64;
-    T* ob = out + (size_t)b * q_bs + (size_t)h * 64;
+    T* ob = out + (size_t)b * o_bs + (size_t)h * 64;                  // out (and accum) have their own strides: q may be a column
+    const T* ab = accum ? accum + (size_t)b * o_bs + (size_t)h * 64 : nullptr;   // block of a packed [.., q | k | v] projection
 
     int query[QB];
     bool valid_q[QB];
@@ -323,7 +325,7 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         // log2-domain log-sum-exp of the scaled scores, kept for the backward kernels: P = exp2(s*c - lse)
         if (lse && hi == 0) lse[(size_t)bh * Nq + query[qi]] = m[qi] + __builtin_amdgcn_logf(l[qi]);
         const float inv = 1.0f / l[qi];
-        T* orow = ob + (size_t)query[qi] * rs;
+        T* orow = ob + (size_t)query[qi] * (size_t)o_rs;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             const int d0 = 8 * rg + 4 * hi;
@@ -332,6 +334,21 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
             w0.y = Tr<T>::pack2(o0[qi][4 * rg + 2] * inv, o0[qi][4 * rg + 3] * inv);
             w1.x = Tr<T>::pack2(o1[qi][4 * rg] * inv, o1[qi][4 * rg + 1] * inv);
             w1.y = Tr<T>::pack2(o1[qi][4 * rg + 2] * inv, o1[qi][4 * rg + 3] * inv);
+            if (ab) {   // out = accum + accum_scale * O, rounded like the separate ops (O to 16 bit first): the image-token branch
+                        // of the cross-attention lands on the text branch's result (attention.py:129-142) without an add kernel
+                typedef T T4 __attribute__((ext_vector_type(4)));
+                const T* arow = ab + (size_t)query[qi] * (size_t)o_rs;
+                const T4 a0 = *reinterpret_cast<const T4*>(arow + d0), a1 = *reinterpret_cast<const T4*>(arow + 32 + d0);
+                const T4 n0 = __builtin_bit_cast(T4, w0), n1 = __builtin_bit_cast(T4, w1);
+                T4 r0, r1;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    r0[e] = (T)((float)a0[e] + (float)(T)(accum_scale * (float)n0[e]));
+                    r1[e] = (T)((float)a1[e] + (float)(T)(accum_scale * (float)n1[e]));
+                }
+                w0 = __builtin_bit_cast(uint2, r0);
+                w1 = __builtin_bit_cast(uint2, r1);
+            }
             *reinterpret_cast<uint2*>(orow + d0) = w0;
             *reinterpret_cast<uint2*>(orow + 32 + d0) = w1;
         }
@@ -928,8 +945,17 @@ int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void*
                               float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs, float* lse,
                               int is_bf16, void* stream_)
 {
+    return gvd_attention_fwd_ex(q, k, v, out, B, H, Nq, Nk, D, scale, q_bs, q_rs, kv_bs, kv_rs, q_bs, q_rs, nullptr, 1.0f, lse,
+                                is_bf16, stream_);
+}
+
+int gvd_attention_fwd_ex(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                         float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs, long long o_bs,
+                         long long o_rs, const void* accum, float accum_scale, float* lse, int is_bf16, void* stream_)
+{
     hipStream_t stream = (hipStream_t)stream_;
-    if ((q_bs | q_rs | kv_bs | kv_rs) & 7) return fail(-1, "gvd_attention_fwd: strides must be multiples of 8 elements");
+    if ((q_bs | q_rs | kv_bs | kv_rs | o_bs | o_rs) & 7) return fail(-1, "gvd_attention_fwd: strides must be multiples of 8 elements");
+    if ((uintptr_t)accum & 15) return fail(-1, "gvd_attention_fwd: accum must be 16-byte aligned");
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return fail(-1, "gvd_attention_fwd: bad arguments");
     if (D != 64) return fail(-1, "gvd_attention_fwd: head dim must be 64");
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(-1, "gvd_attention_fwd: pointers must be 16-byte aligned");
@@ -942,7 +968,7 @@ int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void*
     dim3 grid((unsigned)(B * H), (unsigned)((Nq + rows - 1) / rows));
 #define GVD_ATTN_LAUNCH(T, W, Q)                                                                                          \
     hipLaunchKernelGGL((k_attn_fwd<T, W, Q>), grid, dim3(W * 64), 0, stream, (const T*)q, (const T*)k, (const T*)v, (T*)out, lse, \
-                       H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs)
+                       H, Nq, Nk, sl2, q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs, (const T*)accum, accum_scale)
     if (is_bf16) {
         if (mode == 2) GVD_ATTN_LAUNCH(__bf16, 4, 2); else if (mode == 1) GVD_ATTN_LAUNCH(__bf16, 4, 1); else GVD_ATTN_LAUNCH(__bf16, 1, 1);
     } else {

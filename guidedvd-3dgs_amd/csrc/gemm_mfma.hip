@@ -1,0 +1,540 @@
+// gemm_mfma.hip -- hand-written gfx950 NT GEMM  Y[M, N] = X[M, K] . W[N, K]^T  on MFMA 32x32x16 with the transformer-side
+// epilogues of the ViewCrafter U-Net fused in (C-ABI: include/gvd_diffusion.h, gvd_gemm_nt / gvd_row_stats).
+//
+// Replaces (reference lines, all nn.Linear / 1x1 convolutions on token rows; hipBLASLt through F.linear until round 2):
+//   CrossAttention  to_q / to_k / to_v / to_out (+ to_k_ip / to_v_ip)          lvdm/modules/attention.py:53-57,76,86-99,144
+//   BasicTransformerBlock  x + attn(LayerNorm(x)), x + ff(LayerNorm(x))         attention.py:212-246  (LayerNorm folded, residual fused)
+//   GEGLU / FeedForward                                                         attention.py:415-442  (gate fused)
+//   SpatialTransformer / TemporalTransformer proj_in / proj_out (+ x_in)        attention.py:249-412
+//   ResBlock emb_layers, skip_connection (1x1), time / fps embedding MLPs       lvdm/modules/networks/openaimodel3d.py:109-236,360-387
+//   VAE AttnBlock q / k / v / proj_out (1x1 convolutions) and its d = 512 attention as chunked GEMMs   ae_modules.py:26-78
+//
+// Layout: X rows = tokens (row stride ldx), W rows = output channels (row stride ldw), both K-contiguous 16-bit; Y rows = tokens.
+//
+// Design (one workgroup = 512 threads = 8 waves, one workgroup per CU):
+//   * Tile: BN = 320 (or 256) output channels x 256 tokens, K in steps of 64.  Waves 2 (channels) x 4 (tokens); a wave owns
+//     160 (128) channels x 64 tokens = 5 (4) x 2 MFMA 32x32 blocks: 10 (8) MFMAs per 7 (6) operand reads, 160 (128) accumulator
+//     registers.  MFMA roles as in conv_mfma.hip: A = W rows (channels), B = X rows (tokens): a lane ends with 4 consecutive
+//     channels of ONE token per register quad, so the epilogue writes channel-contiguous rows.
+//   * Staging is LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass): the LDS image of a stage is
+//     [BN + 256 rows][128 B], filled linearly (wave base + lane x 16 B); the bank-conflict-free layout for the ds_read_b128
+//     operand reads (16-lane groups {0-3,12-15,20-27} ...) is an XOR of the 16-byte slot with ((row >> 1) & 7), applied to the
+//     per-lane GLOBAL address (inside the row's own 128-byte line, so coalescing is untouched) and to the read address.
+//   * Two LDS stages (2 x 72 KiB): the DMA of K-tile t+1 is in flight under the 40 MFMAs of tile t; one barrier per K-tile.
+//   * PERSISTENT workgroups (one per CU) walk their tiles; the first K-tile of the NEXT tile is issued before the epilogue of
+//     the current one, so its HBM / L2 latency hides under the epilogue's stores (with K = 320 a tile is only 5 K-steps long).
+//   * Epilogue straight from the accumulator registers (no LDS round trip, no barriers): scale, the LAYERNORM FOLD, bias in
+//     fp32; GEGLU gate; 16-bit rounding; residual; 16-byte row-contiguous stores -- the two wave halves, which hold channels
+//     8 rg + [0, 4) and 8 rg + [4, 8) of a token, exchange 8-byte halves with v_permlane32_swap to own whole octets.
+//   * LayerNorm fold: LN(x) W^T = rstd (x W'^T - mean s) + c with W' = W gamma (per input channel), s[n] = sum_k W'[n, k],
+//     c[n] = sum_k beta[k] W[n, k] + bias[n]: the GEMM runs on the raw tokens and the normalisation is two per-row scalars
+//     (gvd_row_stats) and two per-column vectors in the epilogue -- no normalised tensor is ever written or read.
+//   * Slot -> tile map is XCD-aware: workgroup b runs on XCD b % 8 (observed) and keeps to slots = b mod 8; the column tiles
+//     of one token tile are consecutive slots of ONE XCD, so the 256-token panel is pulled through one L2 once.
+#include <stdlib.h>
+
+#include "diffusion_common.h"
+
+using namespace gvdd;
+
+namespace {
+
+struct GemmArgs {
+    const void* x; const void* w; void* y;
+    long long ldx, ldw, ldy, sx, sw, sy;   // row / batch strides (elements)
+    int M, N, K, batch;
+    int tiles_m, tiles_n, mgroups;         // mgroups = ceil(tiles_m / 8)
+    float alpha;                           // scale on the accumulator (1 / sqrt(d) for attention scores)
+    const float* bias;                     // [N] or nullptr (added after the fold)
+    const float2* row_stats;               // [batch][M] (mean, rstd) or nullptr
+    const float* col_sum;                  // [N] s[n] (with row_stats)
+    const void* res; long long ldr, sr;    // residual rows (layout of y) or nullptr
+    int geglu;                             // W rows in [16 value | 16 gate] blocks (gvd_diffusion.h); y has N / 2 columns
+    int dbg;                               // experiments only (GVD_GEMM_DBG): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue stores
+};
+
+constexpr int BK = 64, ROWB = 128, BM = 256, NI = 2, WN = 4, WM = 2, NT = 512;
+__device__ const uint4 g_zero16 = { 0u, 0u, 0u, 0u };   // source of K-tail slots
+
+// exact-form GELU 0.5 g (1 + erf(g / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: far below the 16-bit rounding
+// of the result), ~12 instructions with v_exp / v_rcp instead of libdevice erff's ~40 -- the gate runs once per output element
+__device__ __forceinline__ float gelu_erf(float g)
+{
+    const float x = fabsf(g) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    return 0.5f * g * (1.f + copysignf(erf_abs, g));
+}
+
+// pack four fp32 values to 16 bit: (lo dword, hi dword)
+template <typename T>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(Tr<T>::pack2(a, b), Tr<T>::pack2(c, d)); }
+
+template <typename T, int MI>
+__global__ void __launch_bounds__(NT, 2) k_gemm_nt(const GemmArgs a)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int BN = WM * MI * 32;
+    constexpr int STAGE = (BN + BM) * ROWB;
+    constexpr int NP = STAGE / (NT * 16);           // DMA pieces per thread per stage: 9 (BN 320) / 8 (BN 256)
+    static_assert(STAGE % (NT * 16) == 0 && BN % 64 == 0, "a piece is one kind of row");
+    constexpr int NPW = BN / 64;                    // pieces 0 .. NPW-1 are W rows, the rest X rows
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, r32 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kslot = (tid & 7) ^ (((tid >> 3) >> 1) & 7);  // logical 16-byte slot (8 channels) stored at physical slot tid & 7
+    const int nk = (a.K + BK - 1) / BK, nk_full = a.K / BK;
+
+    // ---- persistent workgroup: slots s = blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0, so a workgroup stays on "its" XCD's
+    //      slots); slot -> (batch, token tile, channel tile): the channel tiles of a token tile are consecutive slots of ONE XCD,
+    //      i.e. they run back to back there and the 256-token panel is pulled through one L2 once ----
+    const int per_batch = a.mgroups * 8 * a.tiles_n, total = per_batch * a.batch;
+    auto decode = [&](int slot, int& b, int& m0, int& n0) {
+        b = slot / per_batch;
+        const int r = slot - b * per_batch, xcd = r & 7, j = r >> 3;
+        const int tm = (j / a.tiles_n) * 8 + xcd;
+        m0 = tm * BM;
+        n0 = (j % a.tiles_n) * BN;
+        return tm < a.tiles_m;
+    };
+    auto next_valid = [&](int slot) {
+        int b, m0, n0;
+        while (slot < total && !decode(slot, b, m0, n0)) slot += gridDim.x;
+        return slot;
+    };
+
+    // ---- DMA source map: piece p of this thread fills LDS bytes [p * 8192 + tid * 16, +16) of a stage; 32-bit byte offsets
+    //      from the tile's two (wave-uniform) bases ----
+    const char* wbase = nullptr;
+    const char* xbase = nullptr;
+    unsigned off[NP];                                        // ((p * 64) does not change ((row >> 1) & 7))
+    auto aim = [&](int b, int m0, int n0) {
+        wbase = reinterpret_cast<const char*>((const T*)a.w + (size_t)b * a.sw + (size_t)n0 * a.ldw);
+        xbase = reinterpret_cast<const char*>((const T*)a.x + (size_t)b * a.sx + (size_t)m0 * a.ldx);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int r = p * 64 + (tid >> 3);              // LDS row of the stage
+            if (p < NPW) {
+                const int lim = a.N - 1 - n0;
+                off[p] = (unsigned)(((long long)(r < lim ? r : lim) * a.ldw + kslot * 8) * 2);
+            } else {
+                const int lim = a.M - 1 - m0, rr = r - BN;
+                off[p] = (unsigned)(((long long)(rr < lim ? rr : lim) * a.ldx + kslot * 8) * 2);
+            }
+        }
+    };
+    auto issue = [&](int kt, int stage) {                    // a full K-tile
+        unsigned char* dst = lds + stage * STAGE + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const char* g = (p < NPW ? wbase : xbase) + off[p] + (size_t)kt * (BK * 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(dst + p * 8192), 16, 0, 0);
+        }
+    };
+    auto issue_tail = [&](int kt, int stage) {               // the last, partial K-tile: slots past K read zeros
+        unsigned char* dst = lds + stage * STAGE + wave * 1024;
+        const bool dead = kt * BK + kslot * 8 >= a.K;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const char* g = (p < NPW ? wbase : xbase) + off[p] + (size_t)kt * (BK * 2);
+            if (dead) g = reinterpret_cast<const char*>(&g_zero16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(dst + p * 8192), 16, 0, 0);
+        }
+    };
+    auto issue_first = [&]() { if (nk_full > 0) issue(0, 0); else issue_tail(0, 0); };
+
+    // ---- MFMA operand addresses within a stage ----
+    int a_off[4], b_off[NI];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) a_off[ks] = (wm * MI * 32 + r32) * ROWB + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4);
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) b_off[ni] = (BN + (wn * NI + ni) * 32 + r32) * ROWB;
+
+    int slot = next_valid(blockIdx.x);
+    if (slot >= total) return;
+    int cb, cm0, cn0;
+    decode(slot, cb, cm0, cn0);
+    aim(cb, cm0, cn0);
+    issue_first();
+
+    while (true) {
+        f16v acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) acc[mi][ni] = f16v{};
+
+        for (int kt = 0; kt < nk; kt++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                 // tile kt landed for everyone; stage (kt + 1) & 1 is free
+            if (!(a.dbg & 1)) {
+                if (kt + 1 < nk_full) issue(kt + 1, (kt + 1) & 1);
+                else if (kt + 1 < nk) issue_tail(kt + 1, (kt + 1) & 1);
+            }
+            const unsigned char* st = lds + (kt & 1) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                vec8 af[MI], bf[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const vec8*>(st + a_off[ks] + mi * 32 * ROWB);
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++)
+                    bf[ni] = *reinterpret_cast<const vec8*>(st + b_off[ni] + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4));
+                if (a.dbg & 2) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ni++) acc[mi][ni][0] += (float)af[mi][0] * (float)bf[ni][0];
+                    continue;
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
+            }
+        }
+        __syncthreads();   // all operand reads retired: both stages are free
+
+        // ---- the next tile's first K-tile goes out now: its latency hides under this tile's epilogue ----
+        const int tb = cb, tm0 = cm0, tn0 = cn0;
+        slot = next_valid(slot + gridDim.x);
+        const bool more = slot < total;
+        if (more) {
+            decode(slot, cb, cm0, cn0);
+            aim(cb, cm0, cn0);
+            issue_first();
+        }
+
+        // ---- epilogue straight from the accumulators: a lane holds, per 32x32 block (mi, ni), 4 x 4 consecutive channels
+        //      (8 rg + 4 hi + e) of ONE token; scale, LayerNorm fold and bias in fp32, then 16-byte stores ----
+        if (a.dbg & 4) { if (!more) break; continue; }
+        T* __restrict__ yb = (T*)a.y + (size_t)tb * a.sy;
+        const T* __restrict__ rb = a.res ? (const T*)a.res + (size_t)tb * a.sr : nullptr;
+        const float2* __restrict__ rs = a.row_stats ? a.row_stats + (size_t)tb * a.M : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int m = tm0 + (wn * NI + ni) * 32 + r32;
+            const bool row_ok = m < a.M;
+            float mean = 0.f, rstd = 1.f;
+            if (rs && row_ok) { const float2 sm = rs[m]; mean = sm.x; rstd = sm.y; }
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int blk = wm * MI + mi, cblk = tn0 + blk * 32;     // first tile column (W row) of this 32-channel block
+                if (cblk >= a.N) continue;                                // (wave-uniform)
+                float v[16];
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int c = cblk + 8 * rg + 4 * hi;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = bv;
+                    if (c < a.N) {
+                        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + c);
+                        if (rs) sv = *reinterpret_cast<const float4*>(a.col_sum + c);
+                    }
+                    const float bq[4] = { bv.x, bv.y, bv.z, bv.w }, sq[4] = { sv.x, sv.y, sv.z, sv.w };
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float f = acc[mi][ni][4 * rg + e] * a.alpha;
+                        if (rs) f = rstd * fmaf(-mean, sq[e], f);
+                        v[4 * rg + e] = f + bq[e];
+                    }
+                }
+                if (a.geglu) {
+                    // tile columns 0-15 of the block are values, 16-31 their gates (same rg & 1, hi, e): this lane owns the 8
+                    // consecutive outputs 8 hi + 4 rg + e (rg = 0, 1) of the block's 16 -- one 16-byte store, no exchange
+                    float o[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const T av = (T)v[q], gv = (T)v[8 + q];          // rounded like the unfused pair (k_geglu)
+                        const T ge = (T)gelu_erf((float)gv);
+                        o[q] = (float)av * (float)ge;
+                    }
+                    const int oc = (tn0 >> 1) + blk * 16 + 8 * hi;
+                    if (row_ok && cblk + 4 * hi < a.N) {
+                        uint4 w = make_uint4(Tr<T>::pack2(o[0], o[1]), Tr<T>::pack2(o[2], o[3]), Tr<T>::pack2(o[4], o[5]), Tr<T>::pack2(o[6], o[7]));
+                        if (rb) {
+                            const uint4 r = *reinterpret_cast<const uint4*>(rb + (size_t)m * a.ldr + oc);
+                            const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
+                            unsigned oo[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const T2 x2 = __builtin_bit_cast(T2, wi[q]), r2 = __builtin_bit_cast(T2, ri[q]);
+                                oo[q] = Tr<T>::pack2((float)x2[0] + (float)r2[0], (float)x2[1] + (float)r2[1]);
+                            }
+                            w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                        }
+                        *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + oc) = w;
+                    }
+                } else {
+                    // the two wave halves hold channels 8 rg + [0, 4) and 8 rg + [4, 8): one v_permlane32_swap per dword gives
+                    // lanes 0-31 the whole octet of rg = 0 / 2 and lanes 32-63 the octet of rg = 1 / 3 (16-byte stores)
+#pragma unroll
+                    for (int pr = 0; pr < 2; pr++) {
+                        const uint2 p0 = pack4<T>(v[8 * pr], v[8 * pr + 1], v[8 * pr + 2], v[8 * pr + 3]);
+                        const uint2 p1 = pack4<T>(v[8 * pr + 4], v[8 * pr + 5], v[8 * pr + 6], v[8 * pr + 7]);
+                        const auto sl = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
+                        const auto sh = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
+                        uint4 w = make_uint4(sl[0], sh[0], sl[1], sh[1]);
+                        const int c = cblk + 8 * (2 * pr + hi);
+                        if (row_ok && c < a.N) {
+                            if (rb) {
+                                const uint4 r = *reinterpret_cast<const uint4*>(rb + (size_t)m * a.ldr + c);
+                                const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
+                                unsigned oo[4];
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {   // the 16-bit sum of the ROUNDED product and the residual, as the separate ops
+                                    const T2 x2 = __builtin_bit_cast(T2, wi[q]), r2 = __builtin_bit_cast(T2, ri[q]);
+                                    oo[q] = Tr<T>::pack2((float)x2[0] + (float)r2[0], (float)x2[1] + (float)r2[1]);
+                                }
+                                w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                            }
+                            *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + c) = w;
+                        }
+                    }
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+// (mean, rstd) of every row of x [M, C] (16-bit), LayerNorm's biased variance; one wave per row, the row held in registers.
+template <typename T>
+__global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ x, float2* __restrict__ out, long long M, int C, long long ldx, float eps)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int lane = threadIdx.x & 63, oct = C >> 3;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * ldx;
+    constexpr int MAXV = 8;                                  // C <= 64 * 8 * 8 = 4096
+    vec8 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        const int o = lane + 64 * i;
+        v[i] = vec8{};
+        if (o < oct) {
+            v[i] = *reinterpret_cast<const vec8*>(xr + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += (float)v[i][k];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        if (lane + 64 * i < oct) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float d = (float)v[i][k] - mean; q = fmaf(d, d, q); }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+    if (lane == 0) out[row] = make_float2(mean, rsqrtf(q / (float)C + eps));
+}
+
+// ---- row kernels of the wide-head attention (ae_modules.py:26-78 as chunked GEMMs, lvdm_amd/wide_attention.py) ----
+// In-place softmax over the rows of s [rows, N] (16-bit, row stride ld), fp32 math, one wave per row with the row in registers;
+// lse[row] = max + log(sum) (natural log) for the backward.
+template <typename T, int MAXV>
+__global__ void __launch_bounds__(256) k_softmax_rows(T* __restrict__ s, long long ld, long long rows, int N, float* __restrict__ lse)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int lane = threadIdx.x & 63, oct = N >> 3;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    T* sr = s + row * ld;
+    vec8 v[MAXV];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        const int o = lane + 64 * i;
+        if (o < oct) {
+            v[i] = *reinterpret_cast<const vec8*>(sr + o * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) mx = fmaxf(mx, (float)v[i][k]);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float sum = 0.f;
+    float e[MAXV][8];
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        if (lane + 64 * i < oct) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { e[i][k] = __builtin_amdgcn_exp2f(((float)v[i][k] - mx) * 1.4426950408889634f); sum += e[i][k]; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        const int o = lane + 64 * i;
+        if (o < oct) {
+            vec8 p;
+#pragma unroll
+            for (int k = 0; k < 8; k++) p[k] = (T)(e[i][k] * inv);
+            *reinterpret_cast<vec8*>(sr + o * 8) = p;
+        }
+    }
+    if (lse && lane == 0) lse[row] = mx + __logf(sum);
+}
+
+// Backward element step, in place: s holds the scaled scores and becomes P = exp(s - lse); dp holds dO V^T and becomes
+// dS' = P (dp - delta).  lse / delta are per ROW (by_col = 0: index row) or per COLUMN (by_col = 1: the transposed pass; index
+// (row / rows_per_batch) * N + column).
+template <typename T>
+__global__ void __launch_bounds__(256) k_attn_ds(T* __restrict__ s, T* __restrict__ dp, const float* __restrict__ lse,
+                                                 const float* __restrict__ delta, long long rows, int N, long long rows_per_batch, int by_col)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int oct = N >> 3;
+    const long long total = rows * oct, step = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) {
+        const long long r = i / oct;
+        const int o = (int)(i - r * oct);
+        vec8 sv = *reinterpret_cast<const vec8*>(s + r * N + o * 8), dv = *reinterpret_cast<const vec8*>(dp + r * N + o * 8);
+        float l[8], d[8];
+        if (by_col) {
+            const long long base = (r / rows_per_batch) * N + o * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { l[k] = lse[base + k]; d[k] = delta[base + k]; }
+        } else {
+            const float lr = lse[r], dr = delta[r];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { l[k] = lr; d[k] = dr; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float p = __builtin_amdgcn_exp2f(((float)sv[k] - l[k]) * 1.4426950408889634f);
+            const T pt = (T)p;
+            sv[k] = pt;
+            dv[k] = (T)((float)pt * ((float)dv[k] - d[k]));
+        }
+        *reinterpret_cast<vec8*>(s + r * N + o * 8) = sv;
+        *reinterpret_cast<vec8*>(dp + r * N + o * 8) = dv;
+    }
+}
+
+template <typename T, int MI>
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t stream)
+{
+    constexpr int BN = WM * MI * 32;
+    constexpr int smem = 2 * (BN + BM) * ROWB;
+    auto kern = k_gemm_nt<T, MI>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 64 && !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    static int cus[64] = {};
+    if (dev < 64 && cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const long long slots = (long long)a.mgroups * 8 * a.tiles_n * a.batch;          // (a multiple of 8)
+    const int ncu = (dev < 64 ? cus[dev] : 256) / 8 * 8;
+    const unsigned grid = (unsigned)(slots < ncu ? slots : ncu);                        // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvd_gemm_tile_n(int N, int geglu)
+{
+    // 320-wide tiles when they waste less of N than 256-wide ones (320 / 640 / 1280 / 2560 ... exactly); the GEGLU form pairs
+    // 16-column groups, both widths are multiples of 16
+    const int t320 = (N + 319) / 320 * 320, t256 = (N + 255) / 256 * 256;
+    (void)geglu;
+    return t320 <= t256 ? 320 : 256;
+}
+
+int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
+                void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
+                const float* row_stats, const float* col_sum, const void* residual, long long ldr, long long stride_r,
+                int geglu, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return fail(-1, "gvd_gemm_nt: bad arguments");
+    if ((K & 7) || (ldx & 7) || (ldw & 7) || (ldy & 7) || (stride_x & 7) || (stride_w & 7) || (stride_y & 7) ||
+        (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)residual) & 15))
+        return fail(-1, "gvd_gemm_nt: K, row and batch strides must be multiples of 8 elements and tensors 16-byte aligned");
+    if (geglu ? (N & 31) : (N & 7)) return fail(-1, "gvd_gemm_nt: N must be a multiple of 8 (32 with the GEGLU epilogue)");
+    if ((row_stats == nullptr) != (col_sum == nullptr)) return fail(-1, "gvd_gemm_nt: the LayerNorm fold needs row_stats AND col_sum");
+    if (residual && ((ldr & 7) || (stride_r & 7))) return fail(-1, "gvd_gemm_nt: residual strides must be multiples of 8");
+    GemmArgs a{};
+    a.x = x; a.w = w; a.y = y; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.sx = stride_x; a.sw = stride_w; a.sy = stride_y;
+    a.M = M; a.N = N; a.K = K; a.batch = batch; a.alpha = alpha; a.bias = bias;
+    a.row_stats = reinterpret_cast<const float2*>(row_stats); a.col_sum = col_sum;
+    a.res = residual; a.ldr = ldr; a.sr = stride_r; a.geglu = geglu ? 1 : 0;
+    { const char* d = getenv("GVD_GEMM_DBG"); a.dbg = d ? atoi(d) : 0; }
+    const int bn = gvd_gemm_tile_n(N, geglu);
+    a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + bn - 1) / bn; a.mgroups = (a.tiles_m + 7) / 8;
+    if ((long long)a.mgroups * 8 * a.tiles_n * batch >= (1LL << 31)) return fail(-1, "gvd_gemm_nt: grid too large");
+    hipError_t e;
+    if (bn == 320) e = is_bf16 ? launch_gemm<__bf16, 5>(a, stream) : launch_gemm<_Float16, 5>(a, stream);
+    else e = is_bf16 ? launch_gemm<__bf16, 4>(a, stream) : launch_gemm<_Float16, 4>(a, stream);
+    if (e != hipSuccess) return fail(-2, "launch k_gemm_nt", e);
+    return 0;
+}
+
+int gvd_row_stats(const void* x, long long ldx, float* stats, long long M, int C, float eps, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !stats || M <= 0 || C <= 0 || (C & 7) || C > 4096 || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)stats & 7))
+        return fail(-1, "gvd_row_stats: C must be a multiple of 8 and <= 4096, pointers aligned");
+    const unsigned blocks = (unsigned)((M + 3) / 4);
+    if (is_bf16) hipLaunchKernelGGL(k_row_stats<__bf16>, dim3(blocks), dim3(256), 0, stream, (const __bf16*)x, reinterpret_cast<float2*>(stats), M, C, ldx, eps);
+    else hipLaunchKernelGGL(k_row_stats<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)x, reinterpret_cast<float2*>(stats), M, C, ldx, eps);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_row_stats", e);
+    return 0;
+}
+
+int gvd_softmax_rows(void* s, long long ld, long long rows, int N, float* lse, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!s || rows <= 0 || N <= 0 || (N & 7) || (ld & 7) || N > 16384 || ((uintptr_t)s & 15))
+        return fail(-1, "gvd_softmax_rows: N must be a multiple of 8 and <= 16384, pointer aligned");
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+#define GVD_SM(T, V) hipLaunchKernelGGL((k_softmax_rows<T, V>), dim3(blocks), dim3(256), 0, stream, (T*)s, ld, rows, N, lse)
+    if (is_bf16) { if (N <= 4096) GVD_SM(__bf16, 8); else GVD_SM(__bf16, 32); }
+    else { if (N <= 4096) GVD_SM(_Float16, 8); else GVD_SM(_Float16, 32); }
+#undef GVD_SM
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_softmax_rows", e);
+    return 0;
+}
+
+int gvd_attn_ds(void* s, void* dp, const float* lse, const float* delta, long long rows, int N, long long rows_per_batch, int by_col,
+                int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!s || !dp || !lse || !delta || rows <= 0 || N <= 0 || (N & 7) || rows_per_batch <= 0 || (((uintptr_t)s | (uintptr_t)dp) & 15))
+        return fail(-1, "gvd_attn_ds: bad arguments");
+    const long long vecs = rows * (N / 8);
+    const unsigned blocks = (unsigned)((vecs + 255) / 256 < 16384 ? (vecs + 255) / 256 : 16384);
+    if (is_bf16) hipLaunchKernelGGL(k_attn_ds<__bf16>, dim3(blocks), dim3(256), 0, stream, (__bf16*)s, (__bf16*)dp, lse, delta, rows, N, rows_per_batch, by_col);
+    else hipLaunchKernelGGL(k_attn_ds<_Float16>, dim3(blocks), dim3(256), 0, stream, (_Float16*)s, (_Float16*)dp, lse, delta, rows, N, rows_per_batch, by_col);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_attn_ds", e);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+"""Hand-written MFMA GEMM for every Linear / 1x1 convolution on token rows (csrc/gemm_mfma.hip through `gvd_gemm_nt`).
+
+    linear(x, weight, bias, ln=..., residual=..., geglu=...)     y = [geglu]( LayerNorm?(x) W^T + b ) [+ residual]
+    linear_cat(x, [w_q, w_k, w_v], ln=...)                       several Linears of one input as ONE launch (q | k | v columns)
+    gemm_nt(x, w, ...)                                           the raw  Y = alpha X W^T  with strides / batch (attention chunks)
+
+The LayerNorm never materialises: LN(x) W^T = rstd (x W'^T - mean s) + c with W' = W gamma, s = rowsum(W'), c = W beta + b -- the
+kernel runs on the raw tokens, `row_stats` supplies (mean, rstd) per row, (s, c) are per-column vectors of the epilogue.  The
+folded / permuted / concatenated weight images are cached on the parameter objects (invalidated by in-place updates; see
+conv.invalidate_packed for `.data` writes).
+
+No CPU path: CPU tensors raise unless `ops.use_reference_math(True)` (tests / cpu_baseline), which evaluates the same expression
+with the reference's torch ops (F.layer_norm, F.linear, gelu).  fp32 device tensors (parity runs) take that form too, with the
+usual one-time RuntimeWarning.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+_P, _LL = ctypes.c_void_p, ctypes.c_longlong
+_SIG = False
+
+
+def _lib():
+    global _SIG
+    L = ops.lib()
+    if not _SIG:
+        L.gvd_gemm_nt.argtypes = [_P, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_float, _P, _P, _P, _P, _LL, _LL, ctypes.c_int, ctypes.c_int, _P]
+        L.gvd_gemm_nt.restype = ctypes.c_int
+        L.gvd_row_stats.argtypes = [_P, _LL, _P, _LL, ctypes.c_int, ctypes.c_float, ctypes.c_int, _P]
+        L.gvd_row_stats.restype = ctypes.c_int
+        _SIG = True
+    return L
+
+
+def _mat(t, what):
+    """(rows, cols, row stride, batch, batch stride) of a 2-D [R, C] or 3-D [B, R, C] tensor whose last dim is contiguous."""
+    if t.dim() == 2:
+        R, C = t.shape
+        b, bs = 1, 0
+        ld = t.stride(0)
+    elif t.dim() == 3:
+        b, R, C = t.shape
+        bs, ld = t.stride(0), t.stride(1)
+    else:
+        raise ValueError(f"gemm_nt: {what} must be 2-D or 3-D, got {tuple(t.shape)}")
+    if t.stride(-1) != 1 and C > 1:
+        raise ValueError(f"gemm_nt: {what} must be contiguous along its last dimension")
+    if R == 1:
+        ld = max(ld, C)
+    return R, C, ld, b, bs
+
+
+def gemm_nt(x, w, *, alpha=1.0, bias=None, row_stats=None, col_sum=None, residual=None, geglu=False, out=None):
+    """Y = epilogue(alpha X W^T).  x [M, K] or [B, M, K], w [N, K] or [B, N, K] (a 2-D operand is shared by the batch), 16-bit,
+    last dim contiguous (row / batch strides free: views are read in place).  Returns [.., M, N] (N / 2 with geglu)."""
+    M, K, ldx, bx, sx = _mat(x, "x")
+    N, Kw, ldw, bw, sw = _mat(w, "w")
+    if K != Kw or x.dtype != w.dtype or x.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"gemm_nt: x {tuple(x.shape)} {x.dtype} / w {tuple(w.shape)} {w.dtype}")
+    batch = max(bx, bw)
+    if (bx not in (1, batch)) or (bw not in (1, batch)):
+        raise ValueError("gemm_nt: batch sizes differ")
+    No = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((batch, M, No) if (x.dim() == 3 or w.dim() == 3) else (M, No), dtype=x.dtype, device=x.device)
+    Mo, Noo, ldy, _, sy = _mat(out, "out")
+    if (Mo, Noo) != (M, No):
+        raise ValueError(f"gemm_nt: out {tuple(out.shape)} for M = {M}, N = {No}")
+    ldr = sr = 0
+    if residual is not None:
+        Mr, Nr, ldr, br, sr = _mat(residual, "residual")
+        if (Mr, Nr) != (M, No) or residual.dtype != x.dtype:
+            raise ValueError(f"gemm_nt: residual {tuple(residual.shape)} {residual.dtype}")
+    p = lambda t: _P(None if t is None else t.data_ptr())
+    with ops._on(x.device):
+        rc = _lib().gvd_gemm_nt(p(x), ldx, sx if bx > 1 else 0, p(w), ldw, sw if bw > 1 else 0, p(out), ldy, sy if batch > 1 else 0,
+                                M, N, K, batch, float(alpha), p(bias), p(row_stats), p(col_sum), p(residual), ldr, sr,
+                                int(bool(geglu)), 1 if x.dtype == torch.bfloat16 else 0, _P(ops._stream()))
+    ops._check(rc)
+    return out
+
+
+def row_stats(x2, eps):
+    """fp32 (mean, rstd) pairs [M, 2] of the rows of x2 [M, C] (16-bit; row stride free)."""
+    M, C = x2.shape
+    out = torch.empty((M, 2), dtype=torch.float32, device=x2.device)
+    with ops._on(x2.device):
+        ops._check(_lib().gvd_row_stats(_P(x2.data_ptr()), x2.stride(0) if M > 1 else C, _P(out.data_ptr()), M, C, float(eps),
+                                        1 if x2.dtype == torch.bfloat16 else 0, _P(ops._stream())))
+    return out
+
+
+# ---- weight images ------------------------------------------------------------------------------------------------------------
+def _tag(t):
+    return None if t is None else (t._version, t.data_ptr(), t.dtype, t.device)
+
+
+def _geglu_perm(n2, device):
+    """Row order of the GEGLU projection for the kernel's register epilogue (include/gvd_diffusion.h): per block of 32 tile rows,
+    rows 0-15 are the VALUES and rows 16-31 the GATES of 16 consecutive outputs; within each half, row c = 8 rg + 4 hi + e holds
+    output u = 8 hi + 4 rg + e -- so that a lane of the MFMA accumulator layout owns value and gate of 8 consecutive outputs.
+    (value rows 0 .. n-1, gate rows n .. 2n-1 of the projection.)"""
+    n = n2 // 2
+    c = torch.arange(16, device=device)
+    u = 8 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3)                       # output index within the block for half-row c
+    blocks = torch.arange(n // 16, device=device)[:, None] * 16 + u[None, :]   # [n / 16, 16] value rows
+    return torch.cat([blocks, blocks + n], dim=1).reshape(-1)
+
+
+def _prepared(weights, biases, ln, geglu, dtype):
+    """(W image [N, K] in `dtype`, bias / c vector fp32 [N] or None, col_sum fp32 [N] or None) for a list of Linear weights that
+    share their input: rows concatenated, LayerNorm `ln` folded in, GEGLU row order applied.  Cached on the first weight."""
+    w0 = weights[0]
+    key = (tuple(_tag(w) for w in weights), tuple(_tag(b) for b in biases), None if ln is None else (_tag(ln.weight), _tag(ln.bias)),
+           bool(geglu), dtype)
+    cache = getattr(w0, "_gvd_gemm", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    with torch.no_grad():
+        W = torch.cat([w.detach().reshape(w.shape[0], -1).float() for w in weights], dim=0)        # (1x1 conv weights flatten to [N, K])
+        have_bias = any(b is not None for b in biases)
+        c = None
+        if have_bias or ln is not None:
+            c = torch.cat([(torch.zeros(w.shape[0], device=W.device) if b is None else b.detach().float()) for w, b in zip(weights, biases)])
+        s = None
+        if ln is not None:
+            gamma = torch.ones(W.shape[1], device=W.device) if ln.weight is None else ln.weight.detach().float()
+            if ln.bias is not None:
+                c = c + W @ ln.bias.detach().float()
+            Wd = (W * gamma[None, :]).to(dtype)
+            s = Wd.float().sum(dim=1)              # of the ROUNDED image: acc - mean s == sum_k (x_k - mean) W'_k exactly
+        else:
+            Wd = W.to(dtype)
+        if geglu:
+            perm = _geglu_perm(Wd.shape[0], Wd.device)
+            Wd = Wd[perm]
+            c = None if c is None else c[perm]
+            s = None if s is None else s[perm]
+        pad = (-Wd.shape[1]) % 8
+        if pad:
+            Wd = F.pad(Wd, (0, pad))
+        val = (Wd.contiguous(), None if c is None else c.contiguous(), None if s is None else s.contiguous())
+    try:
+        w0._gvd_gemm = (key, val)
+    except AttributeError:
+        pass
+    return val
+
+
+def _transposed(weight, dtype):
+    """[K, N] image of a Linear weight [N, K] (the input-gradient operator), cached."""
+    key = (_tag(weight), dtype)
+    cache = getattr(weight, "_gvd_gemm_t", None)
+    if cache is None or cache[0] != key:
+        cache = (key, weight.detach().reshape(weight.shape[0], -1).to(dtype).t().contiguous())
+        try:
+            weight._gvd_gemm_t = cache
+        except AttributeError:
+            pass
+    return cache[1]
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the MFMA kernel; gradient w.r.t. x only (the guided sampler differentiates with frozen weights)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        Wd, c, _ = _prepared([weight], [bias], None, False, x2.dtype)
+        ctx.weight = weight
+        return gemm_nt(x2, Wd, bias=c)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy if gy.stride(-1) == 1 else gy.contiguous()
+        Wt = _transposed(ctx.weight, gy.dtype)
+        pad = (-gy.shape[1]) % 8
+        if pad:
+            gy, Wt = F.pad(gy, (0, pad)), F.pad(Wt, (0, pad))
+        return gemm_nt(gy, Wt), None, None
+
+
+def _rows(x):
+    """[..., K] -> a 2-D [M, K] view with a uniform row stride (a copy only if no such view exists)."""
+    K = x.shape[-1]
+    if x.dim() == 2:
+        return x if x.stride(-1) == 1 else x.contiguous()
+    try:
+        x2 = x.view(-1, K)
+    except RuntimeError:
+        x2 = x.reshape(-1, K)
+    return x2 if x2.stride(-1) == 1 else x2.contiguous()
+
+
+def _hip_ok(x, weights):
+    on_dev = ops._require_device(x, "linear")
+    ok = on_dev and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0 and all(w.shape[0] % 8 == 0 for w in weights)
+    if on_dev and not ok:
+        ops._torch_form("linear", f"dtype {x.dtype}, K = {x.shape[-1]}, N = {[w.shape[0] for w in weights]} (the MFMA GEMM covers 16-bit rows with K, N multiples of 8)")
+    return ok
+
+
+def linear(x, weight, bias=None, *, ln=None, residual=None, geglu=False):
+    """[geglu](LayerNorm?(x) W^T + b) [+ residual] over the last dim of x.  weight [N, K] (or a 1x1 conv weight [N, K, 1(, 1)]);
+    ln: an nn.LayerNorm-like module (weight, bias, eps) applied to x first; residual: tensor of the output's shape; geglu: the
+    projection's two halves are value | gate (attention.py:415-423)."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    No = N // 2 if geglu else N
+    lead = x.shape[:-1]
+    if not _hip_ok(x, [weight]) or (geglu and N % 32):
+        h = x if ln is None else F.layer_norm(x, (K,), ln.weight, ln.bias, ln.eps)
+        y = F.linear(h, weight.reshape(N, -1).to(h.dtype), None if bias is None else bias.to(h.dtype))
+        if geglu:
+            y = ops.geglu(y) if y.is_cuda and y.dtype in (torch.float16, torch.bfloat16) else ops.geglu_math(y)
+        return y if residual is None else y + residual
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
+    if torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)):
+        raise RuntimeError("lvdm_amd.gemm.linear: only the input gradient is implemented (freeze the weights)")
+    if needs_grad:   # guided sampler: compose the kernels that have input gradients (LayerNorm / GEGLU row kernels + this GEMM)
+        h = x if ln is None else ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        y = _LinearFn.apply(_rows(h), weight, bias).reshape(*lead, N)
+        if geglu:
+            y = ops.geglu(y)
+        return y if residual is None else y + residual
+    x2 = _rows(x)
+    Wd, c, s = _prepared([weight], [bias], ln, geglu, x.dtype)
+    st = None if ln is None else row_stats(x2, ln.eps)
+    r2 = None if residual is None else _rows(residual)
+    return gemm_nt(x2, Wd, bias=c, row_stats=st, col_sum=s, residual=r2, geglu=geglu).reshape(*lead, No)
+
+
+def linear_cat(x, weights, biases=None, *, ln=None):
+    """Several Linears of ONE input as one launch: returns [..., sum N_i]; column block i is Linear_i(LayerNorm?(x)).  The caller
+    slices views (the attention kernels read them in place through their row strides)."""
+    biases = [None] * len(weights) if biases is None else biases
+    K = x.shape[-1]
+    if not _hip_ok(x, weights) or (torch.is_grad_enabled() and x.requires_grad):
+        h = x if ln is None else (ops.layer_norm(x, ln.weight, ln.bias, ln.eps) if x.is_cuda else F.layer_norm(x, (K,), ln.weight, ln.bias, ln.eps))
+        return torch.cat([linear(h, w, b) for w, b in zip(weights, biases)], dim=-1)
+    x2 = _rows(x)
+    Wd, c, s = _prepared(list(weights), list(biases), ln, False, x.dtype)
+    st = None if ln is None else row_stats(x2, ln.eps)
+    return gemm_nt(x2, Wd, bias=c, row_stats=st, col_sum=s).reshape(*x.shape[:-1], Wd.shape[0])

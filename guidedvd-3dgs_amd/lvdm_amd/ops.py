@@ -137,21 +137,54 @@ def _attn_geometry(q, k, heads, frame_major):
     return B, Nq, Nk, C // heads, (Nq * C, C, Nk * C, C)
 
 
-def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False):
-    """q [B,Nq,C], k/v [B,Nk,C]; with frame_major=True the tensors are [N, B, C] (sequence outermost: the T
-    frames of B pixels) and are read in place through the kernel's strided addressing."""
-    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    B, Nq, Nk, d, strides = _attn_geometry(q, k, heads, frame_major)
-    out = torch.empty_like(q)
+def _view_strides(t, frame_major, B):
+    """(batch stride, row stride) of a [B, N, C] (or frame-major [N, B, C]) tensor read in place; a size-1 batch dim of K / V
+    broadcasts (stride 0).  The channel dim must be contiguous and the strides multiples of 8 elements."""
+    bd, rd = (1, 0) if frame_major else (0, 1)
+    bs = 0 if (t.shape[bd] == 1 and B > 1) else t.stride(bd)
+    rs = t.stride(rd)
+    if t.shape[rd] == 1:
+        rs = t.shape[-1]
+    if t.shape[bd] == 1 and B == 1:
+        bs = 0
+    return bs, rs
+
+
+def _readable_in_place(t):
+    return t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
+def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False, accum=None, accum_scale=1.0):
+    """q [B,Nq,C], k/v [B,Nk,C] (k/v with B = 1 are shared by all batch entries); with frame_major=True the tensors are
+    [N, B, C] (sequence outermost: the T frames of B pixels).  q / k / v are read IN PLACE through their strides -- column blocks
+    of a packed [.., q | k | v] projection, broadcast contexts -- as long as the channel dim is contiguous; k and v must share
+    their strides.  accum: out = accum + accum_scale * attention (same shape as the dense output)."""
+    q, k, v = (t if _readable_in_place(t) else t.contiguous() for t in (q, k, v))
+    B = q.shape[1] if frame_major else q.shape[0]
+    Nq = q.shape[0] if frame_major else q.shape[1]
+    Nk = k.shape[0] if frame_major else k.shape[1]
+    C = q.shape[-1]
+    d = C // heads
+    q_bs, q_rs = _view_strides(q, frame_major, B)
+    kv_bs, kv_rs = _view_strides(k, frame_major, B)
+    if _view_strides(v, frame_major, B) != (kv_bs, kv_rs):
+        v = v.contiguous()
+        k = k.contiguous()
+        kv_bs, kv_rs = _view_strides(k, frame_major, B)
+    out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    o_bs, o_rs = _view_strides(out, frame_major, B)
+    if accum is not None:
+        accum = accum.contiguous()
+        if accum.shape != out.shape or accum.dtype != out.dtype:
+            raise ValueError("attention: accum must have the output's shape and dtype")
     lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if want_lse else None
     is_bf16 = 1 if q.dtype == torch.bfloat16 else 0
-    LL = ctypes.c_longlong
+    LL, P = ctypes.c_longlong, ctypes.c_void_p
     with _on(q.device):
-        rc = lib().gvd_attention_fwd_strided(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
-                                             ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                             B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), *(LL(s) for s in strides),
-                                             ctypes.c_void_p(lse.data_ptr() if want_lse else None),
-                                             is_bf16, ctypes.c_void_p(_stream()))
+        rc = lib().gvd_attention_fwd_ex(P(q.data_ptr()), P(k.data_ptr()), P(v.data_ptr()), P(out.data_ptr()),
+                                        B, heads, Nq, Nk, d, ctypes.c_float(d ** -0.5), LL(q_bs), LL(q_rs), LL(kv_bs), LL(kv_rs),
+                                        LL(o_bs), LL(o_rs), P(None if accum is None else accum.data_ptr()), ctypes.c_float(accum_scale),
+                                        P(lse.data_ptr() if want_lse else None), is_bf16, P(_stream()))
     _check(rc)
     return (out, lse) if want_lse else out
 
@@ -172,18 +205,37 @@ def _hip_attention_bwd(q, k, v, out, g, lse, heads, frame_major=False):
     return dq, dk, dv
 
 
-def attention(q, k, v, heads, frame_major=False):
-    """softmax(q k^T / sqrt(d)) v per head.  q [B,Nq,h*d], k/v [B,Nk,h*d]; frame_major: [N,B,h*d] (see above)."""
+def attention(q, k, v, heads, frame_major=False, accum=None, accum_scale=1.0):
+    """softmax(q k^T / sqrt(d)) v per head.  q [B,Nq,h*d], k/v [B,Nk,h*d] (or [1,Nk,h*d]: shared by the batch); frame_major:
+    [N,B,h*d] (see above).  accum / accum_scale: returns accum + accum_scale * attention (fused in the kernel's epilogue)."""
     on_dev = _require_device(q, "attention")
     d = q.shape[-1] // heads
     if on_dev and q.dtype in (torch.float16, torch.bfloat16) and d == 64 and k.dtype == q.dtype and v.dtype == q.dtype:
-        if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
-            return _FlashAttention.apply(q, k, v, heads, frame_major)
-        return _hip_attention_fwd(q, k, v, heads, frame_major)
-    # fp32 tensors (parity tests) and head sizes the MFMA kernel does not cover (VAE mid-attention, d=512)
+        if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad or (accum is not None and accum.requires_grad)):
+            B = q.shape[1] if frame_major else q.shape[0]
+            bd = 1 if frame_major else 0
+            if k.shape[bd] != B:   # broadcast context: the backward kernels address one K / V per batch entry
+                k, v = k.expand(*[B if i == bd else -1 for i in range(3)]), v.expand(*[B if i == bd else -1 for i in range(3)])
+            o = _FlashAttention.apply(q, k, v, heads, frame_major)
+            return o if accum is None else accum + accum_scale * o
+        return _hip_attention_fwd(q, k, v, heads, frame_major, accum=accum, accum_scale=accum_scale)
+    if on_dev and heads == 1 and not frame_major and accum is None:
+        from . import wide_attention      # single wide head (the VAE's d = 512 mid block): chunked MFMA GEMMs + row kernels
+        if wide_attention.supported(q, k, v):
+            return wide_attention.attention(q, k, v)
+    # fp32 tensors (parity tests) and shapes neither kernel family covers
     if on_dev:
-        _torch_form("attention", f"dtype {q.dtype}, head dim {d} (the MFMA kernel covers 16-bit inputs with 64-wide heads)")
-    return attention_math(q, k, v, heads, frame_major)
+        if q.dtype in (torch.float16, torch.bfloat16) and not _REFERENCE_MATH:
+            raise RuntimeError(f"lvdm_amd.ops.attention: no kernel for 16-bit inputs with {heads} head(s) of {d} channels, Nq = "
+                               f"{q.shape[0 if frame_major else 1]}, Nk = {k.shape[0 if frame_major else 1]} (d = 64 heads: any "
+                               "shape; one wide head: d, Nq, Nk multiples of 8, <= 16384 tokens)")
+        _torch_form("attention", f"dtype {q.dtype}, head dim {d} (the MFMA kernels cover 16-bit inputs)")
+    if k.shape[0 if not frame_major else 1] != q.shape[0 if not frame_major else 1]:
+        bd = 1 if frame_major else 0
+        k = k.expand(*[q.shape[bd] if i == bd else -1 for i in range(3)])
+        v = v.expand(*[q.shape[bd] if i == bd else -1 for i in range(3)])
+    o = attention_math(q, k, v, heads, frame_major)
+    return o if accum is None else accum + accum_scale * o
 
 
 # --------------------------------------------------------------------------------------------------

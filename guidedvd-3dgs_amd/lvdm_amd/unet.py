@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint as _ckpt
 
-from . import conv as mconv, ops, parallel
+from . import conv as mconv, gemm, ops, parallel
 from .schedule import timestep_embedding
 
 
@@ -111,39 +111,45 @@ class CrossAttention(nn.Module):
                 self.register_parameter("alpha", nn.Parameter(torch.tensor(0.)))
 
     def _kv(self, context, frames):
-        """Project K/V (and image-prompt K/V).  `frames` > 1 means `context` holds ONE copy of a context
-        shared by `frames` consecutive batch rows: project once, then expand."""
+        """K / V (and image-prompt K / V) of the context, each pair as ONE GEMM ([k | v] column blocks, read in place by the
+        attention kernel).  `frames` > 1 means `context` holds ONE copy of a context shared by `frames` consecutive batch rows:
+        projected once; with a single context row the attention kernel broadcasts it (batch stride 0), otherwise it is expanded."""
+        C = self.to_k.weight.shape[0]
         ctx_t = context[:, :self.text_context_len]
-        k, v = self.to_k(ctx_t), self.to_v(ctx_t)
-        k_ip = v_ip = None
+        kv = gemm.linear_cat(ctx_t, [self.to_k.weight, self.to_v.weight])
+        kv_ip = None
         if self.image_cross_attention:
-            ctx_i = context[:, self.text_context_len:]
-            k_ip, v_ip = self.to_k_ip(ctx_i), self.to_v_ip(ctx_i)
-        if frames > 1:
+            kv_ip = gemm.linear_cat(context[:, self.text_context_len:], [self.to_k_ip.weight, self.to_v_ip.weight])
+        if frames > 1 and kv.shape[0] != 1:
             rep = lambda t: None if t is None else t.repeat_interleave(frames, dim=0)
-            k, v, k_ip, v_ip = rep(k), rep(v), rep(k_ip), rep(v_ip)
-        return k, v, k_ip, v_ip
+            kv, kv_ip = rep(kv), rep(kv_ip)
+        split = lambda t: (None, None) if t is None else (t[..., :C], t[..., C:])
+        return split(kv) + split(kv_ip)
 
-    def forward(self, x, context=None, shared_frames=1, frame_major=False):
-        q = self.to_q(x)
+    def forward(self, x, context=None, shared_frames=1, frame_major=False, norm=None, residual=None):
+        """norm: the LayerNorm in front of this attention (attention.py:283-285) -- folded into the q / k / v GEMMs instead of
+        being applied; residual: the block's `+ x`, added in to_out's epilogue."""
+        C = self.to_q.weight.shape[0]
         if context is None:
-            k, v = self.to_k(x), self.to_v(x)
+            qkv = gemm.linear_cat(x, [self.to_q.weight, self.to_k.weight, self.to_v.weight], ln=norm)   # one launch, LayerNorm folded
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
             if frame_major:  # x [b, T, pixels, C]: one T-long sequence per pixel, read in place
                 outs = [ops.attention(q[i], k[i], v[i], self.heads, frame_major=True) for i in range(x.shape[0])]
                 out = outs[0][None] if len(outs) == 1 else torch.stack(outs, 0)   # b = 1 (the sampler's case): a view, not a copy
             else:
                 out = ops.attention(q, k, v, self.heads)
         else:
+            q = gemm.linear(x, self.to_q.weight, ln=norm)
             k, v, k_ip, v_ip = self._kv(context, shared_frames)
             out = ops.attention(q, k, v, self.heads)
             if k_ip is not None:
-                out_ip = ops.attention(q, k_ip, v_ip, self.heads)
                 s = self.image_cross_attention_scale
                 if self.image_cross_attention_scale_learnable:
-                    out = out + s * out_ip * (torch.tanh(self.alpha) + 1)
-                else:
-                    out = out + s * out_ip
-        return self.to_out(out)
+                    out = out + s * ops.attention(q, k_ip, v_ip, self.heads) * (torch.tanh(self.alpha) + 1)
+                else:   # out + s * out_ip in the second attention's epilogue
+                    out = ops.attention(q, k_ip, v_ip, self.heads, accum=out, accum_scale=float(s))
+        lo = self.to_out[0]
+        return self.to_out[1](gemm.linear(out, lo.weight, lo.bias, residual=residual))
 
 
 class LayerNorm(nn.LayerNorm):
@@ -158,8 +164,8 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
-    def forward(self, x):
-        return ops.geglu(self.proj(x))
+    def forward(self, x, norm=None):
+        return gemm.linear(x, self.proj.weight, self.proj.bias, ln=norm, geglu=True)   # LayerNorm fold + gate in ONE launch
 
 
 class FeedForward(nn.Module):
@@ -167,8 +173,10 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(dropout), nn.Linear(dim * mult, dim))
 
-    def forward(self, x):
-        return self.net(x)
+    def forward(self, x, norm=None, residual=None):
+        """norm: the LayerNorm in front (folded into the projection); residual: the block's `+ x` (second GEMM's epilogue)."""
+        h = self.net[1](self.net[0](x, norm=norm))
+        return gemm.linear(h, self.net[2].weight, self.net[2].bias, residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -183,9 +191,11 @@ class BasicTransformerBlock(nn.Module):
         self.use_checkpoint = use_checkpoint
 
     def _fwd(self, x, context, shared_frames, frame_major):
-        x = self.attn1(self.norm1(x), frame_major=frame_major) + x
-        x = self.attn2(self.norm2(x), context, shared_frames, frame_major=frame_major) + x
-        return self.ff(self.norm3(x)) + x
+        # every LayerNorm is folded into the GEMM behind it and every `+ x` into the GEMM in front of it (gemm.py): a block is
+        # 7 GEMM + 3 (4) attention + 3 row-statistics launches, no normalised / gated / summed intermediate tensor
+        x = self.attn1(x, frame_major=frame_major, norm=self.norm1, residual=x)
+        x = self.attn2(x, context, shared_frames, frame_major=frame_major, norm=self.norm2, residual=x)
+        return self.ff(x, norm=self.norm3, residual=x)
 
     def forward(self, x, context=None, shared_frames=1, frame_major=False):
         return _run(lambda a, c: self._fwd(a, c, shared_frames, frame_major), self.use_checkpoint, x, context)
@@ -208,21 +218,15 @@ class SpatialTransformer(nn.Module):
             for _ in range(depth)])
         self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv2d(inner, in_channels, 1))
 
-    @staticmethod
-    def _proj(layer, t):  # per-token projection; a 1x1 Conv2d is a Linear with weight [out, in, 1, 1]
-        if isinstance(layer, nn.Linear):
-            return layer(t)
-        return F.linear(t, layer.weight.flatten(1), layer.bias)
-
     def forward(self, x, context=None, shared_frames=1):
         n, c, h, w = x.shape
         tok = _tok(x)
         t = _gn_tokens(self.norm, tok, n).reshape(n, h * w, c)
-        t = self._proj(self.proj_in, t)
+        t = gemm.linear(t, self.proj_in.weight, self.proj_in.bias)     # (a 1x1 Conv2d is a Linear with weight [out, in, 1, 1])
         for blk in self.transformer_blocks:
             t = blk(t, context, shared_frames)
-        t = self._proj(self.proj_out, t)
-        return _img(t.reshape(n, h, w, c) + tok)
+        t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias, residual=tok.reshape(n, h * w, c))   # `+ x_in` in the epilogue
+        return _img(t.reshape(n, h, w, c))
 
 
 class TemporalTransformer(nn.Module):
@@ -241,12 +245,6 @@ class TemporalTransformer(nn.Module):
             BasicTransformerBlock(inner, n_heads, d_head, dropout, None, use_checkpoint) for _ in range(depth)])
         self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv1d(inner, in_channels, 1))
 
-    @staticmethod
-    def _proj(layer, t):  # Conv1d(k=1) == per-token Linear with weight [out, in, 1]
-        if isinstance(layer, nn.Linear):
-            return layer(t)
-        return F.linear(t, layer.weight.squeeze(-1), layer.bias)
-
     def forward(self, x, batch_size):  # x [(b T), C, H, W]
         bt, c, h, w = x.shape
         b, T = batch_size, bt // batch_size
@@ -257,13 +255,15 @@ class TemporalTransformer(nn.Module):
         else:  # frames are sharded: finish the statistics across the group, then re-shard frames -> pixels
             t = _gn_tokens(self.norm, tok, b, shard=shard, tokens_total=shard.T * h * w)
             t = parallel.frames_to_pixels(t.reshape(T, h * w, c), shard)[None]  # [1, all T, this rank's pixels, c]
-        t = self._proj(self.proj_in, t)
+        t = gemm.linear(t, self.proj_in.weight, self.proj_in.bias)     # (Conv1d(k = 1) == per-token Linear with weight [out, in, 1])
         for blk in self.transformer_blocks:
             t = blk(t, frame_major=True)
-        t = self._proj(self.proj_out, t)
         if shard is not None:
+            t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias)
             t = parallel.pixels_to_frames(t[0], shard, h * w)
-        return _img(t.reshape(bt, h, w, c) + tok)
+            return _img(t.reshape(bt, h, w, c) + tok)
+        t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias, residual=tok.reshape(t.shape[:-1] + (c,)))
+        return _img(t.reshape(bt, h, w, c))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -387,7 +387,7 @@ class ResBlock(nn.Module):
 
     def _fwd(self, x, emb, batch_size):
         h = self.in_layers[2](self.in_layers[0](x, silu=True))
-        h = h + self.emb_layers[1](F.silu(emb)).to(h.dtype)[:, :, None, None]
+        h = h + gemm.linear(F.silu(emb), self.emb_layers[1].weight, self.emb_layers[1].bias).to(h.dtype)[:, :, None, None]
         h = self.out_layers[3](self.out_layers[2](self.out_layers[0](h, silu=True)))
         h = self.skip_connection(x) + h
         if self.use_temporal_conv and batch_size:
@@ -401,14 +401,14 @@ class ResBlock(nn.Module):
         tok = _tok(x)
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, conv2 = self.out_layers[0], self.out_layers[3]
-        emb_out = self.emb_layers[1](F.silu(emb)).to(tok.dtype)
+        emb_out = gemm.linear(F.silu(emb), self.emb_layers[1].weight, self.emb_layers[1].bias).to(tok.dtype)
         h, part = mconv.fused_conv(tok, conv1, gn=gn1, silu=True, add_nc=emb_out, stats_groups=gn2.num_groups)
         ns2 = mconv.norm_state(gn2, partial=part)
         if isinstance(self.skip_connection, nn.Identity):
             skip = tok
         else:  # 1x1 convolution == per-token GEMM on the same bytes
             sc = self.skip_connection
-            skip = F.linear(tok, sc.weight.flatten(1), sc.bias)
+            skip = gemm.linear(tok, sc.weight, sc.bias)
         temporal = self.use_temporal_conv and batch_size
         h, part = mconv.fused_conv(h, conv2, gn=gn2, norm=ns2, silu=True, residual=skip,
                                    stats_groups=self.temopral_conv.conv1[0].num_groups if temporal else 0)
@@ -548,7 +548,8 @@ class UNetModel(nn.Module):
         xin_dtype = x.dtype
         x = x.to(wdtype)
         context = context.to(wdtype)
-        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).type(x.dtype))
+        mlp = lambda seq, e: gemm.linear(F.silu(gemm.linear(e, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias)
+        emb = mlp(self.time_embed, timestep_embedding(timesteps, self.model_channels).type(x.dtype))
         # Context routing (openaimodel3d.py:555-562): per-frame image tokens only when L == 77 + 16 T,
         # otherwise the SAME context for every frame -> keep ONE copy per batch row and let the
         # cross-attention project it once (shared_frames = T) instead of T identical copies.
@@ -568,7 +569,7 @@ class UNetModel(nn.Module):
         if self.fs_condition:
             if fs is None:
                 fs = torch.full((b,), self.default_fs, dtype=torch.long, device=x.device)
-            fs_emb = self.fps_embedding(timestep_embedding(fs, self.model_channels).type(x.dtype))
+            fs_emb = mlp(self.fps_embedding, timestep_embedding(fs, self.model_channels).type(x.dtype))
             emb = emb + fs_emb.repeat_interleave(t, dim=0)
         h = _cl(x.transpose(1, 2).reshape(b * t, -1, hh, ww))  # -> token-major for the whole network
         hs = []

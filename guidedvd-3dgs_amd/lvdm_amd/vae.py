@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import conv as mconv, ops
+from . import conv as mconv, gemm, ops
 
 
 def _fused(t, module=None):
@@ -64,7 +64,7 @@ class ResnetBlock(nn.Module):
         h, part = mconv.fused_conv(tok, self.conv1, gn=self.norm1, norm=ns1, silu=True, stats_groups=32)
         ns2 = mconv.norm_state(self.norm2, partial=part)
         if hasattr(self, "nin_shortcut"):
-            skip = F.linear(tok, self.nin_shortcut.weight.flatten(1), self.nin_shortcut.bias)
+            skip = gemm.linear(tok, self.nin_shortcut.weight, self.nin_shortcut.bias)
         else:
             skip = tok
         return mconv.fused_conv(h, self.conv2, gn=self.norm2, norm=ns2, silu=True, residual=skip,
@@ -91,9 +91,11 @@ class AttnBlock(nn.Module):
         n, h, w, c = tok.shape
         t = tok.reshape(n, h * w, c)
         hn = ops.group_norm(t, 32, self.norm.weight, self.norm.bias, self.norm.eps, silu=False, channels_last=True)
-        lin = lambda m, a: F.linear(a, m.weight.flatten(1), m.bias)
-        o = ops.attention(lin(self.q, hn), lin(self.k, hn), lin(self.v, hn), heads=1)
-        return (t + lin(self.proj_out, o)).reshape(n, h, w, c)
+        # q | k | v as ONE MFMA GEMM (column blocks read in place), the wide single-head attention (ops.attention -> flash kernel
+        # at d = 64, chunked GEMMs at d = 512: wide_attention.py), proj_out with the `+ x` in its epilogue
+        qkv = gemm.linear_cat(hn, [self.q.weight, self.k.weight, self.v.weight], [self.q.bias, self.k.bias, self.v.bias])
+        o = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], heads=1)
+        return gemm.linear(o, self.proj_out.weight, self.proj_out.bias, residual=t).reshape(n, h, w, c)
 
     def forward(self, x):
         if _fused(x, self):

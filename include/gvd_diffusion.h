@@ -31,6 +31,16 @@ int gvd_attention_fwd_strided(const void* q, const void* k, const void* v, void*
                               long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
                               float* lse, int is_bf16, void* stream);
 
+/* gvd_attention_fwd_strided with (i) separate addressing for out (o_bs, o_rs) -- q, k, v may then be column blocks of one packed
+ * [rows, q | k | v] projection (row stride 3 H D) read in place while out is dense; kv_bs = 0 shares one K / V (the frame-invariant
+ * text / image context of attention.py:129-142) between all batch entries without expanding it -- and (ii) an accumulate form:
+ * accum != NULL (addressed like out; may alias out): out = accum + accum_scale * O, which lands the image-token branch of the
+ * cross-attention on the text branch's result (`out + image_cross_attention_scale * out_ip`) without an elementwise pass. */
+int gvd_attention_fwd_ex(const void* q, const void* k, const void* v, void* out,
+                         int B, int H, int Nq, int Nk, int D, float scale,
+                         long long q_bs, long long q_rs, long long kv_bs, long long kv_rs, long long o_bs, long long o_rs,
+                         const void* accum, float accum_scale, float* lse, int is_bf16, void* stream);
+
 /* Attention backward for the guided sampler's autograd pass (ddim_guidance.py:318-345 differentiates pred_x0 w.r.t.
  * x_t through every attention layer; xformers' memory_efficient_attention backward in the reference).
  * Inputs: q, k, v, out (forward result), d_out, and lse = the [B, H, Nq] fp32 log2-domain log-sum-exp the forward
@@ -167,6 +177,43 @@ int gvd_group_norm_coef(double* stats, const double* partial, int replicas, int 
                         int N, int C, long long S_total, int G, float eps, void* stream);
 
 const char* gvd_diff_last_error(void);
+
+/* NT GEMM on MFMA with the transformer-side epilogues (csrc/gemm_mfma.hip):
+ *     Y[b][m][n] = epilogue( alpha * sum_k X[b][m][k] * W[b][n][k] )         X, W, Y 16-bit, fp32 accumulation
+ * Replaces every nn.Linear / 1x1 convolution on token rows of the U-Net, the VAE attention block and the once-per-video encoders
+ * (F.linear -> hipBLASLt in the reference's stack): lvdm/modules/attention.py:53-57,76,86-99,144,212-246,415-442,
+ * lvdm/modules/networks/openaimodel3d.py:109-236,360-387, lvdm/modules/networks/ae_modules.py:26-78.
+ * ldx / ldw / ldy: row strides, stride_*: batch strides (elements, multiples of 8; a batch stride may be 0).  K % 8 == 0, N % 8 == 0.
+ * Epilogue, in this order (every part optional):
+ *   LayerNorm fold   row_stats [batch][M] (mean, rstd) pairs (gvd_row_stats) and col_sum [N]:  v = rstd[m] * (v - mean[m] * col_sum[n])
+ *                    -- with W pre-multiplied by the norm's weight this IS  LayerNorm(x) W^T  (attention.py:283-285 + the Linear);
+ *   bias [N]         v += bias[n]   (for the fold: sum_k beta[k] W[n][k] + the Linear's bias);
+ *   geglu            W rows come in blocks of 32 = [16 value rows | 16 gate rows] of 16 consecutive outputs, and within each half
+ *                    row c = 8 rg + 4 hi + e holds output 8 hi + 4 rg + e (the MFMA accumulator's lane map: a lane then owns the
+ *                    value and the gate of 8 consecutive outputs): out[m][j] = value * gelu_erf(gate), Y has N / 2 columns
+ *                    (attention.py:415-423), rounded like the unfused pair.  N % 32 == 0;
+ *   residual         Y += R[b][m][n] (row stride ldr, batch stride stride_r), the 16-bit sum of the rounded GEMM result and R. */
+int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
+                void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
+                const float* row_stats, const float* col_sum, const void* residual, long long ldr, long long stride_r,
+                int geglu, int is_bf16, void* stream);
+
+/* Channel-tile width (320 or 256) gvd_gemm_nt uses for N output columns. */
+int gvd_gemm_tile_n(int N, int geglu);
+
+/* (mean, rstd = 1 / sqrt(var + eps)) of every row of x [M, C] (row stride ldx; C % 8 == 0, C <= 4096) as float pairs:
+ * the per-row half of the LayerNorm fold above (nn.LayerNorm's biased variance, attention.py:283-285). */
+int gvd_row_stats(const void* x, long long ldx, float* stats, long long M, int C, float eps, int is_bf16, void* stream);
+
+/* Row kernels of the WIDE-HEAD attention -- the VAE's single-head d = 512 block (ae_modules.py:26-78), evaluated as chunked
+ * GEMMs on gvd_gemm_nt with the scores of one query (or key) chunk living in the Infinity Cache (lvdm_amd/wide_attention.py).
+ * gvd_softmax_rows: in-place softmax over the rows of s [rows, N] (16-bit, row stride ld; N % 8 == 0, N <= 16384), fp32 math;
+ *   lse[row] = max + log(sum) (may be NULL).
+ * gvd_attn_ds: the backward's element step, in place: s (scaled scores) becomes P = exp(s - lse), dp (= dO V^T) becomes
+ *   P (dp - delta); lse / delta indexed by row (by_col = 0) or by (row / rows_per_batch, column) (by_col = 1, the transposed pass). */
+int gvd_softmax_rows(void* s, long long ld, long long rows, int N, float* lse, int is_bf16, void* stream);
+int gvd_attn_ds(void* s, void* dp, const float* lse, const float* delta, long long rows, int N, long long rows_per_batch, int by_col,
+                int is_bf16, void* stream);
 
 #ifdef __cplusplus
 }

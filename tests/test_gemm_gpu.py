@@ -1,0 +1,125 @@
+"""GPU tests (-m gpu) of the hand-written MFMA GEMM (csrc/gemm_mfma.hip via lvdm_amd.gemm) against plain fp32 torch:
+shapes of the U-Net / VAE / attention-chunk call sites, ragged M / N / K edges, strided and batched operands, and every epilogue
+(LayerNorm fold, bias, GEGLU, residual).  Tolerance: the 16-bit output rounding (2^-11 relative for f16, 2^-8 for bf16) on top of
+fp32 accumulation of 16-bit products -- 1.5e-3 / 1.2e-2 of the largest reference entry."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, ref):
+    return float((a.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+
+
+def _mk(g, *shape, dtype=torch.float16, scale=1.0):
+    return (torch.randn(*shape, device=DEV, generator=g) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (257, 640, 1280), (77, 2560, 1024), (3000, 512, 192), (513, 328, 72),
+                                   (25, 1280, 320), (1, 1280, 320), (2304, 1280, 5120), (600, 8, 64), (300, 9216 // 8, 512)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_plain_product_with_bias(M, N, K, dtype):
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x, w = _mk(g, M, K, dtype=dtype), _mk(g, N, K, dtype=dtype, scale=K ** -0.5)
+    b = torch.randn(N, device=DEV, generator=g)
+    y = gemm.gemm_nt(x, w, bias=b)
+    ref = x.float() @ w.float().t() + b
+    assert y.shape == (M, N) and y.dtype == dtype
+    assert _rel(y, ref) < (1.5e-3 if dtype == torch.float16 else 1.2e-2), _rel(y, ref)
+
+
+def test_strided_views_batches_and_scale():
+    """Operands read in place: column slices of a packed [M, 3C] tensor, a broadcast (batch-stride 0) W, a batched W, alpha."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(1)
+    qkv = _mk(g, 3, 704, 3 * 512)
+    q, k = qkv[:, :, :512], qkv[:, :, 512:1024]
+    s = gemm.gemm_nt(q, k, alpha=512 ** -0.5)                       # [3, 704, 704] = q k^T / sqrt(d): batched x batched
+    ref = torch.matmul(q.float(), k.float().transpose(1, 2)) * 512 ** -0.5
+    assert s.shape == (3, 704, 704) and _rel(s, ref) < 1.5e-3
+    w = _mk(g, 320, 512, scale=0.05)
+    y = gemm.gemm_nt(q, w)                                          # batched x shared
+    assert _rel(y, q.float() @ w.float().t()) < 1.5e-3
+    out = torch.zeros(3, 704, 640, dtype=torch.float16, device=DEV)
+    gemm.gemm_nt(q, w, out=out[:, :, 320:])                          # write into a column slice
+    assert float(out[:, :, :320].abs().max()) == 0.0 and _rel(out[:, :, 320:], q.float() @ w.float().t()) < 1.5e-3
+
+
+@pytest.mark.parametrize("C,N", [(320, 320), (640, 1920), (1280, 1280), (1024, 640), (64, 192)])
+def test_layernorm_fold_equals_layernorm_then_linear(C, N):
+    """attention.py:283-285 + the projections: rstd (x W'^T - mean s) + c against F.layer_norm -> F.linear in fp32, incl. rows
+    with a large mean (the cancellation the fold must survive)."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(C + N)
+    M = 1500
+    x = _mk(g, M, C)
+    x[:100] += 6.0                                                   # mean >> std on some rows
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.3 * torch.randn(C, device=DEV, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(C, device=DEV, generator=g))
+    lin = torch.nn.Linear(C, N).to(DEV)
+    ln.half().requires_grad_(False), lin.half().requires_grad_(False)
+    with torch.no_grad():
+        y = gemm.linear(x, lin.weight, lin.bias, ln=ln)
+        ref = F.linear(F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps), lin.weight.float(), lin.bias.float())
+    assert _rel(y, ref) < 2.5e-3, _rel(y, ref)
+    st = gemm.row_stats(x, ln.eps)
+    assert torch.allclose(st[:, 0], x.float().mean(1), atol=2e-5)
+    assert torch.allclose(st[:, 1], torch.rsqrt(x.float().var(1, unbiased=False) + ln.eps), rtol=2e-5)
+
+
+@pytest.mark.parametrize("C", [320, 640, 64])
+def test_feed_forward_pair_geglu_and_residual(C):
+    """attention.py:415-442 + the block's `+ x`: GEGLU(LN(x) W1^T + b1) as ONE launch, then W2 with the residual in its epilogue."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(C)
+    M = 2000
+    x = _mk(g, 5, M // 5, C)
+    ln = torch.nn.LayerNorm(C).to(DEV).half().requires_grad_(False)
+    p1 = torch.nn.Linear(C, 8 * C).to(DEV).half().requires_grad_(False)
+    p2 = torch.nn.Linear(4 * C, C).to(DEV).half().requires_grad_(False)
+    with torch.no_grad():
+        h = gemm.linear(x, p1.weight, p1.bias, ln=ln, geglu=True)
+        y = gemm.linear(h, p2.weight, p2.bias, residual=x)
+        hf = F.linear(F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps), p1.weight.float(), p1.bias.float())
+        a, gate = hf.chunk(2, dim=-1)
+        href = a * F.gelu(gate)
+        yref = F.linear(href, p2.weight.float(), p2.bias.float()) + x.float()
+    assert h.shape == (5, M // 5, 4 * C) and _rel(h, href) < 3e-3, _rel(h, href)
+    assert _rel(y, yref) < 3e-3, _rel(y, yref)
+
+
+def test_linear_cat_and_input_gradient():
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(9)
+    C = 320
+    x = _mk(g, 2, 300, C)
+    ws = [torch.nn.Linear(C, n, bias=False).to(DEV).half().requires_grad_(False).weight for n in (320, 320, 320)]
+    ln = torch.nn.LayerNorm(C).to(DEV).half().requires_grad_(False)
+    with torch.no_grad():
+        qkv = gemm.linear_cat(x, ws, ln=ln)
+    assert qkv.shape == (2, 300, 960)
+    hn = F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps)
+    for i, w in enumerate(ws):
+        assert _rel(qkv[..., 320 * i:320 * (i + 1)], hn @ w.float().t()) < 2.5e-3
+    # guided path: d/dx of x + Linear(LN(x)) through the MFMA GEMM (dX = dY W) and the LayerNorm row kernel
+    lin = torch.nn.Linear(C, C).to(DEV).half().requires_grad_(False)
+    xg = x.clone().requires_grad_(True)
+    y = gemm.linear(xg, lin.weight, lin.bias, ln=ln, residual=xg)
+    probe = _mk(g, *y.shape)
+    (gx,) = torch.autograd.grad(y, xg, probe)
+    xf = x.float().requires_grad_(True)
+    yf = F.linear(F.layer_norm(xf, (C,), ln.weight.float(), ln.bias.float(), ln.eps), lin.weight.float(), lin.bias.float()) + xf
+    (gref,) = torch.autograd.grad(yf, xf, probe.float())
+    assert _rel(y.detach(), yf.detach()) < 2.5e-3 and _rel(gx, gref) < 4e-3, (_rel(y.detach(), yf.detach()), _rel(gx, gref))
+
+
+def test_no_cpu_path():
+    from lvdm_amd import gemm
+    with pytest.raises(RuntimeError):
+        gemm.linear(torch.randn(4, 64), torch.randn(8, 64))

@@ -93,6 +93,24 @@ def _mini_diffusion(plan):
     return gs.GuidedDiffusionRunner(ld, cond, uc, [1, 4, T, HL, WL], (2 * HL, 2 * WL), "cpu", ddim_steps=2, plan=plan, seed=321)
 
 
+def _by_value(obj):
+    """Tensors -> numpy for the trip through a multiprocessing queue: a torch tensor travels as a shared-memory handle that the
+    receiver has to fetch while the sender is still alive (a worker that exits right after `put` loses the race)."""
+    if torch.is_tensor(obj):
+        return ("__tensor__", obj.detach().cpu().numpy())
+    if isinstance(obj, dict):
+        return {k: _by_value(v) for k, v in obj.items()}
+    return obj
+
+
+def _from_value(obj):
+    if isinstance(obj, tuple) and len(obj) == 2 and isinstance(obj[0], str) and obj[0] == "__tensor__":
+        return torch.from_numpy(obj[1])
+    if isinstance(obj, dict):
+        return {k: _from_value(v) for k, v in obj.items()}
+    return obj
+
+
 def _run_schedule(roles, plan, deliver_after):
     import guided_schedule as gs
     raster = ToyRaster(roles) if roles.is_raster else None
@@ -127,7 +145,7 @@ def _worker(rank, world, port, layout, cfg, deliver_after, q):
         assert plan.member == roles.is_diffusion
         out = _run_schedule(roles, plan if roles.is_diffusion else None, deliver_after)
         out["role"] = (roles.is_raster, roles.is_diffusion, roles.describe())
-        q.put((rank, out))
+        q.put((rank, _by_value(out)))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -150,7 +168,7 @@ def _launch(world, layout, cfg, deliver_after):
         assert "exception" not in out, out["exception"]
     for p in procs:
         assert p.exitcode == 0
-    return dict(res)
+    return {r: _from_value(o) for r, o in res}
 
 
 def test_packet_round_trip_and_trigger_iterations():
@@ -315,7 +333,7 @@ def _gpu_worker(rank, world, port, deliver_after, q):
         if raster is not None:
             out["state"] = {k: v.cpu() for k, v in raster.state().items()}
             out["frames"] = torch.stack([f for _, f in raster.pseudo]).cpu()
-        q.put((rank, out))
+        q.put((rank, _by_value(out)))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -347,7 +365,7 @@ def test_raster_rank_and_diffusion_rank_on_one_gpu_match_the_single_process_run(
             p.join(timeout=120)
         for _, out in res:
             assert "exception" not in out, out["exception"]
-        return dict(res)
+        return {r: _from_value(o) for r, o in res}
 
     ref = run(1)[0]
     two = run(2)
