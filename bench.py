@@ -759,7 +759,20 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * (3 if mode == mconv.TEMPORAL else 9)))
         return o
 
-    ops._hip_attention_fwd, mconv._launch = timed_attn, timed_conv
+    from lvdm_amd import gemm as mgemm
+    ev_gemm = []
+    orig_gemm = mgemm.gemm_nt
+
+    def timed_gemm(xx, ww, **kw):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        o = orig_gemm(xx, ww, **kw)
+        b.record()
+        bt = max(xx.shape[0] if xx.dim() == 3 else 1, ww.shape[0] if ww.dim() == 3 else 1)
+        ev_gemm.append((a, b, 2.0 * bt * xx.shape[-2] * ww.shape[-2] * xx.shape[-1]))
+        return o
+
+    ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
     t0 = time.perf_counter()
     try:
         for i in range(steps):
@@ -770,7 +783,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     finally:
-        ops._hip_attention_fwd, mconv._launch = orig_attn, orig_conv
+        ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = orig_attn, orig_conv, orig_gemm
     assert torch.isfinite(x).all()
     if world > 1:  # max over ranks
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -792,6 +805,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
 
     r_conv = roof(ev_conv, "k_conv_mfma (3x3 / upsample / temporal implicit-GEMM convolutions, fused GroupNorm+SiLU prologue)")
     r_attn = roof(ev_attn, "k_attn_fwd (all spatial / cross / temporal attention launches)")
+    r_gemm = roof(ev_gemm, "k_gemm_nt (every Linear / 1x1 convolution: LayerNorm fold, GEGLU, residual in the epilogue)")
     dominant = r_conv if (r_conv and (not r_attn or r_conv["ms_per_step"] >= r_attn["ms_per_step"])) else r_attn
     unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
     line = {
@@ -809,7 +823,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
                    "baseline_note": "vs_baseline = steps/s over the ViewCrafter README A100 figure 0.42 steps/s (120 s / 50 steps, "
                                     "whole pipeline incl. VAE/CLIP; third_party/ViewCrafter/README.md:116-118)"},
         "roofline": dominant,
-        "roofline_conv": r_conv, "roofline_attention": r_attn,
+        "roofline_conv": r_conv, "roofline_attention": r_attn, "roofline_gemm": r_gemm,
         "unet_achieved_tflops": (round(2 * unet_tflop * steps / elapsed, 1) if unet_tflop and not guided else None),
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,

@@ -388,8 +388,13 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                     off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
                 }
                 if (!valid || cout0 >= Cout) continue;
-                const float4 v0 = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32);
-                const float4 v1 = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + 16);
+                // a thread reads 32 contiguous bytes as two ds_read_b128; threads oct and oct + 8 of a 16-lane read group are 256
+                // bytes apart (the same banks), so the upper eight read their halves in the opposite order: the 2-way conflict on
+                // these reads was the 16-33 % SQ_LDS_BANK_CONFLICT of the round-2 counters (the operand reads are conflict free)
+                const int sw = (oct >> 3) & 1;
+                const float4 va = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 16 : 0));
+                const float4 vb = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 0 : 16));
+                const float4 v0 = sw ? vb : va, v1 = sw ? va : vb;
                 float v[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
                 vec8 o;
                 if (full_oct) {

@@ -23,9 +23,10 @@
 //   * Two LDS stages (2 x 72 KiB): the DMA of K-tile t+1 is in flight under the 40 MFMAs of tile t; one barrier per K-tile.
 //   * PERSISTENT workgroups (one per CU) walk their tiles; the first K-tile of the NEXT tile is issued before the epilogue of
 //     the current one, so its HBM / L2 latency hides under the epilogue's stores (with K = 320 a tile is only 5 K-steps long).
-//   * Epilogue straight from the accumulator registers (no LDS round trip, no barriers): scale, the LAYERNORM FOLD, bias in
-//     fp32; GEGLU gate; 16-bit rounding; residual; 16-byte row-contiguous stores -- the two wave halves, which hold channels
-//     8 rg + [0, 4) and 8 rg + [4, 8) of a token, exchange 8-byte halves with v_permlane32_swap to own whole octets.
+//   * Epilogue: scale, the LAYERNORM FOLD, bias in fp32 registers; GEGLU gate; 16-bit rounding; the two wave halves, which hold
+//     channels 8 rg + [0, 4) and 8 rg + [4, 8) of a token, exchange 8-byte halves with v_permlane32_swap to own whole octets;
+//     a wave-private transposition through LDS (no barriers); residual; 16-byte stores in which 20 consecutive lanes cover
+//     320 contiguous bytes of one token row.
 //   * LayerNorm fold: LN(x) W^T = rstd (x W'^T - mean s) + c with W' = W gamma (per input channel), s[n] = sum_k W'[n, k],
 //     c[n] = sum_k beta[k] W[n, k] + bias[n]: the GEMM runs on the raw tokens and the normalisation is two per-row scalars
 //     (gvd_row_stats) and two per-column vectors in the epilogue -- no normalised tensor is ever written or read.
@@ -44,16 +45,19 @@ struct GemmArgs {
     long long ldx, ldw, ldy, sx, sw, sy;   // row / batch strides (elements)
     int M, N, K, batch;
     int tiles_m, tiles_n, mgroups;         // mgroups = ceil(tiles_m / 8)
+    int ngroup;                            // channel tiles per L2-resident group (slot order, see decode)
     float alpha;                           // scale on the accumulator (1 / sqrt(d) for attention scores)
     const float* bias;                     // [N] or nullptr (added after the fold)
     const float2* row_stats;               // [batch][M] (mean, rstd) or nullptr
     const float* col_sum;                  // [N] s[n] (with row_stats)
     const void* res; long long ldr, sr;    // residual rows (layout of y) or nullptr
     int geglu;                             // W rows in [16 value | 16 gate] blocks (gvd_diffusion.h); y has N / 2 columns
-    int dbg;                               // experiments only (GVD_GEMM_DBG): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue stores
 };
 
-constexpr int BK = 64, ROWB = 128, BM = 256, NI = 2, WN = 4, WM = 2, NT = 512;
+#ifndef GVD_GEMM_DBG
+#define GVD_GEMM_DBG 0   // experiments only (tests/scripts/build_gemm_variants.sh): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue, 8 = one K-tile only, 16 = no global stores
+#endif
+constexpr int BM = 256, NI = 2, WN = 4;   // tokens per tile: 4 wave columns x 2 blocks of 32
 __device__ const uint4 g_zero16 = { 0u, 0u, 0u, 0u };   // source of K-tail slots
 
 // exact-form GELU 0.5 g (1 + erf(g / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: far below the 16-bit rounding
@@ -71,34 +75,47 @@ __device__ __forceinline__ float gelu_erf(float g)
 template <typename T>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(Tr<T>::pack2(a, b), Tr<T>::pack2(c, d)); }
 
-template <typename T, int MI>
-__global__ void __launch_bounds__(NT, 2) k_gemm_nt(const GemmArgs a)
+// WM: wave rows (channel halves) -- 2: 8 waves, one workgroup per CU; 1: 4 waves, two workgroups per CU (one's epilogue
+// stores drain under the other's K loop).  BK: K-step (64 / 32 channels = 128 / 64-byte LDS rows).
+template <typename T, int MI, int WM, int BK, bool GEGLU>
+__global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 {
     typedef typename Tr<T>::vec8 vec8;
     typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int NT = WM * WN * 64, ROWB = BK * 2, SPR = ROWB / 16, KS = BK / 16;
     constexpr int BN = WM * MI * 32;
     constexpr int STAGE = (BN + BM) * ROWB;
-    constexpr int NP = STAGE / (NT * 16);           // DMA pieces per thread per stage: 9 (BN 320) / 8 (BN 256)
-    static_assert(STAGE % (NT * 16) == 0 && BN % 64 == 0, "a piece is one kind of row");
-    constexpr int NPW = BN / 64;                    // pieces 0 .. NPW-1 are W rows, the rest X rows
+    constexpr int NQ = STAGE / 16;                  // 16-byte DMA pieces per stage
+    constexpr int NP = (NQ + NT - 1) / NT;          // ... per thread
+    constexpr int EP_PITCH = MI * 64 + 16;          // epilogue staging: one token row of a wave (MI * 32 channels, 16 bit) + pad
+    static_assert(NQ % 64 == 0 && (BN * SPR) % 64 == 0, "a wave's DMA instruction is one kind of row");
+    // XOR of the 16-byte slot that makes the ds_read_b128 operand reads (16-lane groups {0-3,12-15,20-27} ...) conflict free
+    auto swz = [](int row) { return SPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, r32 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const int kslot = (tid & 7) ^ (((tid >> 3) >> 1) & 7);  // logical 16-byte slot (8 channels) stored at physical slot tid & 7
     const int nk = (a.K + BK - 1) / BK, nk_full = a.K / BK;
 
     // ---- persistent workgroup: slots s = blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0, so a workgroup stays on "its" XCD's
     //      slots); slot -> (batch, token tile, channel tile): the channel tiles of a token tile are consecutive slots of ONE XCD,
     //      i.e. they run back to back there and the 256-token panel is pulled through one L2 once ----
+    //      Within an XCD the order is: for each GROUP of `ngroup` channel tiles (their W rows, <= ~1.5 MB, stay in the XCD's
+    //      4 MiB L2) / for each token tile of the XCD / for each channel tile of the group -- W is fetched from beyond L2 once per
+    //      group instead of once per token tile, and a token panel is re-read `ngroup` times back to back (L2 hits).
     const int per_batch = a.mgroups * 8 * a.tiles_n, total = per_batch * a.batch;
     auto decode = [&](int slot, int& b, int& m0, int& n0) {
         b = slot / per_batch;
         const int r = slot - b * per_batch, xcd = r & 7, j = r >> 3;
-        const int tm = (j / a.tiles_n) * 8 + xcd;
+        const int span = a.ngroup * a.mgroups;                       // slots of one full group
+        int g = j / span;
+        const int full = a.tiles_n / a.ngroup;
+        if (g > full) g = full;
+        const int gsz = g < full ? a.ngroup : a.tiles_n - full * a.ngroup, jj = j - g * span;
+        const int tm = (jj / gsz) * 8 + xcd;
         m0 = tm * BM;
-        n0 = (j % a.tiles_n) * BN;
+        n0 = (g * a.ngroup + jj % gsz) * BN;
         return tm < a.tiles_m;
     };
     auto next_valid = [&](int slot) {
@@ -107,52 +124,61 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_nt(const GemmArgs a)
         return slot;
     };
 
-    // ---- DMA source map: piece p of this thread fills LDS bytes [p * 8192 + tid * 16, +16) of a stage; 32-bit byte offsets
-    //      from the tile's two (wave-uniform) bases ----
+    // ---- DMA source map: piece q = p * NT + tid of a stage fills LDS bytes [16 q, 16 q + 16): row q / SPR, physical slot q % SPR,
+    //      which holds the row's LOGICAL slot (q % SPR) ^ swz(row) -- the permutation stays inside the row's own 64 / 128-byte
+    //      line, so the global reads stay coalesced ----
+    // 32-bit byte offsets from the tile's two bases (kept scalar); which base a piece uses is a compile-time fact per sweep p
+    // when the W / X boundary falls between sweeps (8-wave form), else a per-thread compare
+    constexpr int WQ = BN * SPR;                             // pieces [0, WQ) are W rows
     const char* wbase = nullptr;
     const char* xbase = nullptr;
-    unsigned off[NP];                                        // ((p * 64) does not change ((row >> 1) & 7))
+    unsigned off[NP];
+    auto piece_slot = [&](int p) { const int q = p * NT + tid; return (q % SPR) ^ swz(q / SPR); };
     auto aim = [&](int b, int m0, int n0) {
         wbase = reinterpret_cast<const char*>((const T*)a.w + (size_t)b * a.sw + (size_t)n0 * a.ldw);
         xbase = reinterpret_cast<const char*>((const T*)a.x + (size_t)b * a.sx + (size_t)m0 * a.ldx);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const int r = p * 64 + (tid >> 3);              // LDS row of the stage
-            if (p < NPW) {
+            const int q = p * NT + tid, r = q / SPR;
+            if (r < BN) {
                 const int lim = a.N - 1 - n0;
-                off[p] = (unsigned)(((long long)(r < lim ? r : lim) * a.ldw + kslot * 8) * 2);
+                off[p] = (unsigned)(((long long)(r < lim ? r : lim) * a.ldw + piece_slot(p) * 8) * 2);
             } else {
                 const int lim = a.M - 1 - m0, rr = r - BN;
-                off[p] = (unsigned)(((long long)(rr < lim ? rr : lim) * a.ldx + kslot * 8) * 2);
+                off[p] = (unsigned)(((long long)(rr < lim ? rr : lim) * a.ldx + piece_slot(p) * 8) * 2);
             }
         }
+    };
+    auto piece_src = [&](int p, int kt) {
+        const bool isw = (WQ % NT == 0) ? (p < WQ / NT) : (p * NT + tid < WQ);
+        return (isw ? wbase : xbase) + off[p] + (size_t)kt * ROWB;
     };
     auto issue = [&](int kt, int stage) {                    // a full K-tile
         unsigned char* dst = lds + stage * STAGE + wave * 1024;
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const char* g = (p < NPW ? wbase : xbase) + off[p] + (size_t)kt * (BK * 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(dst + p * 8192), 16, 0, 0);
+            if ((p + 1) * NT > NQ && p * NT + wave * 64 >= NQ) continue;     // (last, partial sweep: wave-uniform)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)piece_src(p, kt),
+                                             (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
         }
     };
     auto issue_tail = [&](int kt, int stage) {               // the last, partial K-tile: slots past K read zeros
         unsigned char* dst = lds + stage * STAGE + wave * 1024;
-        const bool dead = kt * BK + kslot * 8 >= a.K;
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const char* g = (p < NPW ? wbase : xbase) + off[p] + (size_t)kt * (BK * 2);
-            if (dead) g = reinterpret_cast<const char*>(&g_zero16);
+            if ((p + 1) * NT > NQ && p * NT + wave * 64 >= NQ) continue;
+            const char* g = piece_src(p, kt);
+            if (kt * BK + piece_slot(p) * 8 >= a.K) g = reinterpret_cast<const char*>(&g_zero16);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(dst + p * 8192), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
         }
     };
     auto issue_first = [&]() { if (nk_full > 0) issue(0, 0); else issue_tail(0, 0); };
 
     // ---- MFMA operand addresses within a stage ----
-    int a_off[4], b_off[NI];
+    int a_off[KS], b_off[NI];   // (32-row block offsets do not change swz(row))
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) a_off[ks] = (wm * MI * 32 + r32) * ROWB + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4);
+    for (int ks = 0; ks < KS; ks++) a_off[ks] = (wm * MI * 32 + r32) * ROWB + (((2 * ks + hi) ^ swz(r32)) << 4);
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) b_off[ni] = (BN + (wn * NI + ni) * 32 + r32) * ROWB;
 
@@ -163,40 +189,94 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_nt(const GemmArgs a)
     aim(cb, cm0, cn0);
     issue_first();
 
+    bool more = true;
+    const bool scaled = a.row_stats != nullptr || a.alpha != 1.0f;       // (uniform) the epilogue multiplies by a per-row / global scale
     while (true) {
+        // ---- accumulators start at the epilogue's additive terms, so that the epilogue itself is one multiply (or nothing), the
+        //      16-bit pack and the stores: with  y = scale_m (sum_k x w' + init),
+        //        LayerNorm fold:  scale_m = rstd_m,  init = c_n / rstd_m - mean_m s_n     (== rstd (acc - mean s) + c)
+        //        otherwise:       scale   = alpha,   init = bias_n / alpha
+        //      The vector loads behind this sit in the shadow of the tile's first DMA wait. ----
+        //      The per-column vectors travel through a wave-private corner of LDS stage 1 (free until the K loop's first
+        //      barrier): two loads per lane instead of forty, and the wait for them is the wait for the tile's first DMA.
         f16v acc[MI][NI];
+        float rscale[NI];
+        {
+            float* const vec = reinterpret_cast<float*>(lds + STAGE) + wave * (2 * MI * 32);
+            float rinv[NI], rmean[NI];
+            const bool vecs = a.bias != nullptr || a.row_stats != nullptr;      // (uniform)
+            if (vecs) {
+                const int c = cn0 + wm * MI * 32 + lane * 4;
+                const int cs = (lane < MI * 8 && c < a.N) ? c : 0;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = bv;
+                if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cs);
+                if (a.row_stats) sv = *reinterpret_cast<const float4*>(a.col_sum + cs);
+                float2 st[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; mi++)
+                for (int ni = 0; ni < NI; ni++) {
+                    const int m = cm0 + (wn * NI + ni) * 32 + r32;
+                    st[ni] = a.row_stats ? (a.row_stats + (size_t)cb * a.M)[m < a.M ? m : a.M - 1] : make_float2(0.f, a.alpha);
+                }
+                if (lane < MI * 8) {
+                    if (c >= a.N) { bv = make_float4(0.f, 0.f, 0.f, 0.f); sv = bv; }
+                    *reinterpret_cast<float4*>(vec + lane * 4) = bv;
+                    *reinterpret_cast<float4*>(vec + MI * 32 + lane * 4) = sv;
+                }
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) acc[mi][ni] = f16v{};
+                for (int ni = 0; ni < NI; ni++) { rscale[ni] = st[ni].y; rinv[ni] = __builtin_amdgcn_rcpf(st[ni].y); rmean[ni] = st[ni].x; }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) { rscale[ni] = a.alpha; rinv[ni] = 0.f; rmean[ni] = 0.f; }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = bv;
+                    if (vecs) {
+                        bv = *reinterpret_cast<const float4*>(vec + mi * 32 + 8 * rg + 4 * hi);
+                        sv = *reinterpret_cast<const float4*>(vec + MI * 32 + mi * 32 + 8 * rg + 4 * hi);
+                    }
+                    const float bq[4] = { bv.x, bv.y, bv.z, bv.w }, sq[4] = { sv.x, sv.y, sv.z, sv.w };
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[mi][ni][4 * rg + e] = fmaf(bq[e], rinv[ni], -rmean[ni] * sq[e]);
+                }
+            }
+        }
 
+#if GVD_GEMM_DBG & 8
+        for (int kt = 0; kt < 1; kt++) {
+#else
         for (int kt = 0; kt < nk; kt++) {
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                 // tile kt landed for everyone; stage (kt + 1) & 1 is free
-            if (!(a.dbg & 1)) {
-                if (kt + 1 < nk_full) issue(kt + 1, (kt + 1) & 1);
-                else if (kt + 1 < nk) issue_tail(kt + 1, (kt + 1) & 1);
-            }
+#if !(GVD_GEMM_DBG & 1)
+            if (kt + 1 < nk_full) issue(kt + 1, (kt + 1) & 1);
+            else if (kt + 1 < nk) issue_tail(kt + 1, (kt + 1) & 1);
+#endif
             const unsigned char* st = lds + (kt & 1) * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
+            for (int ks = 0; ks < KS; ks++) {
                 vec8 af[MI], bf[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const vec8*>(st + a_off[ks] + mi * 32 * ROWB);
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++)
-                    bf[ni] = *reinterpret_cast<const vec8*>(st + b_off[ni] + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4));
-                if (a.dbg & 2) {
+                    bf[ni] = *reinterpret_cast<const vec8*>(st + b_off[ni] + (((2 * ks + hi) ^ swz(r32)) << 4));
+#if GVD_GEMM_DBG & 2
 #pragma unroll
-                    for (int mi = 0; mi < MI; mi++)
+                for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ni++) acc[mi][ni][0] += (float)af[mi][0] * (float)bf[ni][0];
-                    continue;
-                }
+                    for (int ni = 0; ni < NI; ni++) acc[mi][ni][0] += (float)af[mi][0] * (float)bf[ni][0];
+#else
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                     for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
+#endif
             }
         }
         __syncthreads();   // all operand reads retired: both stages are free
@@ -204,49 +284,41 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_nt(const GemmArgs a)
         // ---- the next tile's first K-tile goes out now: its latency hides under this tile's epilogue ----
         const int tb = cb, tm0 = cm0, tn0 = cn0;
         slot = next_valid(slot + gridDim.x);
-        const bool more = slot < total;
+        more = slot < total;
         if (more) {
             decode(slot, cb, cm0, cn0);
             aim(cb, cm0, cn0);
             issue_first();
         }
 
-        // ---- epilogue straight from the accumulators: a lane holds, per 32x32 block (mi, ni), 4 x 4 consecutive channels
-        //      (8 rg + 4 hi + e) of ONE token; scale, LayerNorm fold and bias in fp32, then 16-byte stores ----
-        if (a.dbg & 4) { if (!more) break; continue; }
+        // ---- epilogue.  A lane holds, per 32x32 block (mi, ni), 4 x 4 consecutive channels (8 rg + 4 hi + e) of ONE token:
+        //      scale, LayerNorm fold, bias (and the GEGLU gate) in fp32 registers, 16-bit rounding, then a WAVE-PRIVATE transposition
+        //      through LDS (no barriers) so that the global stores are row-contiguous: 20 (16) consecutive lanes cover the wave's
+        //      320 (256) bytes of one token row.  (Row-per-lane stores straight from the registers -- 32-byte pieces of 32 rows per
+        //      instruction -- ran at a fraction of the write bandwidth: the store path handles a row segment per cycle.) ----
+#if GVD_GEMM_DBG & 4
+        if (!more) break;
+        continue;
+#endif
         T* __restrict__ yb = (T*)a.y + (size_t)tb * a.sy;
         const T* __restrict__ rb = a.res ? (const T*)a.res + (size_t)tb * a.sr : nullptr;
-        const float2* __restrict__ rs = a.row_stats ? a.row_stats + (size_t)tb * a.M : nullptr;
+        unsigned char* const ep = lds + STAGE + wave * (32 * EP_PITCH);     // (stage 0 is receiving the next tile)
+        constexpr int NOCT = GEGLU ? MI * 2 : MI * 4;                        // 16-byte chunks per token row of this wave
+        constexpr int NIT = NOCT * 32 / 64;                                  // read-back sweeps of a 32-token block
+        const int wcol = GEGLU ? (tn0 >> 1) + wm * MI * 16 : tn0 + wm * MI * 32, ncols = GEGLU ? (a.N >> 1) : a.N;
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
-            const int m = tm0 + (wn * NI + ni) * 32 + r32;
-            const bool row_ok = m < a.M;
-            float mean = 0.f, rstd = 1.f;
-            if (rs && row_ok) { const float2 sm = rs[m]; mean = sm.x; rstd = sm.y; }
+            const int mrow = tm0 + (wn * NI + ni) * 32;
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
-                const int blk = wm * MI + mi, cblk = tn0 + blk * 32;     // first tile column (W row) of this 32-channel block
-                if (cblk >= a.N) continue;                                // (wave-uniform)
-                float v[16];
+                f16v v = acc[mi][ni];
+                if (scaled) {
 #pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    const int c = cblk + 8 * rg + 4 * hi;
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = bv;
-                    if (c < a.N) {
-                        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + c);
-                        if (rs) sv = *reinterpret_cast<const float4*>(a.col_sum + c);
-                    }
-                    const float bq[4] = { bv.x, bv.y, bv.z, bv.w }, sq[4] = { sv.x, sv.y, sv.z, sv.w };
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float f = acc[mi][ni][4 * rg + e] * a.alpha;
-                        if (rs) f = rstd * fmaf(-mean, sq[e], f);
-                        v[4 * rg + e] = f + bq[e];
-                    }
+                    for (int q = 0; q < 16; q++) v[q] *= rscale[ni];
                 }
-                if (a.geglu) {
+                if (GEGLU) {
                     // tile columns 0-15 of the block are values, 16-31 their gates (same rg & 1, hi, e): this lane owns the 8
-                    // consecutive outputs 8 hi + 4 rg + e (rg = 0, 1) of the block's 16 -- one 16-byte store, no exchange
+                    // consecutive outputs 8 hi + 4 rg + e (rg = 0, 1) of the block's 16 -- one 16-byte chunk, no exchange
                     float o[8];
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -254,48 +326,61 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_nt(const GemmArgs a)
                         const T ge = (T)gelu_erf((float)gv);
                         o[q] = (float)av * (float)ge;
                     }
-                    const int oc = (tn0 >> 1) + blk * 16 + 8 * hi;
-                    if (row_ok && cblk + 4 * hi < a.N) {
-                        uint4 w = make_uint4(Tr<T>::pack2(o[0], o[1]), Tr<T>::pack2(o[2], o[3]), Tr<T>::pack2(o[4], o[5]), Tr<T>::pack2(o[6], o[7]));
-                        if (rb) {
-                            const uint4 r = *reinterpret_cast<const uint4*>(rb + (size_t)m * a.ldr + oc);
-                            const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
-                            unsigned oo[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const T2 x2 = __builtin_bit_cast(T2, wi[q]), r2 = __builtin_bit_cast(T2, ri[q]);
-                                oo[q] = Tr<T>::pack2((float)x2[0] + (float)r2[0], (float)x2[1] + (float)r2[1]);
-                            }
-                            w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
-                        }
-                        *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + oc) = w;
-                    }
+                    const uint4 w = make_uint4(Tr<T>::pack2(o[0], o[1]), Tr<T>::pack2(o[2], o[3]), Tr<T>::pack2(o[4], o[5]), Tr<T>::pack2(o[6], o[7]));
+                    *reinterpret_cast<uint4*>(ep + r32 * EP_PITCH + (mi * 2 + hi) * 16) = w;
                 } else {
                     // the two wave halves hold channels 8 rg + [0, 4) and 8 rg + [4, 8): one v_permlane32_swap per dword gives
-                    // lanes 0-31 the whole octet of rg = 0 / 2 and lanes 32-63 the octet of rg = 1 / 3 (16-byte stores)
+                    // lanes 0-31 the whole octet of rg = 0 / 2 and lanes 32-63 the octet of rg = 1 / 3
 #pragma unroll
                     for (int pr = 0; pr < 2; pr++) {
                         const uint2 p0 = pack4<T>(v[8 * pr], v[8 * pr + 1], v[8 * pr + 2], v[8 * pr + 3]);
                         const uint2 p1 = pack4<T>(v[8 * pr + 4], v[8 * pr + 5], v[8 * pr + 6], v[8 * pr + 7]);
                         const auto sl = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
                         const auto sh = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
-                        uint4 w = make_uint4(sl[0], sh[0], sl[1], sh[1]);
-                        const int c = cblk + 8 * (2 * pr + hi);
-                        if (row_ok && c < a.N) {
-                            if (rb) {
-                                const uint4 r = *reinterpret_cast<const uint4*>(rb + (size_t)m * a.ldr + c);
-                                const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
-                                unsigned oo[4];
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {   // the 16-bit sum of the ROUNDED product and the residual, as the separate ops
-                                    const T2 x2 = __builtin_bit_cast(T2, wi[q]), r2 = __builtin_bit_cast(T2, ri[q]);
-                                    oo[q] = Tr<T>::pack2((float)x2[0] + (float)r2[0], (float)x2[1] + (float)r2[1]);
-                                }
-                                w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
-                            }
-                            *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + c) = w;
-                        }
+                        *reinterpret_cast<uint4*>(ep + r32 * EP_PITCH + (mi * 4 + 2 * pr + hi) * 16) = make_uint4(sl[0], sh[0], sl[1], sh[1]);
                     }
+                }
+            }
+            // read back row-contiguous: chunk c of the wave's [32 tokens][NOCT chunks] block -> token c / NOCT, chunk c % NOCT.
+            // In groups of <= 5 sweeps: a group's residual pieces are fetched together first (unconditional, clamped addresses),
+            // so their latency is exposed once per group -- and 20 registers hold them, not 40 next to the live accumulators
+            constexpr int GRP = NIT > 5 ? (NIT + 1) / 2 : NIT;
+#pragma unroll
+            for (int i0 = 0; i0 < NIT; i0 += GRP) {
+                uint4 rr[GRP];
+                if (rb) {
+#pragma unroll
+                    for (int i = 0; i < GRP; i++) {
+                        if (i0 + i >= NIT) break;
+                        const int c = (i0 + i) * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
+                        int m = mrow + tok, col = wcol + oc * 8;
+                        m = m < a.M ? m : a.M - 1;
+                        col = col < ncols ? col : 0;
+                        rr[i] = *reinterpret_cast<const uint4*>(rb + (size_t)m * a.ldr + col);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < GRP; i++) {
+                    if (i0 + i >= NIT) break;
+                    const int c = (i0 + i) * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
+                    uint4 w = *reinterpret_cast<const uint4*>(ep + tok * EP_PITCH + oc * 16);
+                    const int m = mrow + tok, col = wcol + oc * 8;
+                    if (rb) {
+                        const uint4 r = rr[i];
+                        const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
+                        unsigned oo[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {   // the 16-bit sum of the ROUNDED product and the residual, as the separate ops
+                            const T2 x2 = __builtin_bit_cast(T2, wi[q]), r2 = __builtin_bit_cast(T2, ri[q]);
+                            oo[q] = Tr<T>::pack2((float)x2[0] + (float)r2[0], (float)x2[1] + (float)r2[1]);
+                        }
+                        w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                    }
+#if GVD_GEMM_DBG & 16
+                    if (m < a.M && col < ncols && w.x == 0x12345678u) *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
+#else
+                    if (m < a.M && col < ncols) *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
+#endif
                 }
             }
         }
@@ -345,7 +430,7 @@ __global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ x, floa
 // In-place softmax over the rows of s [rows, N] (16-bit, row stride ld), fp32 math, one wave per row with the row in registers;
 // lse[row] = max + log(sum) (natural log) for the backward.
 template <typename T, int MAXV>
-__global__ void __launch_bounds__(256) k_softmax_rows(T* __restrict__ s, long long ld, long long rows, int N, float* __restrict__ lse)
+__global__ void __launch_bounds__(256) k_softmax_rows(T* __restrict__ s, long long ld, long long rows, int N, int n_valid, float* __restrict__ lse)
 {
     typedef typename Tr<T>::vec8 vec8;
     const int lane = threadIdx.x & 63, oct = N >> 3;
@@ -360,7 +445,7 @@ __global__ void __launch_bounds__(256) k_softmax_rows(T* __restrict__ s, long lo
         if (o < oct) {
             v[i] = *reinterpret_cast<const vec8*>(sr + o * 8);
 #pragma unroll
-            for (int k = 0; k < 8; k++) mx = fmaxf(mx, (float)v[i][k]);
+            for (int k = 0; k < 8; k++) if (o * 8 + k < n_valid) mx = fmaxf(mx, (float)v[i][k]);
         }
     }
 #pragma unroll
@@ -371,7 +456,10 @@ __global__ void __launch_bounds__(256) k_softmax_rows(T* __restrict__ s, long lo
     for (int i = 0; i < MAXV; i++) {
         if (lane + 64 * i < oct) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) { e[i][k] = __builtin_amdgcn_exp2f(((float)v[i][k] - mx) * 1.4426950408889634f); sum += e[i][k]; }
+            for (int k = 0; k < 8; k++) {   // (columns >= n_valid are padding keys: probability 0)
+                e[i][k] = (lane + 64 * i) * 8 + k < n_valid ? __builtin_amdgcn_exp2f(((float)v[i][k] - mx) * 1.4426950408889634f) : 0.f;
+                sum += e[i][k];
+            }
         }
     }
 #pragma unroll
@@ -395,7 +483,7 @@ __global__ void __launch_bounds__(256) k_softmax_rows(T* __restrict__ s, long lo
 // (row / rows_per_batch) * N + column).
 template <typename T>
 __global__ void __launch_bounds__(256) k_attn_ds(T* __restrict__ s, T* __restrict__ dp, const float* __restrict__ lse,
-                                                 const float* __restrict__ delta, long long rows, int N, long long rows_per_batch, int by_col)
+                                                 const float* __restrict__ delta, long long rows, int N, int n_valid, long long rows_per_batch, int by_col)
 {
     typedef typename Tr<T>::vec8 vec8;
     const int oct = N >> 3;
@@ -416,7 +504,7 @@ __global__ void __launch_bounds__(256) k_attn_ds(T* __restrict__ s, T* __restric
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const float p = __builtin_amdgcn_exp2f(((float)sv[k] - l[k]) * 1.4426950408889634f);
+            const float p = o * 8 + k < n_valid ? __builtin_amdgcn_exp2f(((float)sv[k] - l[k]) * 1.4426950408889634f) : 0.f;
             const T pt = (T)p;
             sv[k] = pt;
             dv[k] = (T)((float)pt * ((float)dv[k] - d[k]));
@@ -426,44 +514,58 @@ __global__ void __launch_bounds__(256) k_attn_ds(T* __restrict__ s, T* __restric
     }
 }
 
-template <typename T, int MI>
+template <typename T, int MI, int WM, int BK, bool GEGLU>
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t stream)
 {
     constexpr int BN = WM * MI * 32;
-    constexpr int smem = 2 * (BN + BM) * ROWB;
-    auto kern = k_gemm_nt<T, MI>;
+    constexpr int stage = (BN + BM) * BK * 2, ep = WM * WN * 32 * (MI * 64 + 16);
+    constexpr int smem = stage + (stage > ep ? stage : ep);   // two K stages; the epilogue staging overlays the second
+    auto kern = k_gemm_nt<T, MI, WM, BK, GEGLU>;
     static bool attr_done[64] = {};
+    static int cus[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 64 && !attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
-    static int cus[64] = {};
-    if (dev < 64 && cus[dev] == 0) {
         hipDeviceProp_t prop;
         cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        attr_done[dev] = true;
     }
     const long long slots = (long long)a.mgroups * 8 * a.tiles_n * a.batch;          // (a multiple of 8)
-    const int ncu = (dev < 64 ? cus[dev] : 256) / 8 * 8;
-    const unsigned grid = (unsigned)(slots < ncu ? slots : ncu);                        // persistent: one workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, stream, a);
+    const int resident = (dev < 64 && cus[dev] ? cus[dev] : 256) / 8 * 8 * (WM == 1 ? 2 : 1);   // persistent: every CU full
+    const unsigned grid = (unsigned)(slots < resident ? slots : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, stream, a);
     return hipGetLastError();
+}
+
+// Workgroup form: 1 = 8 waves, 320 / 256-channel tiles, K-step 64, one per CU (the faster main loop); 0 = 4 waves, 160 / 128-channel
+// tiles, K-step 32, two per CU -- taken when the 8-wave form would leave CUs without a tile (small M x N: the 9 x 16 level, the
+// context projections, the wide attention's P V product).  GVD_GEMM_VARIANT = 0 / 1 forces one form (A/B runs).
+int gemm_variant(long long M, int N, int batch)
+{
+    static const int forced = [] { const char* e = getenv("GVD_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 1) return forced;
+    const int w5 = (N + 319) / 320 * 320, w4 = (N + 255) / 256 * 256;
+    const long long tiles = (M + BM - 1) / BM * ((w5 <= w4 ? w5 / 320 : w4 / 256)) * batch;
+    return tiles >= 192 ? 1 : 0;
 }
 
 }  // namespace
 
 extern "C" {
 
-int gvd_gemm_tile_n(int N, int geglu)
+static int tile_n(long long M, int N, int batch)
 {
-    // 320-wide tiles when they waste less of N than 256-wide ones (320 / 640 / 1280 / 2560 ... exactly); the GEGLU form pairs
-    // 16-column groups, both widths are multiples of 16
-    const int t320 = (N + 319) / 320 * 320, t256 = (N + 255) / 256 * 256;
-    (void)geglu;
-    return t320 <= t256 ? 320 : 256;
+    // the 5-block (160 / 320-channel) tile when it wastes less of N than the 4-block (128 / 256) one: 320, 640, 1280, 2560 ...
+    // divide exactly; both widths are multiples of the GEGLU epilogue's 32-row blocks
+    const int big = gemm_variant(M, N, batch) == 1 ? 2 : 1;
+    const int w5 = 160 * big, w4 = 128 * big;
+    const int t5 = (N + w5 - 1) / w5 * w5, t4 = (N + w4 - 1) / w4 * w4;
+    return t5 <= t4 ? w5 : w4;
 }
+
+int gvd_gemm_tile_n(int M, int N, int batch) { return tile_n(M, N, batch); }
 
 int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
                 void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
@@ -483,13 +585,25 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
     a.M = M; a.N = N; a.K = K; a.batch = batch; a.alpha = alpha; a.bias = bias;
     a.row_stats = reinterpret_cast<const float2*>(row_stats); a.col_sum = col_sum;
     a.res = residual; a.ldr = ldr; a.sr = stride_r; a.geglu = geglu ? 1 : 0;
-    { const char* d = getenv("GVD_GEMM_DBG"); a.dbg = d ? atoi(d) : 0; }
-    const int bn = gvd_gemm_tile_n(N, geglu);
+    const int bn = tile_n(M, N, batch);
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + bn - 1) / bn; a.mgroups = (a.tiles_m + 7) / 8;
+    {   // channel tiles whose W rows (bn x K x 2 bytes each) share an XCD's L2 with the token panels in flight
+        static const long long budget = [] { const char* e = getenv("GVD_GEMM_L2_BYTES"); return e ? atoll(e) : (3LL << 19); }();
+        long long g = budget / ((long long)bn * K * 2);
+        a.ngroup = (int)(g < 1 ? 1 : (g > a.tiles_n ? a.tiles_n : g));
+    }
     if ((long long)a.mgroups * 8 * a.tiles_n * batch >= (1LL << 31)) return fail(-1, "gvd_gemm_nt: grid too large");
     hipError_t e;
-    if (bn == 320) e = is_bf16 ? launch_gemm<__bf16, 5>(a, stream) : launch_gemm<_Float16, 5>(a, stream);
-    else e = is_bf16 ? launch_gemm<__bf16, 4>(a, stream) : launch_gemm<_Float16, 4>(a, stream);
+#define GVD_GEMM_GO(MI_, WM_, BK_)                                                                                                  \
+    (is_bf16 ? (geglu ? launch_gemm<__bf16, MI_, WM_, BK_, true>(a, stream) : launch_gemm<__bf16, MI_, WM_, BK_, false>(a, stream))      \
+             : (geglu ? launch_gemm<_Float16, MI_, WM_, BK_, true>(a, stream) : launch_gemm<_Float16, MI_, WM_, BK_, false>(a, stream)))
+    switch (bn) {
+    case 320: e = GVD_GEMM_GO(5, 2, 64); break;
+    case 256: e = GVD_GEMM_GO(4, 2, 64); break;
+    case 160: e = GVD_GEMM_GO(5, 1, 32); break;
+    default: e = GVD_GEMM_GO(4, 1, 32); break;
+    }
+#undef GVD_GEMM_GO
     if (e != hipSuccess) return fail(-2, "launch k_gemm_nt", e);
     return 0;
 }
@@ -507,13 +621,13 @@ int gvd_row_stats(const void* x, long long ldx, float* stats, long long M, int C
     return 0;
 }
 
-int gvd_softmax_rows(void* s, long long ld, long long rows, int N, float* lse, int is_bf16, void* stream_)
+int gvd_softmax_rows(void* s, long long ld, long long rows, int N, int n_valid, float* lse, int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!s || rows <= 0 || N <= 0 || (N & 7) || (ld & 7) || N > 16384 || ((uintptr_t)s & 15))
+    if (!s || rows <= 0 || N <= 0 || (N & 7) || (ld & 7) || N > 16384 || n_valid <= 0 || n_valid > N || ((uintptr_t)s & 15))
         return fail(-1, "gvd_softmax_rows: N must be a multiple of 8 and <= 16384, pointer aligned");
     const unsigned blocks = (unsigned)((rows + 3) / 4);
-#define GVD_SM(T, V) hipLaunchKernelGGL((k_softmax_rows<T, V>), dim3(blocks), dim3(256), 0, stream, (T*)s, ld, rows, N, lse)
+#define GVD_SM(T, V) hipLaunchKernelGGL((k_softmax_rows<T, V>), dim3(blocks), dim3(256), 0, stream, (T*)s, ld, rows, N, n_valid, lse)
     if (is_bf16) { if (N <= 4096) GVD_SM(__bf16, 8); else GVD_SM(__bf16, 32); }
     else { if (N <= 4096) GVD_SM(_Float16, 8); else GVD_SM(_Float16, 32); }
 #undef GVD_SM
@@ -522,16 +636,16 @@ int gvd_softmax_rows(void* s, long long ld, long long rows, int N, float* lse, i
     return 0;
 }
 
-int gvd_attn_ds(void* s, void* dp, const float* lse, const float* delta, long long rows, int N, long long rows_per_batch, int by_col,
-                int is_bf16, void* stream_)
+int gvd_attn_ds(void* s, void* dp, const float* lse, const float* delta, long long rows, int N, int n_valid, long long rows_per_batch,
+                int by_col, int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!s || !dp || !lse || !delta || rows <= 0 || N <= 0 || (N & 7) || rows_per_batch <= 0 || (((uintptr_t)s | (uintptr_t)dp) & 15))
         return fail(-1, "gvd_attn_ds: bad arguments");
     const long long vecs = rows * (N / 8);
     const unsigned blocks = (unsigned)((vecs + 255) / 256 < 16384 ? (vecs + 255) / 256 : 16384);
-    if (is_bf16) hipLaunchKernelGGL(k_attn_ds<__bf16>, dim3(blocks), dim3(256), 0, stream, (__bf16*)s, (__bf16*)dp, lse, delta, rows, N, rows_per_batch, by_col);
-    else hipLaunchKernelGGL(k_attn_ds<_Float16>, dim3(blocks), dim3(256), 0, stream, (_Float16*)s, (_Float16*)dp, lse, delta, rows, N, rows_per_batch, by_col);
+    if (is_bf16) hipLaunchKernelGGL(k_attn_ds<__bf16>, dim3(blocks), dim3(256), 0, stream, (__bf16*)s, (__bf16*)dp, lse, delta, rows, N, n_valid, rows_per_batch, by_col);
+    else hipLaunchKernelGGL(k_attn_ds<_Float16>, dim3(blocks), dim3(256), 0, stream, (_Float16*)s, (_Float16*)dp, lse, delta, rows, N, n_valid, rows_per_batch, by_col);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_attn_ds", e);
     return 0;

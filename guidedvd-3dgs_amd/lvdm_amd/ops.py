@@ -228,7 +228,7 @@ def attention(q, k, v, heads, frame_major=False, accum=None, accum_scale=1.0):
         if q.dtype in (torch.float16, torch.bfloat16) and not _REFERENCE_MATH:
             raise RuntimeError(f"lvdm_amd.ops.attention: no kernel for 16-bit inputs with {heads} head(s) of {d} channels, Nq = "
                                f"{q.shape[0 if frame_major else 1]}, Nk = {k.shape[0 if frame_major else 1]} (d = 64 heads: any "
-                               "shape; one wide head: d, Nq, Nk multiples of 8, <= 16384 tokens)")
+                               "shape; one wide head: d a multiple of 8, <= 16376 tokens)")
         _torch_form("attention", f"dtype {q.dtype}, head dim {d} (the MFMA kernels cover 16-bit inputs)")
     if k.shape[0 if not frame_major else 1] != q.shape[0 if not frame_major else 1]:
         bd = 1 if frame_major else 0

@@ -10,12 +10,13 @@ tokens [b, 256, 1024] — and the single-token `ImageProjModel` variant.
 Parameter names equal the reference's, so `image_proj_model.*` of a ViewCrafter checkpoint loads with strict=True.  The
 reference scales q and k by d^-1/4 each before the product (fp16 range); the flash kernel keeps scores in fp32, so the
 single d^-1/2 factor inside `ops.attention` is the same function.  Attention (12 heads x 64, 256 queries over 513 keys)
-and the LayerNorms run on the HIP kernels of libgvd_diffusion.so for 16-bit activations; the Linear layers are hipBLASLt.
+runs on the flash kernel; every Linear is the MFMA GEMM of csrc/gemm_mfma.hip with the LayerNorm in front of it folded into its
+epilogue and the residual add behind it fused (lvdm_amd/gemm.py) for 16-bit activations.
 """
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import gemm, ops
 
 
 class _LayerNorm(nn.LayerNorm):
@@ -39,7 +40,7 @@ class ImageProjModel(nn.Module):
         self.add_module("norm", _LayerNorm(cross_attention_dim))
 
     def forward(self, image_embeds):
-        wide = self.proj(image_embeds.to(self.proj.weight.dtype))
+        wide = gemm.linear(image_embeds.to(self.proj.weight.dtype), self.proj.weight, self.proj.bias)
         return self.norm(wide.view(-1, self.clip_extra_context_tokens, self.cross_attention_dim))
 
 
@@ -61,11 +62,13 @@ class PerceiverAttention(nn.Module):
                              ("to_kv", _linear(dim, 2 * width, False)), ("to_out", _linear(width, dim, False))):
             self.add_module(name, module)
 
-    def forward(self, x, latents):
-        """x: image tokens [b, n1, D]; latents: query tokens [b, n2, D] -> [b, n2, D]."""
-        image_tokens, queries = self.norm1(x), self.norm2(latents)
-        keys, values = self.to_kv(torch.cat([image_tokens, queries], dim=1)).split(self.heads * self.dim_head, dim=-1)
-        return self.to_out(ops.attention(self.to_q(queries), keys, values, self.heads))
+    def forward(self, x, latents, residual=None):
+        """x: image tokens [b, n1, D]; latents: query tokens [b, n2, D] -> [b, n2, D] (+ residual, in to_out's epilogue).  norm1 /
+        norm2 are folded into the k | v and q projections (no normalised tensor is rounded to 16 bit in between)."""
+        w = self.heads * self.dim_head
+        kv = torch.cat([gemm.linear(x, self.to_kv.weight, ln=self.norm1), gemm.linear(latents, self.to_kv.weight, ln=self.norm2)], dim=1)
+        q = gemm.linear(latents, self.to_q.weight, ln=self.norm2)
+        return gemm.linear(ops.attention(q, kv[..., :w], kv[..., w:], self.heads), self.to_out.weight, residual=residual)
 
 
 class Resampler(nn.Module):
@@ -85,9 +88,10 @@ class Resampler(nn.Module):
             self.layers.append(nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads), FeedForward(dim, ff_mult)]))
 
     def forward(self, x):
-        tokens = self.proj_in(x)
-        state = self.latents.expand(tokens.shape[0], -1, -1)
+        tokens = gemm.linear(x, self.proj_in.weight, self.proj_in.bias)
+        state = self.latents.expand(tokens.shape[0], -1, -1).to(tokens.dtype)
         for attend, feed_forward in self.layers:
-            state = state + attend(tokens, state)
-            state = state + feed_forward(state)
-        return self.norm_out(self.proj_out(state))      # [b, frames * queries, output_dim]
+            state = attend(tokens, state, residual=state)
+            hidden = feed_forward[2](gemm.linear(state, feed_forward[1].weight, ln=feed_forward[0]))
+            state = gemm.linear(hidden, feed_forward[3].weight, residual=state)
+        return self.norm_out(gemm.linear(state, self.proj_out.weight, self.proj_out.bias))      # [b, frames * queries, output_dim]

@@ -11,6 +11,7 @@ output rounded once).  Scores are rounded to 16 bit before the softmax -- exactl
 import ctypes
 
 import torch
+import torch.nn.functional as F
 
 from . import gemm, ops
 
@@ -23,34 +24,48 @@ def _chunk_rows(B, other):
     return max(256, rows // 256 * 256)
 
 
-def _softmax_rows_(S, want_lse):
+def _softmax_rows_(S, n_valid, want_lse):
     rows, N = S.numel() // S.shape[-1], S.shape[-1]
     lse = torch.empty(rows, dtype=torch.float32, device=S.device) if want_lse else None
     with ops._on(S.device):
-        ops._check(ops.lib().gvd_softmax_rows(_P(S.data_ptr()), _LL(N), _LL(rows), N, _P(None if lse is None else lse.data_ptr()),
+        ops._check(ops.lib().gvd_softmax_rows(_P(S.data_ptr()), _LL(N), _LL(rows), N, int(n_valid), _P(None if lse is None else lse.data_ptr()),
                                               1 if S.dtype == torch.bfloat16 else 0, _P(ops._stream())))
     return lse
 
 
-def _ds_(S, dP, lse, delta, rows_per_batch, by_col):
+def _ds_(S, dP, lse, delta, n_valid, rows_per_batch, by_col):
     rows, N = S.numel() // S.shape[-1], S.shape[-1]
     with ops._on(S.device):
         ops._check(ops.lib().gvd_attn_ds(_P(S.data_ptr()), _P(dP.data_ptr()), _P(lse.data_ptr()), _P(delta.data_ptr()), _LL(rows), N,
-                                         _LL(rows_per_batch), int(by_col), 1 if S.dtype == torch.bfloat16 else 0, _P(ops._stream())))
+                                         int(n_valid), _LL(rows_per_batch), int(by_col), 1 if S.dtype == torch.bfloat16 else 0,
+                                         _P(ops._stream())))
+
+
+def _pad_tokens(t):
+    """Token count -> a multiple of 8 (the GEMM's N / K granule) with zero rows; they are masked out by the row kernels."""
+    pad = (-t.shape[1]) % 8
+    return t if pad == 0 else F.pad(t, (0, 0, 0, pad))
+
+
+def _inplace_ok(t):
+    return t.stride(-1) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
 
 
 def _forward(q, k, v, want_lse):
+    """q [B, Nq, d], k / v [B, Nk, d] (token counts already multiples of 8 where it matters); nk_valid keys are real."""
     B, Nq, d = q.shape
+    nk_valid = k.shape[1]
+    k, v = _pad_tokens(k), _pad_tokens(v)
     Nk = k.shape[1]
     scale = d ** -0.5
     vT = v.transpose(1, 2).contiguous()                    # [B, d, Nk]: the second product's W operand (K-contiguous)
-    out = torch.empty_like(q)
+    out = torch.empty((B, Nq, d), dtype=q.dtype, device=q.device)
     lse = torch.empty(B, Nq, dtype=torch.float32, device=q.device) if want_lse else None
     step = _chunk_rows(B, Nk)
     for m0 in range(0, Nq, step):
         m1 = min(Nq, m0 + step)
         S = gemm.gemm_nt(q[:, m0:m1], k, alpha=scale)       # [B, Mc, Nk] scaled scores, 16 bit
-        l = _softmax_rows_(S, want_lse)                     # -> P in place
+        l = _softmax_rows_(S, nk_valid, want_lse)           # -> P in place
         if want_lse:
             lse[:, m0:m1] = l.view(B, m1 - m0)
         gemm.gemm_nt(S, vT, out=out[:, m0:m1])
@@ -60,7 +75,7 @@ def _forward(q, k, v, want_lse):
 class _WideAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v):
-        q, k, v = (t if (t.stride(-1) == 1 and t.stride(1) % 8 == 0) else t.contiguous() for t in (q, k, v))
+        q, k, v = (t if _inplace_ok(t) else t.contiguous() for t in (q, k, v))
         out, lse = _forward(q, k, v, True)
         ctx.save_for_backward(q, k, v, out, lse)
         return out
@@ -68,11 +83,17 @@ class _WideAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         q, k, v, out, lse = ctx.saved_tensors
-        g = g.contiguous()
-        B, Nq, d = q.shape
-        Nk = k.shape[1]
+        B, nq_valid, d = q.shape
+        nk_valid = k.shape[1]
         scale = d ** -0.5
         delta = (g.float() * out.float()).sum(-1)           # [B, Nq]
+        # token counts to multiples of 8: padded keys are masked by n_valid, padded queries by lse = +inf (P = 0 there)
+        q, g, k, v = _pad_tokens(q), _pad_tokens(g.contiguous()), _pad_tokens(k), _pad_tokens(v)
+        Nq, Nk = q.shape[1], k.shape[1]
+        if Nq != nq_valid:
+            lse = F.pad(lse, (0, Nq - nq_valid), value=float("inf"))
+            delta = F.pad(delta, (0, Nq - nq_valid))
+        lse, delta = lse.contiguous(), delta.contiguous()
         kT, qT, gT = (t.transpose(1, 2).contiguous() for t in (k, q, g))
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         step = _chunk_rows(B, Nk)
@@ -80,28 +101,28 @@ class _WideAttention(torch.autograd.Function):
             m1 = min(Nq, m0 + step)
             S = gemm.gemm_nt(q[:, m0:m1], k, alpha=scale)
             dP = gemm.gemm_nt(g[:, m0:m1], v)               # dO v^T  [B, Mc, Nk]
-            _ds_(S, dP, lse[:, m0:m1].contiguous(), delta[:, m0:m1].contiguous(), m1 - m0, False)
+            _ds_(S, dP, lse[:, m0:m1].contiguous(), delta[:, m0:m1].contiguous(), nk_valid, m1 - m0, False)
             gemm.gemm_nt(dP, kT, alpha=scale, out=dq[:, m0:m1])
         step = _chunk_rows(B, Nq)
         for n0 in range(0, Nk, step):                       # pass over key chunks: dk, dv (transposed scores)
             n1 = min(Nk, n0 + step)
             St = gemm.gemm_nt(k[:, n0:n1], q, alpha=scale)  # [B, Nc, Nq]
             dPt = gemm.gemm_nt(v[:, n0:n1], g)
-            _ds_(St, dPt, lse, delta, n1 - n0, True)
+            _ds_(St, dPt, lse, delta, Nq, n1 - n0, True)
             gemm.gemm_nt(St, gT, out=dv[:, n0:n1])          # P^T dO
             gemm.gemm_nt(dPt, qT, alpha=scale, out=dk[:, n0:n1])
-        return dq, dk, dv
+        return dq[:, :nq_valid], dk[:, :nk_valid], dv[:, :nk_valid]
 
 
 def supported(q, k, v):
     d = q.shape[-1]
     return (q.is_cuda and q.dtype in (torch.float16, torch.bfloat16) and k.dtype == q.dtype and v.dtype == q.dtype and q.dim() == 3
-            and d % 8 == 0 and k.shape[1] % 8 == 0 and q.shape[1] % 8 == 0 and k.shape[1] <= 16384 and q.shape[1] <= 16384)
+            and d % 8 == 0 and k.shape[1] <= 16376 and q.shape[1] <= 16376)
 
 
 def attention(q, k, v):
-    """softmax(q k^T / sqrt(d)) v, one head.  q [B, Nq, d], k / v [B, Nk, d], 16-bit on a ROCm device; Nq, Nk, d multiples of 8."""
+    """softmax(q k^T / sqrt(d)) v, one head.  q [B, Nq, d], k / v [B, Nk, d], 16-bit on a ROCm device; d a multiple of 8."""
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
         return _WideAttention.apply(q, k, v)
-    q, k, v = (t if (t.stride(-1) == 1 and t.stride(1) % 8 == 0) else t.contiguous() for t in (q, k, v))
+    q, k, v = (t if _inplace_ok(t) else t.contiguous() for t in (q, k, v))
     return _forward(q, k, v, False)[0]

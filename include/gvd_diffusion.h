@@ -198,8 +198,9 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
                 const float* row_stats, const float* col_sum, const void* residual, long long ldr, long long stride_r,
                 int geglu, int is_bf16, void* stream);
 
-/* Channel-tile width (320 or 256) gvd_gemm_nt uses for N output columns. */
-int gvd_gemm_tile_n(int N, int geglu);
+/* Channel-tile width (320 / 256: 8-wave workgroups; 160 / 128: 4-wave workgroups for problems that would under-fill the chip)
+ * gvd_gemm_nt uses for an M x N problem with `batch` batches. */
+int gvd_gemm_tile_n(int M, int N, int batch);
 
 /* (mean, rstd = 1 / sqrt(var + eps)) of every row of x [M, C] (row stride ldx; C % 8 == 0, C <= 4096) as float pairs:
  * the per-row half of the LayerNorm fold above (nn.LayerNorm's biased variance, attention.py:283-285). */
@@ -210,10 +211,11 @@ int gvd_row_stats(const void* x, long long ldx, float* stats, long long M, int C
  * gvd_softmax_rows: in-place softmax over the rows of s [rows, N] (16-bit, row stride ld; N % 8 == 0, N <= 16384), fp32 math;
  *   lse[row] = max + log(sum) (may be NULL).
  * gvd_attn_ds: the backward's element step, in place: s (scaled scores) becomes P = exp(s - lse), dp (= dO V^T) becomes
- *   P (dp - delta); lse / delta indexed by row (by_col = 0) or by (row / rows_per_batch, column) (by_col = 1, the transposed pass). */
-int gvd_softmax_rows(void* s, long long ld, long long rows, int N, float* lse, int is_bf16, void* stream);
-int gvd_attn_ds(void* s, void* dp, const float* lse, const float* delta, long long rows, int N, long long rows_per_batch, int by_col,
-                int is_bf16, void* stream);
+ *   P (dp - delta); lse / delta indexed by row (by_col = 0) or by (row / rows_per_batch, column) (by_col = 1, the transposed pass).
+ * n_valid <= N: columns >= n_valid are padding (token counts are padded to multiples of 8): probability / dS' 0 there. */
+int gvd_softmax_rows(void* s, long long ld, long long rows, int N, int n_valid, float* lse, int is_bf16, void* stream);
+int gvd_attn_ds(void* s, void* dp, const float* lse, const float* delta, long long rows, int N, int n_valid, long long rows_per_batch,
+                int by_col, int is_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,7 @@ def test_vae_decoder_miniature_error_is_within_the_references_own_fp16_error():
 
 def test_vae_decoder_at_the_shipped_width_d512_mid_attention():
     """The configuration the product runs (inference_pvd_1024.yaml:66-87).  Also asserts which attention implementation ran: the
-    d = 512 flash kernel pair, with no RuntimeWarning about a torch-form fallback."""
+    wide-head kernels (chunked MFMA GEMMs + row kernels), with no RuntimeWarning about a torch-form fallback."""
     import warnings
     from lvdm_amd import ops
     from lvdm_amd.vae import Decoder
@@ -75,8 +75,9 @@ def test_vae_decoder_at_the_shipped_width_d512_mid_attention():
               attn_resolutions=[], dropout=0.0)
     dec = fill_by_name(Decoder(**dd), std=0.02).half().eval().to(DEV).requires_grad_(False)
     z = torch.tensor(F64["dec512_z"], device=DEV).half().requires_grad_(True)
+    from lvdm_amd import wide_attention
     calls = {"fwd": 0, "bwd": 0}
-    of, ob = ops._hip_attention_fwd, ops._hip_attention_bwd
+    of, ob = wide_attention._forward, wide_attention._WideAttention.backward
 
     def cf(*a, **k):
         calls["fwd"] += 1
@@ -85,7 +86,7 @@ def test_vae_decoder_at_the_shipped_width_d512_mid_attention():
     def cb(*a, **k):
         calls["bwd"] += 1
         return ob(*a, **k)
-    ops._hip_attention_fwd, ops._hip_attention_bwd = cf, cb
+    wide_attention._forward, wide_attention._WideAttention.backward = cf, staticmethod(cb)
     ops._WARNED.clear()
     try:
         with warnings.catch_warnings(record=True) as w:
@@ -93,9 +94,9 @@ def test_vae_decoder_at_the_shipped_width_d512_mid_attention():
             img = dec(z)
             (gz,) = torch.autograd.grad(img, z, torch.tensor(F64["dec512_gi"], device=DEV).half())
     finally:
-        ops._hip_attention_fwd, ops._hip_attention_bwd = of, ob
+        wide_attention._forward, wide_attention._WideAttention.backward = of, staticmethod(ob)
     assert not [m for m in w if issubclass(m.category, RuntimeWarning) and "attention" in str(m.message)], [str(m.message) for m in w]
-    assert calls == {"fwd": 1, "bwd": 1}, calls
+    assert calls == {"fwd": 1, "bwd": 1}, calls      # the chunked-GEMM wide-head attention (wide_attention.py), forward and backward
     _judge("dec512", img, gz)
 
 

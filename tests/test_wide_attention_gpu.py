@@ -18,7 +18,7 @@ def _rel(a, b):
     return float((a.float() - b).abs().max() / b.abs().max())
 
 
-@pytest.mark.parametrize("B,Nq,Nk,d,dtype", [(2, 1000, 1000, 512, torch.float16), (1, 2304, 2304, 512, torch.float16), (3, 520, 776, 128, torch.float16),
+@pytest.mark.parametrize("B,Nq,Nk,d,dtype", [(2, 1000, 1000, 512, torch.float16), (1, 2304, 2304, 512, torch.float16), (3, 520, 776, 128, torch.float16), (2, 140, 140, 512, torch.float16), (1, 35, 35, 128, torch.float16),
                                              (2, 1000, 1000, 512, torch.bfloat16)])
 def test_forward_and_gradients_match_fp32(B, Nq, Nk, d, dtype, monkeypatch):
     from lvdm_amd import ops, wide_attention
