@@ -54,11 +54,20 @@ struct GemmArgs {
     int geglu;                             // W rows in [16 value | 16 gate] blocks (gvd_diffusion.h); y has N / 2 columns
 };
 
+#ifndef GVD_GEMM_KUNROLL5
+#define GVD_GEMM_KUNROLL5 2
+#endif
 #ifndef GVD_GEMM_DBG
 #define GVD_GEMM_DBG 0   // experiments only (tests/scripts/build_gemm_variants.sh): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue, 8 = one K-tile only, 16 = no global stores
 #endif
 constexpr int BM = 256, NI = 2, WN = 4;   // tokens per tile: 4 wave columns x 2 blocks of 32
 __device__ const uint4 g_zero16 = { 0u, 0u, 0u, 0u };   // source of K-tail slots
+#ifdef GVD_GEMM_TRACE
+__device__ unsigned long long g_trace[1024];   // experiments: s_memtime stamps of workgroup 0, wave 0
+#define GVD_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && trace_n + (i) < 1024) g_trace[trace_n + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GVD_STAMP(i) do { } while (0)
+#endif
 
 // exact-form GELU 0.5 g (1 + erf(g / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: far below the 16-bit rounding
 // of the result), ~12 instructions with v_exp / v_rcp instead of libdevice erff's ~40 -- the gate runs once per output element
@@ -87,15 +96,33 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
     constexpr int STAGE = (BN + BM) * ROWB;
     constexpr int NQ = STAGE / 16;                  // 16-byte DMA pieces per stage
     constexpr int NP = (NQ + NT - 1) / NT;          // ... per thread
+    constexpr int KUNROLL = (MI == 5 && KS == 4) ? GVD_GEMM_KUNROLL5 : KS;   // (5-block tiles sit at the register cap: see tile_n)
     constexpr int EP_PITCH = MI * 64 + 16;          // epilogue staging: one token row of a wave (MI * 32 channels, 16 bit) + pad
     static_assert(NQ % 64 == 0 && (BN * SPR) % 64 == 0, "a wave's DMA instruction is one kind of row");
     // XOR of the 16-byte slot that makes the ds_read_b128 operand reads (16-lane groups {0-3,12-15,20-27} ...) conflict free
     auto swz = [](int row) { return SPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hi = lane >> 5, r32 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
+    // Per-lane geometry.  Re-derived from the thread id at the top of every tile (behind an opaque asm): kept live across the
+    // whole persistent loop these ~25 values were spilled to scratch by the 5-block kernels (160 accumulators + fragments at the
+    // 256-register cap) and reloaded with exposed latency (~10k cycles per tile); recomputing them is ~30 VALU instructions.
+    int lane, wave, hi, r32, wm, wn, lrow, lslot;
+    int a_off[KS], b_off[NI];   // MFMA operand addresses within a stage (32-row block offsets do not change swz(row))
+    auto geometry = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        lane = t & 63; wave = t >> 6;
+        wave = __builtin_amdgcn_readfirstlane(wave);
+        hi = lane >> 5; r32 = lane & 31;
+        wm = wave / WN; wn = wave % WN;
+        lrow = lane / SPR;
+        lslot = (lane % SPR) ^ (SPR == 8 ? ((wave * 4 + (lane >> 4)) & 7) : ((wave * 4 + (lane >> 4)) & 3));
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) a_off[ks] = (wm * MI * 32 + r32) * ROWB + (((2 * ks + hi) ^ swz(r32)) << 4);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) b_off[ni] = (BN + (wn * NI + ni) * 32 + r32) * ROWB;
+    };
+    geometry();
     const int nk = (a.K + BK - 1) / BK, nk_full = a.K / BK;
 
     // ---- persistent workgroup: slots s = blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0, so a workgroup stays on "its" XCD's
@@ -127,31 +154,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
     // ---- DMA source map: piece q = p * NT + tid of a stage fills LDS bytes [16 q, 16 q + 16): row q / SPR, physical slot q % SPR,
     //      which holds the row's LOGICAL slot (q % SPR) ^ swz(row) -- the permutation stays inside the row's own 64 / 128-byte
     //      line, so the global reads stay coalesced ----
-    // 32-bit byte offsets from the tile's two bases (kept scalar); which base a piece uses is a compile-time fact per sweep p
-    // when the W / X boundary falls between sweeps (8-wave form), else a per-thread compare
+    // A wave's DMA instruction of sweep p covers 64 / SPR consecutive rows: row = R0(p, wave) + lane / SPR, physical slot
+    // lane % SPR; the row's swizzle depends on (wave, lane) only (R0's contribution to the swizzled bits is 0), so the per-lane
+    // state is TWO registers (row-in-instruction, logical slot) and everything else about a piece is wave-uniform (scalar):
+    // no per-piece offset array lives across the K loop.  Rows past the matrix edge are clamped (loaded twice, never stored).
     constexpr int WQ = BN * SPR;                             // pieces [0, WQ) are W rows
     const char* wbase = nullptr;
     const char* xbase = nullptr;
-    unsigned off[NP];
-    auto piece_slot = [&](int p) { const int q = p * NT + tid; return (q % SPR) ^ swz(q / SPR); };
+    int wlim = 0, xlim = 0;
     auto aim = [&](int b, int m0, int n0) {
         wbase = reinterpret_cast<const char*>((const T*)a.w + (size_t)b * a.sw + (size_t)n0 * a.ldw);
         xbase = reinterpret_cast<const char*>((const T*)a.x + (size_t)b * a.sx + (size_t)m0 * a.ldx);
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const int q = p * NT + tid, r = q / SPR;
-            if (r < BN) {
-                const int lim = a.N - 1 - n0;
-                off[p] = (unsigned)(((long long)(r < lim ? r : lim) * a.ldw + piece_slot(p) * 8) * 2);
-            } else {
-                const int lim = a.M - 1 - m0, rr = r - BN;
-                off[p] = (unsigned)(((long long)(rr < lim ? rr : lim) * a.ldx + piece_slot(p) * 8) * 2);
-            }
-        }
+        wlim = a.N - 1 - n0;
+        xlim = a.M - 1 - m0;
     };
     auto piece_src = [&](int p, int kt) {
-        const bool isw = (WQ % NT == 0) ? (p < WQ / NT) : (p * NT + tid < WQ);
-        return (isw ? wbase : xbase) + off[p] + (size_t)kt * ROWB;
+        const int q0 = p * NT + wave * 64;                   // (wave-uniform) first piece of this instruction
+        const bool isw = q0 < WQ;
+        int r = q0 / SPR - (isw ? 0 : BN) + lrow;
+        const int lim = isw ? wlim : xlim;
+        r = r < lim ? r : lim;
+        const unsigned off = (unsigned)r * (unsigned)(isw ? a.ldw : a.ldx) * 2u + (unsigned)lslot * 16u + (unsigned)kt * ROWB;
+        return (isw ? wbase : xbase) + off;
     };
     auto issue = [&](int kt, int stage) {                    // a full K-tile
         unsigned char* dst = lds + stage * STAGE + wave * 1024;
@@ -168,19 +192,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
         for (int p = 0; p < NP; p++) {
             if ((p + 1) * NT > NQ && p * NT + wave * 64 >= NQ) continue;
             const char* g = piece_src(p, kt);
-            if (kt * BK + piece_slot(p) * 8 >= a.K) g = reinterpret_cast<const char*>(&g_zero16);
+            if (kt * BK + lslot * 8 >= a.K) g = reinterpret_cast<const char*>(&g_zero16);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
         }
     };
     auto issue_first = [&]() { if (nk_full > 0) issue(0, 0); else issue_tail(0, 0); };
-
-    // ---- MFMA operand addresses within a stage ----
-    int a_off[KS], b_off[NI];   // (32-row block offsets do not change swz(row))
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) a_off[ks] = (wm * MI * 32 + r32) * ROWB + (((2 * ks + hi) ^ swz(r32)) << 4);
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++) b_off[ni] = (BN + (wn * NI + ni) * 32 + r32) * ROWB;
 
     int slot = next_valid(blockIdx.x);
     if (slot >= total) return;
@@ -189,20 +206,26 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
     aim(cb, cm0, cn0);
     issue_first();
 
+    int trace_n = 0;
+    (void)trace_n;
     bool more = true;
     const bool scaled = a.row_stats != nullptr || a.alpha != 1.0f;       // (uniform) the epilogue multiplies by a per-row / global scale
     while (true) {
+        geometry();
         // ---- accumulators start at the epilogue's additive terms, so that the epilogue itself is one multiply (or nothing), the
         //      16-bit pack and the stores: with  y = scale_m (sum_k x w' + init),
         //        LayerNorm fold:  scale_m = rstd_m,  init = c_n / rstd_m - mean_m s_n     (== rstd (acc - mean s) + c)
         //        otherwise:       scale   = alpha,   init = bias_n / alpha
         //      The vector loads behind this sit in the shadow of the tile's first DMA wait. ----
-        //      The per-column vectors travel through a wave-private corner of LDS stage 1 (free until the K loop's first
-        //      barrier): two loads per lane instead of forty, and the wait for them is the wait for the tile's first DMA.
+        //      The per-column vectors travel through wave-private LDS (the wave's epilogue staging area, untouched until the K
+        //      loop's first barrier): two loads per lane instead of forty, and the wait for them is the wait for the tile's first DMA.
+        GVD_STAMP(0);
         f16v acc[MI][NI];
         float rscale[NI];
         {
-            float* const vec = reinterpret_cast<float*>(lds + STAGE) + wave * (2 * MI * 32);
+            // (the wave's OWN epilogue staging area: free once its previous epilogue is done -- other waves may still be inside
+            //  theirs, so no other part of stage 1 may be touched here)
+            float* const vec = reinterpret_cast<float*>(lds + STAGE + wave * (32 * EP_PITCH));
             float rinv[NI], rmean[NI];
             const bool vecs = a.bias != nullptr || a.row_stats != nullptr;      // (uniform)
             if (vecs) {
@@ -246,6 +269,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
             }
         }
 
+        GVD_STAMP(1);
 #if GVD_GEMM_DBG & 8
         for (int kt = 0; kt < 1; kt++) {
 #else
@@ -253,12 +277,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                 // tile kt landed for everyone; stage (kt + 1) & 1 is free
+            if (kt == 0) GVD_STAMP(2);
+            if (kt == 1) GVD_STAMP(3);
 #if !(GVD_GEMM_DBG & 1)
             if (kt + 1 < nk_full) issue(kt + 1, (kt + 1) & 1);
             else if (kt + 1 < nk) issue_tail(kt + 1, (kt + 1) & 1);
 #endif
             const unsigned char* st = lds + (kt & 1) * STAGE;
-#pragma unroll
+#pragma unroll(KUNROLL)
             for (int ks = 0; ks < KS; ks++) {
                 vec8 af[MI], bf[NI];
 #pragma unroll
@@ -279,7 +305,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 #endif
             }
         }
+        GVD_STAMP(4);
         __syncthreads();   // all operand reads retired: both stages are free
+        GVD_STAMP(5);
 
         // ---- the next tile's first K-tile goes out now: its latency hides under this tile's epilogue ----
         const int tb = cb, tm0 = cm0, tn0 = cn0;
@@ -300,6 +328,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
         if (!more) break;
         continue;
 #endif
+        GVD_STAMP(6);
         T* __restrict__ yb = (T*)a.y + (size_t)tb * a.sy;
         const T* __restrict__ rb = a.res ? (const T*)a.res + (size_t)tb * a.sr : nullptr;
         unsigned char* const ep = lds + STAGE + wave * (32 * EP_PITCH);     // (stage 0 is receiving the next tile)
@@ -384,6 +413,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
                 }
             }
         }
+        GVD_STAMP(7);
+#ifdef GVD_GEMM_TRACE
+        trace_n += 8;
+#endif
         if (!more) break;
     }
 }
@@ -557,12 +590,15 @@ extern "C" {
 
 static int tile_n(long long M, int N, int batch)
 {
-    // the 5-block (160 / 320-channel) tile when it wastes less of N than the 4-block (128 / 256) one: 320, 640, 1280, 2560 ...
-    // divide exactly; both widths are multiples of the GEGLU epilogue's 32-row blocks
-    const int big = gemm_variant(M, N, batch) == 1 ? 2 : 1;
+    // 5-block (160 / 320-channel) or 4-block (128 / 256) tiles: the one whose launch is shorter under the simple model
+    // rounds-of-resident-workgroups x tile width (padding of N and a mostly empty last round both cost); ties go to the wider tile
+    static const int forced = [] { const char* e = getenv("GVD_GEMM_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int v = gemm_variant(M, N, batch), big = v == 1 ? 2 : 1, resident = v == 1 ? 256 : 512;
     const int w5 = 160 * big, w4 = 128 * big;
-    const int t5 = (N + w5 - 1) / w5 * w5, t4 = (N + w4 - 1) / w4 * w4;
-    return t5 <= t4 ? w5 : w4;
+    if (forced == 4 || forced == 5) return forced == 5 ? w5 : w4;
+    const long long mt = (M + BM - 1) / BM * batch;
+    auto cost = [&](int w) { const long long tiles = mt * ((N + w - 1) / w); return (tiles + resident - 1) / resident * w; };
+    return cost(w5) <= cost(w4) ? w5 : w4;
 }
 
 int gvd_gemm_tile_n(int M, int N, int batch) { return tile_n(M, N, batch); }
@@ -650,5 +686,12 @@ int gvd_attn_ds(void* s, void* dp, const float* lse, const float* delta, long lo
     if (e != hipSuccess) return fail(-2, "launch k_attn_ds", e);
     return 0;
 }
+
+#ifdef GVD_GEMM_TRACE
+int gvd_gemm_trace_read(unsigned long long* host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * (n < 1024 ? n : 1024)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

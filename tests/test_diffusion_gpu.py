@@ -536,8 +536,13 @@ def test_resampler_on_device_golden_and_fp16_kernels():
     rs = fill_by_name(Resampler(**big), std=0.02).eval().to(DEV)
     g = torch.Generator(device=DEV).manual_seed(9)
     tokens = torch.randn(2, 257, 1280, device=DEV, generator=g)
-    calls = {"attn": 0, "ln": 0}
-    orig_a, orig_l = ops._hip_attention_fwd, ops._hip_layer_norm
+    from lvdm_amd import gemm
+    calls = {"attn": 0, "ln": 0, "gemm": 0}
+    orig_a, orig_l, orig_g = ops._hip_attention_fwd, ops._hip_layer_norm, gemm.gemm_nt
+
+    def count_g(*a, **k):
+        calls["gemm"] += 1
+        return orig_g(*a, **k)
 
     def count_a(*a, **k):
         calls["attn"] += 1
@@ -550,11 +555,13 @@ def test_resampler_on_device_golden_and_fp16_kernels():
     with torch.no_grad():
         y32 = rs(tokens)
         half = rs.half()
-        ops._hip_attention_fwd, ops._hip_layer_norm = count_a, count_l
+        ops._hip_attention_fwd, ops._hip_layer_norm, gemm.gemm_nt = count_a, count_l, count_g
         try:
             y16 = half(tokens.half())
         finally:
-            ops._hip_attention_fwd, ops._hip_layer_norm = orig_a, orig_l
-    assert y16.shape == (2, 256, 1024) and calls["attn"] == 4 and calls["ln"] == 4 * 3 + 1, calls
+            ops._hip_attention_fwd, ops._hip_layer_norm, gemm.gemm_nt = orig_a, orig_l, orig_g
+    # 4 attention launches; every Linear is the MFMA GEMM (proj_in, 6 per layer, proj_out) with the 3 LayerNorms of a layer folded
+    # into its projections -- only norm_out is still a LayerNorm launch
+    assert y16.shape == (2, 256, 1024) and calls == {"attn": 4, "ln": 1, "gemm": 2 + 4 * 6}, calls
     err = float((y16.float() - y32).abs().max()) / float(y32.abs().max())
     assert err < 2e-2, err

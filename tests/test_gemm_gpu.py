@@ -123,3 +123,31 @@ def test_no_cpu_path():
     from lvdm_amd import gemm
     with pytest.raises(RuntimeError):
         gemm.linear(torch.randn(4, 64), torch.randn(8, 64))
+
+
+@pytest.mark.parametrize("geglu", [False, True])
+def test_many_tiles_per_persistent_workgroup(geglu):
+    """More tiles than resident workgroups (each persistent workgroup walks several tiles, its waves drift apart between one
+    tile's epilogue and the next tile's start): every epilogue feature on, full comparison.  A race between one wave's epilogue
+    staging and another wave's next-tile set-up produced non-finite values at the 25-frame U-Net size only (round 3)."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(17)
+    M, C, N = 60000, 320, 2560
+    x = _mk(g, M, C)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.3 * torch.randn(C, device=DEV, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(C, device=DEV, generator=g))
+    lin = torch.nn.Linear(C, N).to(DEV)
+    ln.half().requires_grad_(False), lin.half().requires_grad_(False)
+    res = _mk(g, M, N // 2 if geglu else N)
+    with torch.no_grad():
+        for _ in range(3):                                   # (a race is timing dependent: several launches)
+            y = gemm.linear(x, lin.weight, lin.bias, ln=ln, geglu=geglu, residual=res)
+            assert torch.isfinite(y).all()
+        ref = F.linear(F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps), lin.weight.float(), lin.bias.float())
+        if geglu:
+            a, gate = ref.chunk(2, dim=-1)
+            ref = a * F.gelu(gate)
+        ref = ref + res.float()
+    assert _rel(y, ref) < 3e-3, _rel(y, ref)
