@@ -202,6 +202,20 @@ def raster_run(args, dev, rank, world):
     import multiview
     L = _C.lib()
 
+    # workload statistics for the algorithmic byte counts (instances and visible Gaussians per camera), collected BEFORE the
+    # timed loop: one no-grad render per camera with the exact (reference) forward
+    Rs, vis = [], []
+    cap0 = args.instance_capacity
+    _C.set_instance_capacity(0)
+    with torch.no_grad():
+        for s_ in cams:
+            out = _C.rasterize_gaussians(bg, means3D.detach(), torch.Tensor([]), opac.detach(), scales.detach(), rots.detach(),
+                                         1.0, torch.Tensor([]), s_.viewmatrix, s_.projmatrix, s_.tanfovx, s_.tanfovy, H, W,
+                                         shs.detach(), args.sh_degree, s_.campos, False, False)
+            Rs.append(int(out[0]))
+            vis.append(int((out[4] > 0).sum().item()))
+    _C.set_instance_capacity(cap0)
+
     def timed_region(n_warm, n_steps, profile):
         for i in range(n_warm):
             step(i)
@@ -294,16 +308,7 @@ def raster_run(args, dev, rank, world):
     kern.update(kern_live)  # blend kernels: the live numbers
 
     if rank == 0:
-        # workload statistics for the algorithmic byte counts (mean over the cameras rank 0 used)
-        Rs, vis = [], []
-        _C.set_instance_capacity(0)  # the statistics below need the exact num_rendered
-        with torch.no_grad():
-            for s in cams:
-                out = _C.rasterize_gaussians(bg, means3D.detach(), torch.Tensor([]), opac.detach(), scales.detach(), rots.detach(),
-                                             1.0, torch.Tensor([]), s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, H, W,
-                                             shs.detach(), args.sh_degree, s.campos, False, False)
-                Rs.append(int(out[0]))
-                vis.append(int((out[4] > 0).sum().item()))
+        # workload statistics (collected above), averaged over the cameras rank 0 used
         used = [(i * world) % len(cams) for i in range(args.warmup, args.warmup + args.steps)]
         R_mean = float(np.mean([Rs[u] for u in used]))
         vis_mean = float(np.mean([vis[u] for u in used]))
@@ -828,6 +833,24 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
     }
+    if not guided and world == 1 and not args.graph and not args.batch_cfg:
+        # the same steps with the two U-Net evaluations replayed from a captured hipGraph (lvdm_amd/graphs.py: sampler.graph_apply)
+        # and no per-kernel event pairs: what the ~1100 launches + 2200 event records per step cost the eager, instrumented line
+        sampler.graph_apply = True
+        try:
+            for i in range(2):
+                x = one(i, x)
+            torch.cuda.synchronize()
+            n_g = min(steps, 10)
+            t0 = time.perf_counter()
+            for i in range(n_g):
+                x = one(2 + i, x)
+            torch.cuda.synchronize()
+            el_g = time.perf_counter() - t0
+            line["graph_replay"] = {"value": round(n_g / el_g, 4), "unit": "steps/s", "steps": n_g, "ms_per_step": round(1e3 * el_g / n_g, 2),
+                                    "what": "U-Net evaluations replayed from a hipGraph, no per-kernel events (not the headline)"}
+        finally:
+            sampler.graph_apply = False
     if cpu_leg_wanted and unet_tflop and world == 1:
         line["cpu_baseline"] = ddim_cpu_leg(unet, T, unet_tflop, guided)
     return line

@@ -26,14 +26,14 @@ template <typename T> __device__ __forceinline__ float to_f(T v) { return (float
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_attn_delta(const T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ delta,
-                                                    int H, int Nq, long long total, long long q_bs, long long q_rs)
+                                                    int H, int Nq, long long total, long long o_bs, long long o_rs)   // (out / d_out addressing)
 {
     typedef typename Tr<T>::vec8 vec8;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (b*H + h) * Nq + n
     if (i >= total) return;
     const long long bh = i / Nq;
     const int n = (int)(i - bh * Nq), b = (int)(bh / H), h = (int)(bh - (long long)b * H);
-    const size_t off = (size_t)b * q_bs + (size_t)n * q_rs + (size_t)h * 64;
+    const size_t off = (size_t)b * o_bs + (size_t)n * o_rs + (size_t)h * 64;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -100,7 +100,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_attn_bwd_dkv(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ d_o,
                const float* __restrict__ lse, const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv,
-               int H, int Nq, int Nk, float scale_log2e, float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs)
+               int H, int Nq, int Nk, float scale_log2e, float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
+               long long o_bs, long long o_rs)
 {
     typedef typename Tr<T>::vec8 vec8;
     __shared__ __attribute__((aligned(16))) T sQ[64][LDS_ROW];
@@ -114,7 +115,7 @@ k_attn_bwd_dkv(const T* __restrict__ q, const T* __restrict__ k, const T* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31;
     const size_t rs = (size_t)q_rs, krs = (size_t)kv_rs;
     const T* qb = q + (size_t)b * q_bs + (size_t)h * 64;
-    const T* gb = d_o + (size_t)b * q_bs + (size_t)h * 64;
+    const T* gb = d_o + (size_t)b * o_bs + (size_t)h * 64;   // d_out has its own strides: q may be a column block of a packed projection
     const size_t kvoff = (size_t)b * kv_bs + (size_t)h * 64;
     const float* lse_b = lse + (size_t)bh * Nq;
     const float* delta_b = delta + (size_t)bh * Nq;
@@ -135,7 +136,7 @@ k_attn_bwd_dkv(const T* __restrict__ q, const T* __restrict__ k, const T* __rest
     float rl = 0.f, rd = 0.f;
     auto prefetch = [&](int qt) {
         tile_load<T, true>(qb, rs, qt, Nq, tid, rq);
-        tile_load<T, true>(gb, rs, qt, Nq, tid, rg);
+        tile_load<T, true>(gb, (size_t)o_rs, qt, Nq, tid, rg);
         const int r = qt + (tid & 63) < Nq ? qt + (tid & 63) : Nq - 1;
         rl = lse_b[r];
         rd = delta_b[r];
@@ -221,7 +222,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_attn_bwd_dq(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ d_o,
               const float* __restrict__ lse, const float* __restrict__ delta, T* __restrict__ dq,
-              int H, int Nq, int Nk, float scale_log2e, float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs)
+              int H, int Nq, int Nk, float scale_log2e, float scale, long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
+              long long o_bs, long long o_rs)
 {
     typedef typename Tr<T>::vec8 vec8;
     __shared__ __attribute__((aligned(16))) T sK[64][LDS_ROW];
@@ -242,7 +244,7 @@ k_attn_bwd_dq(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
     for (int ks = 0; ks < 4; ks++) {
         const size_t qr = (size_t)(valid_q ? query : Nq - 1) * rs + 16 * ks + 8 * hi;   // unconditional load, zeroed below
         qf[ks] = *reinterpret_cast<const vec8*>(q + qoff + qr);
-        gf[ks] = *reinterpret_cast<const vec8*>(d_o + qoff + qr);
+        gf[ks] = *reinterpret_cast<const vec8*>(d_o + (size_t)b * o_bs + (size_t)h * 64 + (size_t)(valid_q ? query : Nq - 1) * (size_t)o_rs + 16 * ks + 8 * hi);
         if (!valid_q) { qf[ks] = vec8{}; gf[ks] = vec8{}; }
     }
     const float L = valid_q ? lse[(size_t)bh * Nq + query] : 3.0e38f;
@@ -315,18 +317,18 @@ k_attn_bwd_dq(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 template <typename T>
 int launch_bwd(const void* q, const void* k, const void* v, const void* out, const void* d_out, const float* lse, float* delta,
                void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, float scale, long long q_bs, long long q_rs,
-               long long kv_bs, long long kv_rs, hipStream_t stream)
+               long long kv_bs, long long kv_rs, long long o_bs, long long o_rs, hipStream_t stream)
 {
     const float sl2 = scale * 1.4426950408889634f;
     const long long total = (long long)B * H * Nq;
     hipLaunchKernelGGL(k_attn_delta<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const T*)out, (const T*)d_out,
-                       delta, H, Nq, total, q_bs, q_rs);
+                       delta, H, Nq, total, o_bs, o_rs);
     hipLaunchKernelGGL(k_attn_bwd_dkv<T>, dim3((unsigned)(B * H), (unsigned)((Nk + 127) / 128)), dim3(256), 0, stream, (const T*)q,
                        (const T*)k, (const T*)v, (const T*)d_out, lse, (const float*)delta, (T*)dk, (T*)dv, H, Nq, Nk, sl2, scale,
-                       q_bs, q_rs, kv_bs, kv_rs);
+                       q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs);
     hipLaunchKernelGGL(k_attn_bwd_dq<T>, dim3((unsigned)(B * H), (unsigned)((Nq + 127) / 128)), dim3(256), 0, stream, (const T*)q,
                        (const T*)k, (const T*)v, (const T*)d_out, lse, (const float*)delta, (T*)dq, H, Nq, Nk, sl2, scale,
-                       q_bs, q_rs, kv_bs, kv_rs);
+                       q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_attn_bwd_*", e);
     return 0;
@@ -334,18 +336,27 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* out, con
 
 }  // namespace
 
-extern "C" int gvd_attention_bwd_strided(const void* q, const void* k, const void* v, const void* out, const void* d_out,
-                                         const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq,
-                                         int Nk, int D, float scale, long long q_bs, long long q_rs, long long kv_bs,
-                                         long long kv_rs, int is_bf16, void* stream_)
+extern "C" int gvd_attention_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* d_out,
+                                    const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq,
+                                    int Nk, int D, float scale, long long q_bs, long long q_rs, long long kv_bs,
+                                    long long kv_rs, long long o_bs, long long o_rs, int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !k || !v || !out || !d_out || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0)
         return fail(-1, "gvd_attention_bwd: bad arguments");
     if (D != 64) return fail(-1, "gvd_attention_bwd: head dim must be 64");
-    if ((q_bs | q_rs | kv_bs | kv_rs) & 7) return fail(-1, "gvd_attention_bwd: strides must be multiples of 8 elements");
+    if ((q_bs | q_rs | kv_bs | kv_rs | o_bs | o_rs) & 7) return fail(-1, "gvd_attention_bwd: strides must be multiples of 8 elements");
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)
         return fail(-1, "gvd_attention_bwd: pointers must be 16-byte aligned");
-    if (is_bf16) return launch_bwd<__bf16>(q, k, v, out, d_out, lse, delta, dq, dk, dv, B, H, Nq, Nk, scale, q_bs, q_rs, kv_bs, kv_rs, stream);
-    return launch_bwd<_Float16>(q, k, v, out, d_out, lse, delta, dq, dk, dv, B, H, Nq, Nk, scale, q_bs, q_rs, kv_bs, kv_rs, stream);
+    if (is_bf16) return launch_bwd<__bf16>(q, k, v, out, d_out, lse, delta, dq, dk, dv, B, H, Nq, Nk, scale, q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs, stream);
+    return launch_bwd<_Float16>(q, k, v, out, d_out, lse, delta, dq, dk, dv, B, H, Nq, Nk, scale, q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs, stream);
+}
+
+extern "C" int gvd_attention_bwd_strided(const void* q, const void* k, const void* v, const void* out, const void* d_out,
+                                         const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq,
+                                         int Nk, int D, float scale, long long q_bs, long long q_rs, long long kv_bs,
+                                         long long kv_rs, int is_bf16, void* stream_)
+{
+    return gvd_attention_bwd_ex(q, k, v, out, d_out, lse, delta, dq, dk, dv, B, H, Nq, Nk, D, scale, q_bs, q_rs, kv_bs, kv_rs, q_bs,
+                                q_rs, is_bf16, stream_);
 }

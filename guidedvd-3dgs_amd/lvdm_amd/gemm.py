@@ -152,36 +152,73 @@ def _prepared(weights, biases, ln, geglu, dtype):
     return val
 
 
-def _transposed(weight, dtype):
-    """[K, N] image of a Linear weight [N, K] (the input-gradient operator), cached."""
-    key = (_tag(weight), dtype)
-    cache = getattr(weight, "_gvd_gemm_t", None)
+def _transposed(weights, dtype):
+    """[K, sum N_i] image of the row-concatenated Linear weights (the input-gradient operator dX = dY W), cached on the first."""
+    weights = list(weights) if isinstance(weights, (list, tuple)) else [weights]
+    key = (tuple(_tag(w) for w in weights), dtype)
+    cache = getattr(weights[0], "_gvd_gemm_t", None)
     if cache is None or cache[0] != key:
-        cache = (key, weight.detach().reshape(weight.shape[0], -1).to(dtype).t().contiguous())
+        W = torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], dim=0).to(dtype)
+        Wt = W.t().contiguous()
+        pad = (-Wt.shape[1]) % 8
+        if pad:
+            Wt = F.pad(Wt, (0, pad))
+        cache = (key, Wt)
         try:
-            weight._gvd_gemm_t = cache
+            weights[0]._gvd_gemm_t = cache
         except AttributeError:
             pass
     return cache[1]
 
 
-class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b on the MFMA kernel; gradient w.r.t. x only (the guided sampler differentiates with frozen weights)."""
+class _FusedLinearFn(torch.autograd.Function):
+    """[geglu](LayerNorm?(x) [W_0; W_1; ...]^T + b) [+ residual] as ONE forward launch under autograd; gradients w.r.t. x and the
+    residual only (the guided sampler differentiates with frozen weights).  The backward needs nothing the forward would have to
+    store beyond x: dY W is one GEMM against the transposed (unfolded) weights, the LayerNorm input gradient is the row kernel
+    that recomputes the statistics from x, and for GEGLU the pre-activation is RECOMPUTED by one more LayerNorm-folded GEMM
+    instead of being written (1.2 GB per block at 576x1024) and kept."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias):
-        Wd, c, _ = _prepared([weight], [bias], None, False, x2.dtype)
-        ctx.weight = weight
-        return gemm_nt(x2, Wd, bias=c)
+    def forward(ctx, x2, r2, ln_w, ln_b, cfg, *wb):
+        n = len(wb) // 2
+        weights, biases = list(wb[:n]), list(wb[n:])
+        ln, geglu = cfg
+        Wd, c, s = _prepared(weights, biases, ln, geglu, x2.dtype)
+        st = None if ln is None else row_stats(x2, ln.eps)
+        ctx.save_for_backward(*([x2] if (ln is not None or geglu) else []))   # (x is only needed by the LayerNorm backward / the gate recompute)
+        ctx.cfg = (weights, biases, ln, geglu, r2 is not None)
+        return gemm_nt(x2, Wd, bias=c, row_stats=st, col_sum=s, residual=r2, geglu=geglu)
 
     @staticmethod
     def backward(ctx, gy):
+        weights, biases, ln, geglu, has_res = ctx.cfg
+        x2 = ctx.saved_tensors[0] if (ln is not None or geglu) else None
         gy = gy if gy.stride(-1) == 1 else gy.contiguous()
-        Wt = _transposed(ctx.weight, gy.dtype)
-        pad = (-gy.shape[1]) % 8
+        g = gy
+        if geglu:   # recompute h = LayerNorm(x) W^T + b (natural column order), then the gate's backward row kernel
+            Wd, c, s = _prepared(weights, biases, ln, False, x2.dtype)
+            st = None if ln is None else row_stats(x2, ln.eps)
+            h = gemm_nt(x2, Wd, bias=c, row_stats=st, col_sum=s)
+            C = h.shape[-1] // 2
+            g = torch.empty_like(h)
+            with ops._on(h.device):
+                ops._check(ops.lib().gvd_geglu_bwd(_P(h.data_ptr()), _P(gy.contiguous().data_ptr()), _P(g.data_ptr()),
+                                                   _LL(h.shape[0]), C, 1 if h.dtype == torch.bfloat16 else 0, _P(ops._stream())))
+        Wt = _transposed(weights, g.dtype)                       # [K, N]
+        pad = Wt.shape[1] - g.shape[1]
         if pad:
-            gy, Wt = F.pad(gy, (0, pad)), F.pad(Wt, (0, pad))
-        return gemm_nt(gy, Wt), None, None
+            g = F.pad(g, (0, pad))
+        dh = gemm_nt(g, Wt)
+        if ln is not None:
+            gx = torch.empty_like(dh)
+            C = dh.shape[-1]
+            x2c = x2 if x2.is_contiguous() else x2.contiguous()
+            with ops._on(dh.device):
+                ops._check(ops.lib().gvd_layer_norm_bwd(_P(x2c.data_ptr()), _P(dh.data_ptr()), _P(ln.weight.data_ptr()), _P(gx.data_ptr()),
+                                                        _LL(dh.shape[0]), C, ctypes.c_float(ln.eps),
+                                                        1 if dh.dtype == torch.bfloat16 else 0, _P(ops._stream())))
+            dh = gx
+        return (dh, gy if has_res else None, None, None, None) + (None,) * (2 * len(weights))
 
 
 def _rows(x):
@@ -194,6 +231,12 @@ def _rows(x):
     except RuntimeError:
         x2 = x.reshape(-1, K)
     return x2 if x2.stride(-1) == 1 else x2.contiguous()
+
+
+def _ln_kernel_ok(x, ln):
+    """The LayerNorm input-gradient row kernel covers 16-bit affine parameters of the activations' type, C <= 2048."""
+    return (ln.weight is not None and ln.bias is not None and ln.weight.dtype == x.dtype and ln.bias.dtype == x.dtype
+            and x.shape[-1] <= 2048 and not ln.weight.requires_grad and not ln.bias.requires_grad)
 
 
 def _hip_ok(x, weights):
@@ -221,12 +264,20 @@ def linear(x, weight, bias=None, *, ln=None, residual=None, geglu=False):
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
     if torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)):
         raise RuntimeError("lvdm_amd.gemm.linear: only the input gradient is implemented (freeze the weights)")
-    if needs_grad:   # guided sampler: compose the kernels that have input gradients (LayerNorm / GEGLU row kernels + this GEMM)
-        h = x if ln is None else ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
-        y = _LinearFn.apply(_rows(h), weight, bias).reshape(*lead, N)
+    if needs_grad:   # guided sampler: the same fused forward, input gradients through _FusedLinearFn
+        if ln is not None and not _ln_kernel_ok(x, ln):
+            h = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+            return linear(h, weight, bias, residual=residual, geglu=geglu)
         if geglu:
-            y = ops.geglu(y)
-        return y if residual is None else y + residual
+            # the gate stays a separate row kernel under autograd: its backward needs the pre-activation, and recomputing it
+            # (measured: guided step 1331 -> 1355 ms) costs more than writing it once (the projection itself is still ONE launch
+            # with the LayerNorm folded in)
+            h = _FusedLinearFn.apply(_rows(x), None, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, False), weight, bias)
+            y = ops.geglu(h).reshape(*lead, No)
+            return y if residual is None else y + residual
+        r2 = None if residual is None else _rows(residual)
+        y = _FusedLinearFn.apply(_rows(x), r2, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, False), weight, bias)
+        return y.reshape(*lead, No)
     x2 = _rows(x)
     Wd, c, s = _prepared([weight], [bias], ln, geglu, x.dtype)
     st = None if ln is None else row_stats(x2, ln.eps)
@@ -239,9 +290,18 @@ def linear_cat(x, weights, biases=None, *, ln=None):
     slices views (the attention kernels read them in place through their row strides)."""
     biases = [None] * len(weights) if biases is None else biases
     K = x.shape[-1]
-    if not _hip_ok(x, weights) or (torch.is_grad_enabled() and x.requires_grad):
+    if not _hip_ok(x, weights):
         h = x if ln is None else (ops.layer_norm(x, ln.weight, ln.bias, ln.eps) if x.is_cuda else F.layer_norm(x, (K,), ln.weight, ln.bias, ln.eps))
         return torch.cat([linear(h, w, b) for w, b in zip(weights, biases)], dim=-1)
+    if torch.is_grad_enabled() and x.requires_grad:
+        if any(w.requires_grad for w in weights):
+            raise RuntimeError("lvdm_amd.gemm.linear_cat: only the input gradient is implemented (freeze the weights)")
+        if ln is not None and not _ln_kernel_ok(x, ln):
+            h = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+            return linear_cat(h, weights, biases)
+        y = _FusedLinearFn.apply(_rows(x), None, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, False),
+                                 *weights, *biases)
+        return y.reshape(*x.shape[:-1], y.shape[-1])
     x2 = _rows(x)
     Wd, c, s = _prepared(list(weights), list(biases), ln, False, x.dtype)
     st = None if ln is None else row_stats(x2, ln.eps)

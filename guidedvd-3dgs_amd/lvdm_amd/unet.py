@@ -132,12 +132,12 @@ class CrossAttention(nn.Module):
         C = self.to_q.weight.shape[0]
         if context is None:
             qkv = gemm.linear_cat(x, [self.to_q.weight, self.to_k.weight, self.to_v.weight], ln=norm)   # one launch, LayerNorm folded
-            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+            # q | k | v are read in place as column blocks (and, under autograd, their gradients written in place)
             if frame_major:  # x [b, T, pixels, C]: one T-long sequence per pixel, read in place
-                outs = [ops.attention(q[i], k[i], v[i], self.heads, frame_major=True) for i in range(x.shape[0])]
+                outs = [ops.self_attention_packed(qkv[i], self.heads, frame_major=True) for i in range(x.shape[0])]
                 out = outs[0][None] if len(outs) == 1 else torch.stack(outs, 0)   # b = 1 (the sampler's case): a view, not a copy
             else:
-                out = ops.attention(q, k, v, self.heads)
+                out = ops.self_attention_packed(qkv, self.heads)
         else:
             q = gemm.linear(x, self.to_q.weight, ln=norm)
             k, v, k_ip, v_ip = self._kv(context, shared_frames)

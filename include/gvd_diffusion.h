@@ -53,6 +53,15 @@ int gvd_attention_bwd_strided(const void* q, const void* k, const void* v, const
                               long long q_bs, long long q_rs, long long kv_bs, long long kv_rs,
                               int is_bf16, void* stream);
 
+/* gvd_attention_bwd_strided with separate addressing (o_bs, o_rs) for out / d_out: q, k, v -- and dq, dk, dv, which are addressed
+ * like them -- may then be column blocks of one packed [rows, q | k | v] tensor, so the gradient of a fused q|k|v projection is
+ * written in place (no slice / concatenate copies under autograd). */
+int gvd_attention_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* d_out,
+                         const float* lse, float* delta, void* dq, void* dk, void* dv,
+                         int B, int H, int Nq, int Nk, int D, float scale,
+                         long long q_bs, long long q_rs, long long kv_bs, long long kv_rs, long long o_bs, long long o_rs,
+                         int is_bf16, void* stream);
+
 /* One complete no-grad DDIM update for the v-parameterisation, batch 1, fp32 latents of n elements:
  *   v      = e_uncond + cfg_scale (e_cond - e_uncond)
  *   v      = phi v std(e_cond)/std(v) + (1 - phi) v              (phi = guidance_rescale; skipped if 0)

@@ -565,3 +565,32 @@ def test_resampler_on_device_golden_and_fp16_kernels():
     assert y16.shape == (2, 256, 1024) and calls == {"attn": 4, "ln": 1, "gemm": 2 + 4 * 6}, calls
     err = float((y16.float() - y32).abs().max()) / float(y32.abs().max())
     assert err < 2e-2, err
+
+
+@pytest.mark.parametrize("frame_major", [False, True])
+def test_packed_self_attention_reads_and_writes_the_projection_in_place(frame_major):
+    """ops.self_attention_packed: q | k | v as column blocks of ONE tensor (the fused projection's output).  Forward and the
+    gradient w.r.t. the packed tensor equal the three-tensor form bit for bit (same kernels, different addressing), and the
+    no-grad form with broadcast K / V (batch stride 0) plus the accumulate epilogue equals the expanded + added form."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(4)
+    B, N, H = (300, 25, 5) if frame_major else (3, 333, 5)
+    C = 64 * H
+    shape = (N, B, 3 * C) if frame_major else (B, N, 3 * C)
+    qkv = torch.randn(*shape, device=DEV, generator=g).half().requires_grad_(True)
+    o = ops.self_attention_packed(qkv, H, frame_major=frame_major)
+    probe = torch.randn(*o.shape, device=DEV, generator=g).half()
+    (gp,) = torch.autograd.grad(o, qkv, probe)
+    q, k, v = (qkv.detach()[..., i * C:(i + 1) * C].contiguous().requires_grad_(True) for i in range(3))
+    o2 = ops.attention(q, k, v, H, frame_major=frame_major)
+    gq, gk, gv = torch.autograd.grad(o2, (q, k, v), probe)
+    assert torch.equal(o, o2)
+    assert torch.equal(gp, torch.cat([gq, gk, gv], dim=-1))
+    if not frame_major:
+        with torch.no_grad():
+            ctx_kv = torch.randn(1, 77, 2 * C, device=DEV, generator=g).half()
+            base = ops.attention(q, ctx_kv[..., :C], ctx_kv[..., C:], H)                          # K / V shared by the batch
+            full = ops.attention(q, ctx_kv[..., :C].expand(B, -1, -1).contiguous(), ctx_kv[..., C:].expand(B, -1, -1).contiguous(), H)
+            assert torch.equal(base, full)
+            acc = ops.attention(q, ctx_kv[..., :C], ctx_kv[..., C:], H, accum=o2.detach(), accum_scale=1.0)
+            assert torch.equal(acc, o2.detach() + base)

@@ -151,3 +151,45 @@ def test_many_tiles_per_persistent_workgroup(geglu):
             ref = a * F.gelu(gate)
         ref = ref + res.float()
     assert _rel(y, ref) < 3e-3, _rel(y, ref)
+
+
+def test_fused_forms_under_autograd_match_fp32():
+    """Guided-sampler path: the fused forward launches (LayerNorm fold + q|k|v concat; LayerNorm fold + GEGLU; residual) keep
+    their fusion under autograd (`_FusedLinearFn`; only the GEGLU gate stays a separate row kernel there)."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(23)
+    C, M = 320, 1100
+    x = _mk(g, 2, M // 2, C).requires_grad_(True)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.3 * torch.randn(C, device=DEV, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(C, device=DEV, generator=g))
+    ln.half().requires_grad_(False)
+    ws = [torch.nn.Linear(C, C, bias=False).to(DEV).half().requires_grad_(False).weight for _ in range(3)]
+    p1 = torch.nn.Linear(C, 8 * C).to(DEV).half().requires_grad_(False)
+    p2 = torch.nn.Linear(4 * C, C).to(DEV).half().requires_grad_(False)
+    calls = {"n": 0}
+    orig = gemm.gemm_nt
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    gemm.gemm_nt = counted
+    try:
+        qkv = gemm.linear_cat(x, ws, ln=ln)                                   # 1 launch
+        h = gemm.linear(x, p1.weight, p1.bias, ln=ln, geglu=True)             # 1 launch (+ the gate's row kernel under autograd)
+        y = gemm.linear(h, p2.weight, p2.bias, residual=x)                    # 1 launch
+        assert calls["n"] == 3
+        probe_q, probe_y = _mk(g, *qkv.shape), _mk(g, *y.shape)
+        (gx,) = torch.autograd.grad([qkv, y], [x], [probe_q, probe_y])
+        assert calls["n"] == 3 + 3                                            # dqkv W_qkv; dy W2; dh W1
+    finally:
+        gemm.gemm_nt = orig
+    xf = x.detach().float().requires_grad_(True)
+    hn = F.layer_norm(xf, (C,), ln.weight.float(), ln.bias.float(), ln.eps)
+    qkv_r = torch.cat([hn @ w.float().t() for w in ws], dim=-1)
+    a, gate = F.linear(hn, p1.weight.float(), p1.bias.float()).chunk(2, dim=-1)
+    y_r = F.linear(a * F.gelu(gate), p2.weight.float(), p2.bias.float()) + xf
+    (g_r,) = torch.autograd.grad([qkv_r, y_r], [xf], [probe_q.float(), probe_y.float()])
+    assert _rel(qkv.detach(), qkv_r.detach()) < 2.5e-3 and _rel(y.detach(), y_r.detach()) < 3e-3
+    assert _rel(gx, g_r) < 6e-3, _rel(gx, g_r)
