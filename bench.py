@@ -761,7 +761,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         a.record()
         o = orig_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw)
         b.record()
-        ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * (3 if mode == mconv.TEMPORAL else 9)))
+        ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * (3 if mode == mconv.TEMPORAL else 9), ("conv", mode, N, H, W, Cin, Cout, int(kw.get("upsample", 0) or 0))))
         return o
 
     from lvdm_amd import gemm as mgemm
@@ -774,7 +774,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         o = orig_gemm(xx, ww, **kw)
         b.record()
         bt = max(xx.shape[0] if xx.dim() == 3 else 1, ww.shape[0] if ww.dim() == 3 else 1)
-        ev_gemm.append((a, b, 2.0 * bt * xx.shape[-2] * ww.shape[-2] * xx.shape[-1]))
+        ev_gemm.append((a, b, 2.0 * bt * xx.shape[-2] * ww.shape[-2] * xx.shape[-1],
+                        ("gemm", bt, xx.shape[-2], ww.shape[-2], xx.shape[-1], bool(kw.get("geglu")), kw.get("row_stats") is not None, kw.get("residual") is not None)))
         return o
 
     ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
@@ -799,8 +800,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     MFMA_PEAK = 2500.0  # TFLOP/s dense f16/bf16 (MI355X_MICROARCH.md)
 
     def roof(evs, name):
-        ms = sum(a.elapsed_time(b) for a, b, _ in evs)
-        fl = sum(f for _, _, f in evs)
+        ms = sum(e[0].elapsed_time(e[1]) for e in evs)
+        fl = sum(e[2] for e in evs)
         if not ms:
             return None
         ach = fl / (ms * 1e-3) / 1e12
@@ -811,6 +812,19 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     r_conv = roof(ev_conv, "k_conv_mfma (3x3 / upsample / temporal implicit-GEMM convolutions, fused GroupNorm+SiLU prologue)")
     r_attn = roof(ev_attn, "k_attn_fwd (all spatial / cross / temporal attention launches)")
     r_gemm = roof(ev_gemm, "k_gemm_nt (every Linear / 1x1 convolution: LayerNorm fold, GEGLU, residual in the epilogue)")
+    if os.environ.get("GVD_BENCH_SHAPE_TABLE"):   # per-shape in-situ times of the two GEMM-like families (profiles/r03_*_by_shape.json)
+        agg = {}
+        for e in ev_conv + ev_gemm:
+            r = agg.setdefault(e[3], [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += e[0].elapsed_time(e[1])
+            r[2] += e[2]
+        rows = sorted(({"shape": list(k), "launches_per_step": v[0] / steps, "ms_per_step": round(v[1] / steps, 3),
+                        "avg_us": round(1e3 * v[1] / v[0], 1), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in agg.items()),
+                      key=lambda r_: -r_["ms_per_step"])
+        with open(os.environ["GVD_BENCH_SHAPE_TABLE"], "w") as fh:
+            json.dump({"legend": {"conv": ["conv", "mode (0 spatial, 1 temporal, 2 stride-2)", "N", "H", "W", "Cin", "Cout", "upsample"],
+                                  "gemm": ["gemm", "batch", "M", "N", "K", "geglu", "layernorm_fold", "residual"]}, "rows": rows}, fh, indent=1)
     dominant = r_conv if (r_conv and (not r_attn or r_conv["ms_per_step"] >= r_attn["ms_per_step"])) else r_attn
     unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
     line = {

@@ -55,7 +55,7 @@ struct GemmArgs {
 };
 
 #ifndef GVD_GEMM_KUNROLL5
-#define GVD_GEMM_KUNROLL5 2
+#define GVD_GEMM_KUNROLL5 4   // (2 measured 1-3 % slower once the kernels stopped spilling)
 #endif
 #ifndef GVD_GEMM_DBG
 #define GVD_GEMM_DBG 0   // experiments only (tests/scripts/build_gemm_variants.sh): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue, 8 = one K-tile only, 16 = no global stores
