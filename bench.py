@@ -67,7 +67,7 @@ def main():
                          "between forward and backward: 'fused' = fused_loss HIP kernels, 'torch' = the reference's conv2d form")
     ap.add_argument("--instance-capacity", type=int, default=0,
                     help="raster: sync-free forward with this (Gaussian, tile) instance capacity (0 = reference behaviour)")
-    ap.add_argument("--graph", action="store_true", help="ddim: replay the U-Net evaluations from a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="ddim: replay the U-Net evaluations from a captured hipGraph (measured equal to eager launches at both resolutions once the timed region carries no event pairs: the step is GPU-bound)")
     ap.add_argument("--pipeline-ddim-steps", type=int, default=50, help="pipeline: DDIM steps per video")
     ap.add_argument("--pipeline-videos", type=int, default=1, help="pipeline: timed videos")
     ap.add_argument("--ae-frames", type=int, default=None, help="ddim_guided / config4: frames per VAE decoder forward/backward in the guided step (default 5; 1 = the reference's per-frame loop)")
@@ -449,7 +449,7 @@ def config4_run(args, dev, rank, world):
     a2.ddim_height, a2.ddim_width = 320, 448                 # the resolution train_guidedvd.py runs the video model at
     for i in range(20):
         train_iter(i)
-    ddim_run(a2, dev, rank, world, guided=True, steps=1, warm=1, cpu_leg_wanted=False, cache=cache)   # builds + warms the models
+    ddim_run(a2, dev, rank, world, guided=True, steps=1, warm=1, cpu_leg_wanted=False, cache=cache, instrument=False)   # builds + warms the models
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     it_ms, step_ms = [], []
@@ -461,7 +461,7 @@ def config4_run(args, dev, rank, world):
             train_iter(r * args.c4_iters + i)
         torch.cuda.synchronize()
         it_ms.append(1e3 * (time.perf_counter() - t0) / args.c4_iters)
-        d = ddim_run(a2, dev, rank, world, guided=True, steps=args.c4_ddim_steps, warm=0, cpu_leg_wanted=False, cache=cache)
+        d = ddim_run(a2, dev, rank, world, guided=True, steps=args.c4_ddim_steps, warm=0, cpu_leg_wanted=False, cache=cache, instrument=False)
         step_ms.append(d["ms_per_step"])
     torch.cuda.synchronize()
     wall = time.perf_counter() - t_all
@@ -629,7 +629,7 @@ def _init_dist(dist, torch, local_rank):
         dist.init_process_group(backend=backend)
 
 
-def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=None):
+def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=None, instrument=True):
     """BASELINE configs[2]: ViewCrafter 25-frame DDIM (unguided: 2 U-Net forwards + fused update per step),
     random-init U-Net with the zero-init modules re-randomised (SURVEY 7 'random-init U-Net is degenerate'),
     fp16 weights/activations with fp32 GroupNorm statistics and fp32 sampler math, synthetic conditioning.
@@ -707,7 +707,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     sampler.batch_cfg = bool(args.batch_cfg)
     if guided and args.ae_frames:
         sampler.decode_group = args.ae_frames
-    sampler.graph_apply = bool(args.graph)
+    sampler.graph_apply = bool(args.graph) and (not guided) and world == 1 and not args.batch_cfg
     plan = None
     if world > 1:
         from lvdm_amd.parallel import ParallelPlan
@@ -778,18 +778,33 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
                         ("gemm", bt, xx.shape[-2], ww.shape[-2], xx.shape[-1], bool(kw.get("geglu")), kw.get("row_stats") is not None, kw.get("residual") is not None)))
         return o
 
-    ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
+    # ---- timed region: the product path, nothing else on the stream (no per-kernel event pairs) ----
     t0 = time.perf_counter()
-    try:
-        for i in range(steps):
-            x = one(warm + i, x)
+    for i in range(steps):
+        x = one(warm + i, x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0
+    # ---- instrumented pass (same process, same inputs, right after the timed region): eager launches with a HIP event pair around
+    #      every convolution / GEMM / attention launch -> the three rooflines.  Kept out of the timed region: ~1100 launches + 2200
+    #      event records per step cost the step ~4 % and the graph-replay path has no per-kernel host call to bracket. ----
+    n_inst = min(steps, 3 if guided else 10) if instrument else 0
+    graph_was = sampler.graph_apply
+    sampler.graph_apply = False
+    ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
+    xi = x
+    t1 = time.perf_counter()
+    try:
+        for i in range(n_inst):
+            xi = one(warm + steps + i, xi)
+        torch.cuda.synchronize()
+        el_inst = max(time.perf_counter() - t1, 1e-9)
     finally:
         ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = orig_attn, orig_conv, orig_gemm
+        sampler.graph_apply = graph_was
+    assert torch.isfinite(xi).all()
     assert torch.isfinite(x).all()
     if world > 1:  # max over ranks
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -806,8 +821,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
             return None
         ach = fl / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "launches": len(evs), "ms_per_step": round(ms / steps, 2),
-                "alg_tflop_per_step": round(fl / steps / 1e12, 2)}
+                "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "launches": len(evs), "ms_per_step": round(ms / n_inst, 2),
+                "alg_tflop_per_step": round(fl / n_inst / 1e12, 2)}
 
     r_conv = roof(ev_conv, "k_conv_mfma (3x3 / upsample / temporal implicit-GEMM convolutions, fused GroupNorm+SiLU prologue)")
     r_attn = roof(ev_attn, "k_attn_fwd (all spatial / cross / temporal attention launches)")
@@ -819,7 +834,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
             r[0] += 1
             r[1] += e[0].elapsed_time(e[1])
             r[2] += e[2]
-        rows = sorted(({"shape": list(k), "launches_per_step": v[0] / steps, "ms_per_step": round(v[1] / steps, 3),
+        rows = sorted(({"shape": list(k), "launches_per_step": v[0] / n_inst, "ms_per_step": round(v[1] / n_inst, 3),
                         "avg_us": round(1e3 * v[1] / v[0], 1), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in agg.items()),
                       key=lambda r_: -r_["ms_per_step"])
         with open(os.environ["GVD_BENCH_SHAPE_TABLE"], "w") as fh:
@@ -847,24 +862,10 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
     }
-    if not guided and world == 1 and not args.graph and not args.batch_cfg:
-        # the same steps with the two U-Net evaluations replayed from a captured hipGraph (lvdm_amd/graphs.py: sampler.graph_apply)
-        # and no per-kernel event pairs: what the ~1100 launches + 2200 event records per step cost the eager, instrumented line
-        sampler.graph_apply = True
-        try:
-            for i in range(2):
-                x = one(i, x)
-            torch.cuda.synchronize()
-            n_g = min(steps, 10)
-            t0 = time.perf_counter()
-            for i in range(n_g):
-                x = one(2 + i, x)
-            torch.cuda.synchronize()
-            el_g = time.perf_counter() - t0
-            line["graph_replay"] = {"value": round(n_g / el_g, 4), "unit": "steps/s", "steps": n_g, "ms_per_step": round(1e3 * el_g / n_g, 2),
-                                    "what": "U-Net evaluations replayed from a hipGraph, no per-kernel events (not the headline)"}
-        finally:
-            sampler.graph_apply = False
+    line["launch_path"] = "hipGraph replay of the two U-Net evaluations per step (DDIMSampler.graph_apply)" if sampler.graph_apply else "eager launches"
+    line["instrumented_pass"] = None if not n_inst else {"steps": n_inst, "ms_per_step": round(1e3 * el_inst / n_inst, 2),
+                                                     "what": "the same steps launched eagerly with a HIP event pair around every convolution / GEMM / attention launch, "
+                                                             "right after the timed region: source of the three roofline objects (not the headline)"}
     if cpu_leg_wanted and unet_tflop and world == 1:
         line["cpu_baseline"] = ddim_cpu_leg(unet, T, unet_tflop, guided)
     return line

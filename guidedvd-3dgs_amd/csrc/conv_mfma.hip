@@ -522,6 +522,38 @@ __global__ void __launch_bounds__(256) k_gn_coef2(const double* __restrict__ sta
     coef[i] = make_float2(a, beta[c] - (float)mean * a);
 }
 
+// k_gn_merge + k_gn_coef2 in one launch (the unsharded case): one wave per (sample, group) sums the replicas / merged samples in the
+// order k_gn_merge does (lane-strided, then the same butterfly), writes the two sums, and lanes 0 .. cpg-1 (strided) form the affine
+// of the group's channels.  A U-Net forward has ~110 norms fed this way: one ~4 us launch each instead of two.
+__global__ void __launch_bounds__(64) k_gn_merge_coef(const double* __restrict__ partial, double* __restrict__ stats, int R, int Nin, int merge,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float2* __restrict__ coef,
+                                                      int C, int G, long long S, float eps)
+{
+    const int lane = threadIdx.x, g = blockIdx.x % G, nout = blockIdx.x / G, cpg = C / G;
+    double s0 = 0.0, s1 = 0.0;
+    for (int j = lane; j < R * merge; j += 64) {
+        const int r = j / merge, m = j - r * merge;
+        const double* p = partial + (((size_t)r * Nin + (size_t)nout * merge + m) * G + g) * 2;
+        s0 += p[0];
+        s1 += p[1];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); }
+    if (lane == 0) {
+        stats[2 * ((size_t)nout * G + g)] = s0;
+        stats[2 * ((size_t)nout * G + g) + 1] = s1;
+    }
+    const double cnt = (double)cpg * (double)S;
+    const double mean = s0 / cnt;
+    const double var = s1 / cnt - mean * mean;
+    const float rstd = rsqrtf((float)(var > 0 ? var : 0) + eps);
+    for (int k = lane; k < cpg; k += 64) {
+        const int c = g * cpg + k;
+        const float a = rstd * gamma[c];
+        coef[(size_t)nout * C + c] = make_float2(a, beta[c] - (float)mean * a);
+    }
+}
+
 // (Measured alternative, not kept: staging the weight slabs with LDS-DMA (global_load_lds) instead of through registers was
 //  within +-3 % on every U-Net / VAE shape -- two workgroups per CU already cover the ds_write pass.)
 
@@ -707,12 +739,14 @@ int gvd_group_norm_coef(double* stats, const double* partial, int replicas, int 
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!stats || !gamma || !beta || N <= 0 || C <= 0 || G <= 0 || C % G || S_total <= 0) return fail(-1, "gvd_group_norm_coef: bad arguments");
+    float2* coef = reinterpret_cast<float2*>(stats + (size_t)N * G * 2);
     if (partial) {
         if (replicas <= 0 || merge <= 0) return fail(-1, "gvd_group_norm_coef: bad replica / merge counts");
-        const int total = N * G * 2;
-        hipLaunchKernelGGL(k_gn_merge, dim3((total + 3) / 4), dim3(256), 0, stream, partial, stats, replicas, N * merge, merge, G, total);
+        hipLaunchKernelGGL(k_gn_merge_coef, dim3(N * G), dim3(64), 0, stream, partial, stats, replicas, N * merge, merge, gamma, beta, coef, C, G, S_total, eps);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(-2, "launch k_gn_merge_coef", e);
+        return 0;
     }
-    float2* coef = reinterpret_cast<float2*>(stats + (size_t)N * G * 2);
     hipLaunchKernelGGL(k_gn_coef2, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const double*)stats, gamma, beta, coef, N, C, G, S_total, eps);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_coef", e);

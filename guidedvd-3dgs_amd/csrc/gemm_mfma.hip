@@ -421,21 +421,25 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
     }
 }
 
-// (mean, rstd) of every row of x [M, C] (16-bit), LayerNorm's biased variance; one wave per row, the row held in registers.
-template <typename T>
+// (mean, rstd) of every row of x [M, C] (16-bit), LayerNorm's biased variance, the row held in registers (mean first, then the
+// centred sum of squares).  G lanes share a row (G = 8 for C <= 512 ... 64 for C <= 4096; every lane owns up to 8 16-byte chunks,
+// chunk o = sub + G i), so a wave covers 64 / G rows: at C = 320 one wave per row left 24 of 64 lanes idle and paid two 6-step
+// reductions for 640 bytes (64 us for the 230 400 rows of a level-0 activation; this form moves the same bytes in ~35).
+template <typename T, int G>
 __global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ x, float2* __restrict__ out, long long M, int C, long long ldx, float eps)
 {
     typedef typename Tr<T>::vec8 vec8;
-    const int lane = threadIdx.x & 63, oct = C >> 3;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const T* xr = x + row * ldx;
-    constexpr int MAXV = 8;                                  // C <= 64 * 8 * 8 = 4096
+    constexpr int RPW = 64 / G;                               // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1), oct = C >> 3;
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
+    const bool live = row < M;
+    const T* xr = x + (live ? row : 0) * ldx;
+    constexpr int MAXV = 8;                                  // C <= G * 8 * 8
     vec8 v[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; i++) {
-        const int o = lane + 64 * i;
+        const int o = sub + G * i;
         v[i] = vec8{};
         if (o < oct) {
             v[i] = *reinterpret_cast<const vec8*>(xr + o * 8);
@@ -444,19 +448,19 @@ __global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ x, floa
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    for (int d = G / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; i++) {
-        if (lane + 64 * i < oct) {
+        if (sub + G * i < oct) {
 #pragma unroll
             for (int k = 0; k < 8; k++) { const float d = (float)v[i][k] - mean; q = fmaf(d, d, q); }
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
-    if (lane == 0) out[row] = make_float2(mean, rsqrtf(q / (float)C + eps));
+    for (int d = G / 2; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+    if (live && sub == 0) out[row] = make_float2(mean, rsqrtf(q / (float)C + eps));
 }
 
 // ---- row kernels of the wide-head attention (ae_modules.py:26-78 as chunked GEMMs, lvdm_amd/wide_attention.py) ----
@@ -649,9 +653,14 @@ int gvd_row_stats(const void* x, long long ldx, float* stats, long long M, int C
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !stats || M <= 0 || C <= 0 || (C & 7) || C > 4096 || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)stats & 7))
         return fail(-1, "gvd_row_stats: C must be a multiple of 8 and <= 4096, pointers aligned");
-    const unsigned blocks = (unsigned)((M + 3) / 4);
-    if (is_bf16) hipLaunchKernelGGL(k_row_stats<__bf16>, dim3(blocks), dim3(256), 0, stream, (const __bf16*)x, reinterpret_cast<float2*>(stats), M, C, ldx, eps);
-    else hipLaunchKernelGGL(k_row_stats<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)x, reinterpret_cast<float2*>(stats), M, C, ldx, eps);
+    const int G = C <= 512 ? 8 : C <= 1024 ? 16 : C <= 2048 ? 32 : 64;
+    const long long rows_per_block = 4 * (64 / G);
+    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+#define GVD_RS(T, GG) hipLaunchKernelGGL((k_row_stats<T, GG>), dim3(blocks), dim3(256), 0, stream, (const T*)x, reinterpret_cast<float2*>(stats), M, C, ldx, eps)
+#define GVD_RS_T(T) do { if (G == 8) GVD_RS(T, 8); else if (G == 16) GVD_RS(T, 16); else if (G == 32) GVD_RS(T, 32); else GVD_RS(T, 64); } while (0)
+    if (is_bf16) GVD_RS_T(__bf16); else GVD_RS_T(_Float16);
+#undef GVD_RS_T
+#undef GVD_RS
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_row_stats", e);
     return 0;

@@ -144,6 +144,31 @@ def norm_state(gn, x=None, partial=None, n_stat=None, merge=1, group=None, S_tot
     return NormState(buf, N, C, G, S, gn.eps, g32, group)
 
 
+class _ZeroArena:
+    """Zeroed fp64 scratch for the statistics accumulators of the convolution epilogues.  Every statistics-producing launch needs its
+    own zeroed [replicas, samples, groups, 2] block (~110 per U-Net forward, 0.5-200 KB each); a `torch.zeros` per launch is a ~4 us
+    fill kernel in front of every convolution.  Blocks are carved from an 8 MB tensor zeroed by ONE fill and never handed out twice
+    (the tensor dies with its last block), so the zeroing costs one launch per ~40 convolutions."""
+    WORDS = 1 << 20
+    _cur = {}
+
+    @classmethod
+    def take(cls, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 15) & ~15                                  # 128-byte granules
+        # (inside a hipGraph capture the fill must belong to the graph that uses the block: no sharing across captures)
+        if n_al > cls.WORDS // 4 or (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            return torch.zeros(shape, dtype=torch.float64, device=device)
+        key = (device.type, device.index, torch.cuda.current_stream(device).stream_id if device.type == "cuda" else 0)
+        buf, used = cls._cur.get(key, (None, cls.WORDS))
+        if used + n_al > cls.WORDS:
+            buf, used = torch.zeros(cls.WORDS, dtype=torch.float64, device=device), 0
+        cls._cur[key] = (buf, used + n_al)
+        return buf[used:used + n].view(shape)
+
+
 def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, silu=False, bias=None, add_nc=None,
             residual=None, stats_groups=0, upsample=0, H_in=0, W_in=0, norm_bwd=None):
     """One launch of the convolution kernel.  norm_bwd = (norm_x, NormState, silu): this is an input-gradient launch whose
@@ -154,7 +179,7 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
     sums = None
     if stats_groups:
         n_stat = 1 if mode == TEMPORAL else N
-        sums = torch.zeros(STATS_REPLICAS, n_stat, stats_groups, 2, dtype=torch.float64, device=x.device)
+        sums = _ZeroArena.take((STATS_REPLICAS, n_stat, stats_groups, 2), x.device)
     if norm_bwd is not None:
         nx, ns, nsilu = norm_bwd
         with ops._on(x.device):

@@ -193,9 +193,26 @@ class DDIMSamplerGuidance(DDIMSampler):
     """ddim_guidance.py: the guided step differentiates pred_x0 w.r.t. x_t through BOTH U-Net evaluations
     and back-propagates the per-frame decoder-space loss gradient (Algorithm 1, L11-L13 of the paper)."""
 
-    #: frames per VAE decoder forward/backward inside the guided step (1 = the reference's loop; each frame's saved decoder
-    #: activations are ~4 GB at 576x1024, so 5 adds ~16 GB to the step's peak and fills the chip on the 72x128 / 144x256 stages)
-    decode_group = 5
+    #: frames per VAE decoder forward/backward inside the guided step (1 = the reference's per-frame loop).  None = chosen from the
+    #: latent size: a frame's saved decoder activations are ~4 GB at 72x128 latents (576x1024) and scale with the pixel count, and
+    #: the groups are the fewest equal ones that keep them under `decode_budget_gb` -- 5 frames at 576x1024 (fills the chip on the
+    #: 72x128 / 144x256 stages; +16 GB), all 25 in one pass at the 320x448 train_guidedvd.py runs (344 -> 330 ms per guided step)
+    decode_group = None
+    decode_budget_gb = 25.0
+
+    def _decode_group(self, n_frames, h, w, device):
+        fixed = getattr(self, "decode_group", None)
+        if fixed:
+            return max(1, int(fixed))
+        per_frame = 4.0 * 2 ** 30 * (h * w) / (72.0 * 128.0)
+        budget = float(self.decode_budget_gb) * 2 ** 30
+        if device.type == "cuda":
+            free, _ = torch.cuda.mem_get_info(device)
+            cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)   # the allocator's own free blocks
+            budget = min(budget, 0.5 * (free + cached))
+        gmax = max(1, int(budget // per_frame))
+        n_groups = -(-n_frames // gmax)
+        return -(-n_frames // n_groups)
 
     def _grad_ctx(self):
         return torch.enable_grad()
@@ -257,7 +274,7 @@ class DDIMSamplerGuidance(DDIMSampler):
             n_frames = pred_x0.shape[2]
             grads, decoded = [], []
             f_lo, f_hi = (0, n_frames) if plan is None else plan.frame_owner_slices(n_frames)[:2]
-            group = max(1, int(getattr(self, "decode_group", 1) or 1))
+            group = self._decode_group(f_hi - f_lo, pred_x0.shape[3], pred_x0.shape[4], pred_x0.device)
             for f0 in range(f_lo, f_hi, group):
                 f1 = min(f0 + group, f_hi)
                 z = pred_x0[:, :, f0:f1].clone().detach().requires_grad_(True)

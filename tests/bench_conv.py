@@ -42,12 +42,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-miopen", action="store_true")
+    ap.add_argument("--temporal-only", action="store_true")
     args = ap.parse_args()
     from lvdm_amd import conv as C, ops
     dev = "cuda:0"
     torch.backends.cudnn.benchmark = True
     g = torch.Generator(device=dev).manual_seed(0)
-    shapes = UNET[:4] if args.quick else UNET + VAE
+    shapes = [] if args.temporal_only else UNET[:4] if args.quick else UNET + VAE
     for (N, H, W, Cin, Cout) in shapes:
         x = torch.randn(N, H, W, Cin, device=dev, generator=g).half()
         m = nn.Conv2d(Cin, Cout, 3, padding=1).to(dev).half()
@@ -84,10 +85,13 @@ def main():
             t0 = timeit(lambda: C.fused_conv(x, m, mode=C.TEMPORAL))
             ns = C.norm_state(gn, x=x, n_stat=1)
             t1 = timeit(lambda: C.fused_conv(x, m, mode=C.TEMPORAL, gn=gn, norm=ns, silu=True, residual=x, stats_groups=32))
+            tp = timeit(lambda: C.fused_conv(x, m, mode=C.TEMPORAL, gn=gn, norm=ns, silu=True))
+            tr = timeit(lambda: C.fused_conv(x, m, mode=C.TEMPORAL, residual=x))
+            ts = timeit(lambda: C.fused_conv(x, m, mode=C.TEMPORAL, stats_groups=32))
             from lvdm_amd.unet import TemporalConvBlock
             taps = m.weight[:, :, :, 0, 0].permute(2, 0, 1).contiguous()
             t2 = timeit(lambda: TemporalConvBlock._temporal_gemm(x[None], taps, m.bias))
-        print(f"temporal T={T} P={Pp} C={Cc}: ours {t0 * 1e3:8.1f} us {flops / t0 / 1e9:7.1f} TF | fused prologue/residual/stats {t1 * 1e3:8.1f} us | 3 hipBLASLt GEMMs {t2 * 1e3:8.1f} us {flops / t2 / 1e9:7.1f} TF",
+        print(f"temporal T={T} P={Pp} C={Cc}: ours {t0 * 1e3:8.1f} us {flops / t0 / 1e9:7.1f} TF | fused prologue/residual/stats {t1 * 1e3:8.1f} us (prologue only {tp * 1e3:.1f}, residual only {tr * 1e3:.1f}, stats only {ts * 1e3:.1f}) | 3 hipBLASLt GEMMs {t2 * 1e3:8.1f} us {flops / t2 / 1e9:7.1f} TF",
               flush=True)
 
 

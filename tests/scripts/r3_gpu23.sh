@@ -1,5 +1,7 @@
-python -m pytest "tests/test_guided_schedule.py::test_raster_rank_and_diffusion_rank_on_one_gpu_match_the_single_process_run" -m gpu -x -q 2>&1 | grep -v "Gloo\|^$" | tail -70 > gpurun_out/r3_t2a.log
-python -m pytest tests/test_raster_gpu.py tests/test_raster_fuzz_gpu.py -m gpu -q 2>&1 | tail -15 > gpurun_out/r3_t2b.log
-python -m pytest tests/test_diffusion_parity_bars_gpu.py -m gpu -q -s 2>&1 | grep -v "^$" | tail -40 > gpurun_out/r3_t2c.log
-python -m pytest tests/test_gemm_gpu.py -m gpu -q -x 2>&1 | tail -25 > gpurun_out/r3_t3a.log
-python tests/bench_gemm.py > gpurun_out/r3_gemm_bench.txt 2>&1
+for af in 5 13 25; do
+python bench.py --workload ddim_guided --ddim-height 320 --ddim-width 448 --steps 5 --warmup 2 --no-cpu-baseline --ae-frames $af > gpurun_out/r3_guided_320_af$af.json 2>> gpurun_out/r3_guided_320.err
+done
+python bench.py --workload ddim --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/r3_ddim_graph.json 2>> gpurun_out/r3_guided_320.err
+python bench.py --workload ddim --steps 20 --warmup 2 --no-cpu-baseline --eager > gpurun_out/r3_ddim_eager.json 2>> gpurun_out/r3_guided_320.err
+python bench.py --workload ddim --ddim-height 320 --ddim-width 448 --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/r3_ddim_320_graph.json 2>> gpurun_out/r3_guided_320.err
+python bench.py --workload ddim --ddim-height 320 --ddim-width 448 --steps 20 --warmup 2 --no-cpu-baseline --eager > gpurun_out/r3_ddim_320_eager.json 2>> gpurun_out/r3_guided_320.err

@@ -73,6 +73,21 @@ def test_layernorm_fold_equals_layernorm_then_linear(C, N):
     assert torch.allclose(st[:, 1], torch.rsqrt(x.float().var(1, unbiased=False) + ln.eps), rtol=2e-5)
 
 
+@pytest.mark.parametrize("C,M", [(8, 5), (64, 33), (320, 1501), (328, 97), (512, 64), (520, 31), (1024, 130), (1280, 77), (2048, 9), (4096, 3)])
+def test_row_stats_every_group_width_and_ragged_row_counts(C, M):
+    """gvd_row_stats: 8 / 16 / 32 / 64 lanes per row (C <= 512 / 1024 / 2048 / 4096), chunk counts that do not fill the last lane,
+    row counts that do not fill the last wave; a strided view (ld > C) reads the same rows."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(C * 7 + M)
+    wide = _mk(g, M, C + 24)
+    wide[: M // 3] += 4.0
+    for x in (wide[:, :C].contiguous(), wide[:, :C]):
+        st = gemm.row_stats(x, 1e-5)
+        assert st.shape == (M, 2)
+        assert torch.allclose(st[:, 0], x.float().mean(1), atol=2e-5)
+        assert torch.allclose(st[:, 1], torch.rsqrt(x.float().var(1, unbiased=False) + 1e-5), rtol=3e-5)
+
+
 @pytest.mark.parametrize("C", [320, 640, 64])
 def test_feed_forward_pair_geglu_and_residual(C):
     """attention.py:415-442 + the block's `+ x`: GEGLU(LN(x) W1^T + b1) as ONE launch, then W2 with the residual in its epilogue."""
