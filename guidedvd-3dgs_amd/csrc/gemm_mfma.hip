@@ -69,15 +69,23 @@ __device__ unsigned long long g_trace[1024];   // experiments: s_memtime stamps 
 #define GVD_STAMP(i) do { } while (0)
 #endif
 
-// exact-form GELU 0.5 g (1 + erf(g / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: far below the 16-bit rounding
-// of the result), ~12 instructions with v_exp / v_rcp instead of libdevice erff's ~40 -- the gate runs once per output element
+// exact-form GELU 0.5 g (1 + erf(g / sqrt 2)) written as  relu(g) - 0.5 |g| erfc(|g| / sqrt 2)  with erfc by Abramowitz-Stegun
+// 7.1.26 (erfc(x) = P(t) exp(-x^2), t = 1 / (1 + p x), |error| <= 1.5e-7: far below the 16-bit rounding of the result).  This form
+// needs no sign restore and no 1 +- erf (the negative tail is the product itself, not a cancellation), and the -0.5 rides in the
+// polynomial's coefficients: 11 plain VALU + v_rcp + v_exp per gate against ~40 for libdevice erff.  The gate runs once per output
+// element and, the two pipes of a SIMD being all but serial on this part, its instruction count is kernel time: the PMC pass of the
+// level-0 feed-forward GEMM showed VALU-active 0.44 against MFMA-busy 0.27 with the previous 14-instruction form plus three 16-bit
+// round trips per element (profiles/r03_mfma_pmc.json).
 __device__ __forceinline__ float gelu_erf(float g)
 {
-    const float x = fabsf(g) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float erf_abs = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
-    return 0.5f * g * (1.f + copysignf(erf_abs, g));
+    const float ag = fabsf(g);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ag, 1.f));
+    float q = fmaf(t, -0.5f * 1.061405429f, 0.5f * 1.453152027f);
+    q = fmaf(t, q, -0.5f * 1.421413741f);
+    q = fmaf(t, q, 0.5f * 0.284496736f);
+    q = fmaf(t, q, -0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * (g * g));   // exp(-x^2), x = |g| / sqrt 2
+    return fmaf(ag, (t * q) * e, fmaxf(g, 0.f));
 }
 
 // pack four fp32 values to 16 bit: (lo dword, hi dword)
@@ -351,9 +359,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
                     float o[8];
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
-                        const T av = (T)v[q], gv = (T)v[8 + q];          // rounded like the unfused pair (k_geglu)
-                        const T ge = (T)gelu_erf((float)gv);
-                        o[q] = (float)av * (float)ge;
+                        o[q] = v[q] * gelu_erf(v[8 + q]);   // fp32 through the gate: one rounding, at the store (the unfused pair rounds the projection and the gate first)
                     }
                     const uint4 w = make_uint4(Tr<T>::pack2(o[0], o[1]), Tr<T>::pack2(o[2], o[3]), Tr<T>::pack2(o[4], o[5]), Tr<T>::pack2(o[6], o[7]));
                     *reinterpret_cast<uint4*>(ep + r32 * EP_PITCH + (mi * 2 + hi) * 16) = w;

@@ -39,4 +39,20 @@ m3 = nn.Conv3d(320, 320, (3, 1, 1), padding=(1, 0, 0)).to(dev).half().requires_g
 with torch.no_grad():
     for _ in range(3):
         C.fused_conv(xt, m3, mode=C.TEMPORAL)
+del xt
+# the MFMA GEMM (csrc/gemm_mfma.hip) on three of the U-Net's Linear shapes: the level-0 feed-forward in (LayerNorm fold + GEGLU),
+# the level-0 attention out-projection with the residual add, the level-2 feed-forward in
+from lvdm_amd import gemm as Gm
+for (M, N, K, kind) in [(230400, 2560, 320, "geglu"), (230400, 320, 320, "residual"), (14400, 10240, 1280, "geglu"), (57600, 1920, 640, "ln")]:
+    xg = torch.randn(M, K, device=dev, generator=g).half()
+    lin = nn.Linear(K, N).to(dev).half().requires_grad_(False)
+    ln = nn.LayerNorm(K).to(dev).half().requires_grad_(False)
+    with torch.no_grad():
+        for _ in range(3):
+            if kind == "geglu":
+                Gm.linear(xg, lin.weight, lin.bias, ln=ln, geglu=True)
+            elif kind == "ln":
+                Gm.linear(xg, lin.weight, lin.bias, ln=ln)
+            else:
+                Gm.linear(xg, lin.weight, lin.bias, residual=xg)
 torch.cuda.synchronize()

@@ -20,13 +20,19 @@ def rows_of(d):
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(set))
 dur = collections.defaultdict(dict)
+GEMM_CASES = ["L0 ff-in 230400x2560x320 LN+GEGLU", "L0 out-proj 230400x320x320 +residual", "L2 ff-in 14400x10240x1280 LN+GEGLU", "L1 qkv 57600x1920x640 LN"]
 for rows in (rows_of(a_dir), rows_of(b_dir)):
+    # the persistent GEMM launches one grid for every shape: tell the cases of diff_kernels_one.py apart by launch order (3 each)
+    gemm_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "k_gemm_nt" in r["Kernel_Name"]})
+    gemm_case = {d: GEMM_CASES[min(i // 3, len(GEMM_CASES) - 1)] for i, d in enumerate(gemm_ids)}
     for r in rows:
         n = r["Kernel_Name"]
-        if "k_conv_mfma" not in n and "k_attn_fwd" not in n and "k_attn_bwd" not in n:
+        if "k_conv_mfma" not in n and "k_attn_fwd" not in n and "k_attn_bwd" not in n and "k_gemm_nt" not in n:
             continue
-        kind = "conv" if "k_conv_mfma" in n else ("attn_bwd_dkv" if "bwd_dkv" in n else ("attn_bwd_dq" if "bwd_dq" in n else "attn"))
-        key = kind + " " + n.split("ConvArgs")[0][-40:] + f" grid={r['Grid_Size']}"
+        kind = "conv" if "k_conv_mfma" in n else ("gemm" if "k_gemm_nt" in n else ("attn_bwd_dkv" if "bwd_dkv" in n else ("attn_bwd_dq" if "bwd_dq" in n else "attn")))
+        key = kind + " " + n.split("ConvArgs")[0].split("GemmArgs")[0][-40:] + f" grid={r['Grid_Size']}"
+        if kind == "gemm":
+            key = "gemm " + gemm_case[int(r["Dispatch_Id"])]
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[key][r["Counter_Name"]].add(r["Dispatch_Id"])
         if "Start_Timestamp" in r and r.get("End_Timestamp"):
