@@ -38,6 +38,10 @@
 
 #include "diffusion_common.h"
 
+#ifndef GVD_CONV_DBG
+#define GVD_CONV_DBG 0   // experiments only (tests/scripts/run_conv_lds_hunt.sh): 1 = no patch ds_writes in the loop, 2 = no weight ds_writes in the loop,
+#endif                   // 4 = no epilogue staging writes, 8 = no epilogue staging reads, 16 = no MFMA operand reads of the patch, 32 = ... of the weights
+
 using namespace gvdd;
 
 namespace {
@@ -161,7 +165,14 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     if (SPATIAL) npp = G_::NPP_MAX; else npp = (a.N + 2) * PB * 4;
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
-        const int q = tid + i * 256, pixel = q >> 2;
+        const int q = tid + i * 256;
+        int pixel = q >> 2;
+        // ds_write_b128 is serviced in groups of 8 contiguous lanes against 32 banks (MI355X_MICROARCH.md): a group writes the 4 slots
+        // of TWO patch pixels, and at the 80-byte pixel pitch neighbours p, p + 1 overlap by one slot mod 128 bytes (2-way: 86 % of the
+        // kernel's SQ_LDS_BANK_CONFLICT cycles, profiles/r03_conv_lds_hunt.txt).  Pixels p and p + 4 are 320 = 64 (mod 128) bytes
+        // apart -- disjoint halves of the bank window -- so within every full block of 16 patch pixels the lanes take them in the
+        // order 0 4 8 12 1 5 ...; the global reads stay 64 contiguous bytes per lane quad, the operand reads do not change.
+        if (((pixel >> 4) + 1) * 64 <= npp) pixel = (pixel & ~15) + ((pixel & 3) << 2) + ((pixel >> 2) & 3);
         goff[i] = -1;
         loff[i] = 0;
         if (q < npp) {
@@ -237,6 +248,9 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 }
             }
             if (!ok) v = vec8{};   // conv zero padding applies to the ACTIVATED tensor (and dummy reads are dropped here)
+#if GVD_CONV_DBG & 1
+            if (buf < 2 && v[0] == (T)123.456f)
+#endif
             *reinterpret_cast<vec8*>(pb + loff[i]) = v;
         }
     };
@@ -258,6 +272,9 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int q = tid + i * 256;
+#if GVD_CONV_DBG & 2
+            if (wreg[i][0] == (T)123.456f)
+#endif
             if (q < NWP) *reinterpret_cast<vec8*>(wbuf + buf * WBYTES + q * 16) = wreg[i];
         }
     };
@@ -309,9 +326,21 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         for (int ks = 0; ks < 2; ks++) {
             vec8 af[MI], bf[NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048);
+            for (int mi = 0; mi < MI; mi++) {
+#if GVD_CONV_DBG & 32
+                af[mi] = vec8{}; af[mi][0] = (T)(float)(it + mi);
+#else
+                af[mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048);
+#endif
+            }
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) bf[ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32);
+            for (int ni = 0; ni < NI; ni++) {
+#if GVD_CONV_DBG & 16
+                bf[ni] = vec8{}; bf[ni][0] = (T)(float)(it + ni);
+#else
+                bf[ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32);
+#endif
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -368,6 +397,9 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 for (int rg = 0; rg < 4; rg++) {
                     const int cl = (wm * MI + mi) * 32 + 8 * rg + 4 * hi;
                     const float4 v = make_float4(acc[mi][ni][4 * rg], acc[mi][ni][4 * rg + 1], acc[mi][ni][4 * rg + 2], acc[mi][ni][4 * rg + 3]);
+#if GVD_CONV_DBG & 4
+                    if (v.x == 123.456f)
+#endif
                     *reinterpret_cast<float4*>(ep + pl * EP_PITCH + cl * 4) = v;
                 }
             }
@@ -392,8 +424,12 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 // bytes apart (the same banks), so the upper eight read their halves in the opposite order: the 2-way conflict on
                 // these reads was the 16-33 % SQ_LDS_BANK_CONFLICT of the round-2 counters (the operand reads are conflict free)
                 const int sw = (oct >> 3) & 1;
+#if GVD_CONV_DBG & 8
+                const float4 va = make_float4((float)pl, 0.f, 1.f, 2.f), vb = va;
+#else
                 const float4 va = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 16 : 0));
                 const float4 vb = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 0 : 16));
+#endif
                 const float4 v0 = sw ? vb : va, v1 = sw ? va : vb;
                 float v[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
                 vec8 o;
