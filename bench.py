@@ -71,7 +71,8 @@ def main():
     ap.add_argument("--pipeline-ddim-steps", type=int, default=50, help="pipeline: DDIM steps per video")
     ap.add_argument("--pipeline-videos", type=int, default=1, help="pipeline: timed videos")
     ap.add_argument("--ae-frames", type=int, default=None, help="ddim_guided / config4: frames per VAE decoder forward/backward in the guided step (default 5; 1 = the reference's per-frame loop)")
-    ap.add_argument("--batch-cfg", action="store_true", help="ddim: evaluate cond/uncond as one batch-2 U-Net call")
+    ap.add_argument("--batch-cfg", action="store_true", help="ddim / ddim_guided: always evaluate cond/uncond as one batch-2 U-Net call (default: the sampler's rule -- batched up to 4096 latent pixels per frame, i.e. at 320x448, sequential at 576x1024)")
+    ap.add_argument("--no-batch-cfg", action="store_true", help="ddim / ddim_guided: always two sequential U-Net calls")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -704,7 +705,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     uc = {"c_crossattn": [torch.randn(1, 333, 1024, device=dev, generator=g).half()], "c_concat": cond["c_concat"]}
     sampler = DDIMSamplerGuidance(ld) if guided else DDIMSampler(ld)
     sampler.make_schedule(50, "uniform_trailing", 1.0)
-    sampler.batch_cfg = bool(args.batch_cfg)
+    sampler.batch_cfg = True if args.batch_cfg else (False if args.no_batch_cfg else None)
     if guided and args.ae_frames:
         sampler.decode_group = args.ae_frames
     sampler.graph_apply = bool(args.graph) and (not guided) and world == 1 and not args.batch_cfg

@@ -32,6 +32,40 @@ def _cat_cond(c, uc):
     return {k: [torch.cat([a, b], dim=0) for a, b in zip(c[k], uc[k])] for k in c}
 
 
+#: latent pixels per frame up to which `batch_cfg = None` (auto) evaluates the CFG pair as ONE batch-2 U-Net call.  Measured on one
+#: MI355X: at 40x56 latents (320x448, what train_guidedvd.py runs) the batch-2 call takes 80 ms against 93 ms for the two sequential
+#: ones (the per-frame problems are small: the larger grids fill the chip better and every weight is read once), at 72x128
+#: (576x1024) 263 against 259 ms.
+BATCH_CFG_MAX_PIXELS = 4096
+
+
+def _batched_pair(sampler, m, x, t, c, uc, kwargs):
+    """(e_cond, e_uncond) from one batch-2 evaluation (ddim.py:222-223 / ddim_guidance.py:262-263 make two sequential ones): every
+    layer is per-sample (GroupNorm statistics, attention, convolutions), so each half equals its own batch-1 call; under autograd
+    x receives the sum of both halves' gradients, as it does from the two calls."""
+    kw2 = {k_: (torch.cat([v_, v_]) if torch.is_tensor(v_) and v_.dim() >= 1 and v_.shape[0] == x.shape[0] else v_)
+           for k_, v_ in kwargs.items()}
+    e = m.apply_model(torch.cat([x, x]), torch.cat([t, t]), _cat_cond(c, uc), **kw2)
+    return e.chunk(2, dim=0)
+
+
+def _per_sample_model(m):
+    """True when `m.apply_model` is known to treat the samples of a batch independently: the wrapper around THIS package's U-Net
+    (GroupNorm statistics, attention and convolutions are per sample; openaimodel3d.py has no cross-sample layer).  A duck-typed
+    model from elsewhere may mix the batch (tests/pipeline_duck.py does, on purpose) and keeps the reference's two calls."""
+    from .unet import UNetModel
+    return isinstance(getattr(getattr(m, "model", None), "diffusion_model", None), UNetModel)
+
+
+def _wants_batched_pair(sampler, x, c, uc):
+    mode = getattr(sampler, "batch_cfg", None)
+    if mode is False or not _same_structure(c, uc):
+        return False
+    if mode:
+        return True
+    return x.is_cuda and x.shape[-1] * x.shape[-2] <= BATCH_CFG_MAX_PIXELS and _per_sample_model(sampler.model)
+
+
 class DDIMSampler(object):
     # "device": draw on the latent's device from its global generator (what the reference does on CUDA); "cpu": draw on the
     # CPU generator and move -- reproduces a CPU trajectory on the GPU (tests/test_diffusion_goldens_gpu.py).
@@ -160,15 +194,10 @@ class DDIMSampler(object):
             if plan is not None:
                 raise NotImplementedError("the multi-GPU plan partitions the CFG pair; run without a plan when CFG is off")
             e_cond, e_uncond = m.apply_model(x, t, c, **kwargs), None
-        elif plan is not None:
+        elif plan is not None and plan.world > 1:
             e_cond, e_uncond = plan.eval_cfg(m, x, t, c, unconditional_conditioning, **kwargs)
-        elif getattr(self, "batch_cfg", False) and _same_structure(c, unconditional_conditioning):
-            # one batch-2 evaluation instead of the reference's two sequential ones (ddim.py:222-223): every layer
-            # is per-sample (GroupNorm statistics, attention, convolutions), so each half equals its own batch-1 call
-            kw2 = {k_: (torch.cat([v_, v_]) if torch.is_tensor(v_) and v_.dim() >= 1 and v_.shape[0] == x.shape[0] else v_)
-                   for k_, v_ in kwargs.items()}
-            e = m.apply_model(torch.cat([x, x]), torch.cat([t, t]), _cat_cond(c, unconditional_conditioning), **kw2)
-            e_cond, e_uncond = e.chunk(2, dim=0)
+        elif not getattr(self, "graph_apply", False) and _wants_batched_pair(self, x, c, unconditional_conditioning):
+            e_cond, e_uncond = _batched_pair(self, m, x, t, c, unconditional_conditioning, kwargs)
         elif getattr(self, "graph_apply", False) and x.is_cuda and not torch.is_grad_enabled():
             # hipGraph replay of the two U-Net evaluations (graphs.py): same kernels, no per-launch host cost
             if getattr(self, "_graphed", None) is None or self._graphed.model is not m:
@@ -250,7 +279,11 @@ class DDIMSamplerGuidance(DDIMSampler):
         step_kw = {k_: v_ for k_, v_ in kwargs.items() if k_ != "loss_guidance_fn"}
         for _ in range(repeat):
             x = x.detach().requires_grad_(True)
-            if plan is None:
+            if plan is not None and plan.world == 1:
+                plan = None    # one rank, nothing partitioned: the local forms below (a one-rank plan would run the pair sequentially)
+            if plan is None and _wants_batched_pair(self, x, c, unconditional_conditioning):
+                e_cond, e_uncond = _batched_pair(self, m, x, t, c, unconditional_conditioning, step_kw)
+            elif plan is None:
                 e_cond = m.apply_model(x, t, c, **kwargs)
                 e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
             else:

@@ -219,8 +219,25 @@ def test_small_model_on_the_device_matches_its_cpu_reference_form_with_guidance(
         ref = run("cpu")
     finally:
         ops.use_reference_math(False)
+    batches = []
+    apply = model.apply_model
+    model.apply_model = lambda x, *a_, **k_: (batches.append(x.shape[0]), apply(x, *a_, **k_))[1]
     out = run("cuda:0")
     assert next(model.model.diffusion_model.parameters()).dtype == torch.float16      # converted once by _prepare_native
     assert out.shape == ref.shape == (1, 1, 3, T, H, W) and torch.isfinite(out).all()
     err = float((out - ref).abs().max() / ref.abs().max())
     assert err < 5e-2, err
+    # the CFG pair went through the U-Net as ONE batch-2 call per step (samplers.BATCH_CFG_MAX_PIXELS: small latents on a device,
+    # this package's U-Net); forced back to the reference's two sequential calls the video is the same up to fp16 rounding
+    assert batches == [2, 2, 2], batches
+    del batches[:]
+    samplers.DDIMSamplerGuidance.batch_cfg = False
+    try:
+        out_seq = run("cuda:0")
+    finally:
+        del samplers.DDIMSamplerGuidance.batch_cfg
+        model.apply_model = apply
+    assert batches == [1] * 6, batches
+    # (one evaluation agrees to 1.3e-3 forward / 1.6e-3 input gradient -- tests/scripts/r3_pair_probe.py: rounding level, the batch-2
+    #  launches tile differently -- and three guided steps at CFG 7.5 amplify that like they amplify the fp16-vs-fp32 difference above)
+    assert float((out - out_seq).abs().max() / out_seq.abs().max()) < 5e-2
