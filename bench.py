@@ -806,6 +806,24 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = orig_attn, orig_conv, orig_gemm
         sampler.graph_apply = graph_was
     assert torch.isfinite(xi).all()
+    if os.environ.get("GVD_BENCH_TORCH_PROFILE"):   # dev: where do the step's copy / fill / add / cat launches come from?  (op, first package frame) table
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            xi = one(warm + steps + n_inst, xi)
+            torch.cuda.synchronize()
+        want = ("aten::copy_", "aten::add", "aten::add_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::sum", "aten::index_select", "aten::gather")
+        agg = {}
+        for ev in prof.events():
+            if ev.name not in want:
+                continue
+            frames = [f for f in (ev.stack or []) if ("lvdm_amd" in f or "bench.py" in f or "lvdm/" in f) and "torch/" not in f]
+            key = (ev.name, frames[0].strip() if frames else "(autograd engine / no python frame)")
+            r = agg.setdefault(key, [0, 0.0])
+            r[0] += 1
+            r[1] += getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0)
+        with open(os.environ["GVD_BENCH_TORCH_PROFILE"], "w") as fh:
+            for (name, frame), (n_, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:80]:
+                fh.write(f"{us / 1e3:8.2f} ms  n={n_:5d}  {name:18s} {frame}\n")
     assert torch.isfinite(x).all()
     if world > 1:  # max over ranks
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)

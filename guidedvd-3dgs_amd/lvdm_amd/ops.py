@@ -131,49 +131,71 @@ class _FlashAttention(torch.autograd.Function):
 class _PackedSelfAttention(torch.autograd.Function):
     """Self-attention on a packed projection qkv [..., 3 C] (q | k | v column blocks, the output of ONE fused GEMM) under
     autograd: the forward reads the three blocks in place, the backward kernels write dq / dk / dv straight into the packed
-    gradient -- no slice copies going in, no zero-fill + scatter coming back (they were ~55 ms of a guided step)."""
+    gradient -- no slice copies going in, no zero-fill + scatter coming back (they were ~55 ms of a guided step).
+    A frame-major input may carry a leading sample dimension ([b, T, pixels, 3 C], the temporal transformer of a batched CFG pair):
+    the samples are separate launches INSIDE this node (a frame-major view cannot fold b into the pixel dimension), so the graph
+    has no per-sample select / stack nodes -- each of those was a zero-fill + copy of the whole packed gradient plus an accumulation."""
 
     @staticmethod
     def forward(ctx, qkv, heads, frame_major):
         qkv = qkv if (qkv.is_contiguous()) else qkv.contiguous()
         C = qkv.shape[-1] // 3
-        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-        out, lse = _hip_attention_fwd(q, k, v, heads, frame_major, want_lse=True)
-        ctx.save_for_backward(qkv, out, lse)
+        samples = [qkv[i] for i in range(qkv.shape[0])] if qkv.dim() == 4 else [qkv]
+        out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
+        lses = []
+        for i, s3 in enumerate(samples):
+            _, lse = _hip_attention_fwd(s3[..., :C], s3[..., C:2 * C], s3[..., 2 * C:], heads, frame_major, want_lse=True,
+                                        out=out[i] if qkv.dim() == 4 else out)
+            lses.append(lse)
+        ctx.save_for_backward(qkv, out, *lses)
         ctx.cfg = (heads, frame_major)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qkv, out, lse = ctx.saved_tensors
+        qkv, out, *lses = ctx.saved_tensors
         heads, frame_major = ctx.cfg
         g = g.contiguous()
         C = qkv.shape[-1] // 3
-        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         dqkv = torch.empty_like(qkv)
-        dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
-        B = q.shape[1] if frame_major else q.shape[0]
-        Nq = q.shape[0] if frame_major else q.shape[1]
-        d = C // heads
-        q_bs, q_rs = _view_strides(q, frame_major, B)
-        o_bs, o_rs = _view_strides(out, frame_major, B)
-        delta = torch.empty_like(lse)
+        four = qkv.dim() == 4
         LL, P = ctypes.c_longlong, ctypes.c_void_p
-        with _on(q.device):
-            rc = lib().gvd_attention_bwd_ex(P(q.data_ptr()), P(k.data_ptr()), P(v.data_ptr()), P(out.data_ptr()), P(g.data_ptr()),
-                                            P(lse.data_ptr()), P(delta.data_ptr()), P(dq.data_ptr()), P(dk.data_ptr()), P(dv.data_ptr()),
-                                            B, heads, Nq, Nq, d, ctypes.c_float(d ** -0.5), LL(q_bs), LL(q_rs), LL(q_bs), LL(q_rs),
-                                            LL(o_bs), LL(o_rs), 1 if q.dtype == torch.bfloat16 else 0, P(_stream()))
-        _check(rc)
+        for i, lse in enumerate(lses):
+            s3, d3, o3, g3 = (qkv[i], dqkv[i], out[i], g[i]) if four else (qkv, dqkv, out, g)
+            q, k, v = s3[..., :C], s3[..., C:2 * C], s3[..., 2 * C:]
+            dq, dk, dv = d3[..., :C], d3[..., C:2 * C], d3[..., 2 * C:]
+            B = q.shape[1] if frame_major else q.shape[0]
+            Nq = q.shape[0] if frame_major else q.shape[1]
+            d = C // heads
+            q_bs, q_rs = _view_strides(q, frame_major, B)
+            o_bs, o_rs = _view_strides(o3, frame_major, B)
+            delta = torch.empty_like(lse)
+            with _on(q.device):
+                rc = lib().gvd_attention_bwd_ex(P(q.data_ptr()), P(k.data_ptr()), P(v.data_ptr()), P(o3.data_ptr()), P(g3.data_ptr()),
+                                                P(lse.data_ptr()), P(delta.data_ptr()), P(dq.data_ptr()), P(dk.data_ptr()), P(dv.data_ptr()),
+                                                B, heads, Nq, Nq, d, ctypes.c_float(d ** -0.5), LL(q_bs), LL(q_rs), LL(q_bs), LL(q_rs),
+                                                LL(o_bs), LL(o_rs), 1 if q.dtype == torch.bfloat16 else 0, P(_stream()))
+            _check(rc)
         return dqkv, None, None
 
 
 def self_attention_packed(qkv, heads, frame_major=False):
-    """softmax(q k^T / sqrt(d)) v for q | k | v given as the column blocks of one tensor [B, N, 3 h d] (frame_major: [N, B, 3 h d])."""
+    """softmax(q k^T / sqrt(d)) v for q | k | v given as the column blocks of one tensor [B, N, 3 h d] (frame_major: [N, B, 3 h d], or
+    [b, N, B, 3 h d] -- b samples of a frame-major problem, e.g. the temporal attention of a batched CFG pair)."""
     C = qkv.shape[-1] // 3
     on_dev = _require_device(qkv, "attention")
-    if (on_dev and qkv.dtype in (torch.float16, torch.bfloat16) and C // heads == 64 and torch.is_grad_enabled() and qkv.requires_grad):
+    hip = on_dev and qkv.dtype in (torch.float16, torch.bfloat16) and C // heads == 64
+    if hip and torch.is_grad_enabled() and qkv.requires_grad:
         return _PackedSelfAttention.apply(qkv, heads, frame_major)
+    if qkv.dim() == 4:
+        if hip:
+            qc = qkv if qkv.is_contiguous() else qkv.contiguous()
+            out = torch.empty(qc.shape[:-1] + (C,), dtype=qc.dtype, device=qc.device)
+            for i in range(qc.shape[0]):
+                _hip_attention_fwd(qc[i][..., :C], qc[i][..., C:2 * C], qc[i][..., 2 * C:], heads, frame_major, out=out[i])
+            return out
+        return torch.stack([attention(qkv[i][..., :C], qkv[i][..., C:2 * C], qkv[i][..., 2 * C:], heads, frame_major)
+                            for i in range(qkv.shape[0])], 0)
     return attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, frame_major)
 
 
@@ -203,7 +225,7 @@ def _readable_in_place(t):
     return t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
 
 
-def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False, accum=None, accum_scale=1.0):
+def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False, accum=None, accum_scale=1.0, out=None):
     """q [B,Nq,C], k/v [B,Nk,C] (k/v with B = 1 are shared by all batch entries); with frame_major=True the tensors are
     [N, B, C] (sequence outermost: the T frames of B pixels).  q / k / v are read IN PLACE through their strides -- column blocks
     of a packed [.., q | k | v] projection, broadcast contexts -- as long as the channel dim is contiguous; k and v must share
@@ -220,7 +242,8 @@ def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False, accum=
         v = v.contiguous()
         k = k.contiguous()
         kv_bs, kv_rs = _view_strides(k, frame_major, B)
-    out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    if out is None:
+        out = torch.empty(q.shape, dtype=q.dtype, device=q.device)   # (out: a caller's dense [like q] slot, e.g. one sample of a batch)
     o_bs, o_rs = _view_strides(out, frame_major, B)
     if accum is not None:
         accum = accum.contiguous()

@@ -134,8 +134,7 @@ class CrossAttention(nn.Module):
             qkv = gemm.linear_cat(x, [self.to_q.weight, self.to_k.weight, self.to_v.weight], ln=norm)   # one launch, LayerNorm folded
             # q | k | v are read in place as column blocks (and, under autograd, their gradients written in place)
             if frame_major:  # x [b, T, pixels, C]: one T-long sequence per pixel, read in place
-                outs = [ops.self_attention_packed(qkv[i], self.heads, frame_major=True) for i in range(x.shape[0])]
-                out = outs[0][None] if len(outs) == 1 else torch.stack(outs, 0)   # b = 1 (the sampler's case): a view, not a copy
+                out = ops.self_attention_packed(qkv, self.heads, frame_major=True)   # [b, T, pixels, 3 C]: samples looped inside the op
             else:
                 out = ops.self_attention_packed(qkv, self.heads)
         else:
@@ -269,6 +268,20 @@ class TemporalTransformer(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # convolutional side (openaimodel3d.py)
 # ------------------------------------------------------------------------------------------------
+class _SplitSamples(torch.autograd.Function):
+    """[(b t), ...] -> b views [t, ...].  Under autograd plain slices would each bring a zero-fill of the WHOLE tensor, a copy of the
+    slice's gradient into it and an accumulation add between the b results; this node's backward is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, tok, b):
+        T = tok.shape[0] // b
+        return tuple(tok[i * T:(i + 1) * T] for i in range(b))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return torch.cat(grads, 0), None
+
+
 class TemporalConvBlock(nn.Module):
     """openaimodel3d.py:239-279: 4 x [GN32 -> SiLU -> (Dropout) -> Conv3d k=(3,1,1) pad (1,0,0)] + identity.
 
@@ -326,7 +339,8 @@ class TemporalConvBlock(nn.Module):
         else:
             T = bt // b
             group = total = None
-            samples = [tok[bi * T:(bi + 1) * T].reshape(T, hh * ww, c) for bi in range(b)]
+            samples = [tk.reshape(T, hh * ww, c) for tk in (_SplitSamples.apply(tok, b) if b > 1 and tok.requires_grad else
+                                                            [tok[bi * T:(bi + 1) * T] for bi in range(b)])]
         outs = []
         for x0 in samples:
             h, part = x0, (stats if b == 1 else None)
