@@ -377,6 +377,58 @@ def test_layer_norm_and_geglu_input_gradients_match_fp32_autograd(dtype, M, C):
     assert gh.shape == h.shape and float((gh.float() - rh).abs().max()) < tol * float(rh.abs().max())
 
 
+def test_batch_two_unet_evaluation_matches_two_single_sample_calls():
+    """The batched CFG pair (samplers._batched_pair): one batch-2 evaluation of the fp16 token-major U-Net against two batch-1
+    evaluations, forward and input gradient.  Every layer is per sample; the temporal attention loops the samples inside its autograd
+    node (ops._PackedSelfAttention on [b, T, pixels, 3 C]) and the temporal convolution blocks split them with one node
+    (unet._SplitSamples) -- so the graph has no per-sample select / slice / stack nodes.  Agreement is to fp16 rounding (the batch-2
+    launches tile differently), not bitwise."""
+    from lvdm_amd.model import DiffusionWrapper
+    from lvdm_amd.unet import UNetModel
+    cfg = dict(in_channels=8, out_channels=4, model_channels=64, attention_resolutions=[1, 2], num_res_blocks=1,
+               channel_mult=[1, 2], dropout=0.0, num_head_channels=64, transformer_depth=1, context_dim=64, use_linear=True,
+               use_checkpoint=False, temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
+               use_relative_position=False, use_causal_attention=False, temporal_length=16, addition_attention=True,
+               image_cross_attention=True, default_fs=10, fs_condition=True)
+    unet = fill_by_name(UNetModel(**cfg), std=0.08).half().eval().to(DEV).to_token_major()
+    unet.requires_grad_(False)
+    w = DiffusionWrapper(unet)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    mk = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    T, H, W = 5, 16, 24
+    x = mk(1, 4, T, H, W)
+    c = {"c_crossattn": [mk(1, 93, 64).half()], "c_concat": [(mk(1, 4, T, H, W) * 0.2).half()]}
+    uc = {"c_crossattn": [mk(1, 93, 64).half()], "c_concat": c["c_concat"]}
+    t, fs, probe = torch.tensor([500], device=DEV), torch.tensor([10], device=DEV), mk(1, 4, T, H, W)
+
+    def two_calls(xs):
+        return w(xs.half(), t, **c, fs=fs), w(xs.half(), t, **uc, fs=fs)
+
+    def one_call(xs):
+        cc = {k: [torch.cat([a, b]) for a, b in zip(c[k], uc[k])] for k in c}
+        return w(torch.cat([xs, xs]).half(), torch.cat([t, t]), **cc, fs=torch.cat([fs, fs])).chunk(2)
+
+    res = {}
+    for name, fn in (("two", two_calls), ("one", one_call)):
+        xs = x.clone().requires_grad_(True)
+        e1, e2 = fn(xs)
+        names, stack, seen = set(), [e1.grad_fn, e2.grad_fn], set()
+        while stack:
+            node = stack.pop()
+            if node is None or node in seen:
+                continue
+            seen.add(node)
+            names.add(type(node).__name__)
+            stack.extend(n_ for n_, _ in node.next_functions)
+        (gx,) = torch.autograd.grad((e1.float() * probe).sum() + 0.7 * (e2.float() * probe).sum(), xs)
+        res[name] = (e1.detach().float(), e2.detach().float(), gx.detach(), names)
+    assert not ({"SelectBackward0", "StackBackward0"} & res["one"][3]), res["one"][3]
+    assert "_SplitSamplesBackward" in res["one"][3] and "_SplitSamplesBackward" not in res["two"][3]
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(res["one"][0], res["two"][0]) < 4e-3 and rel(res["one"][1], res["two"][1]) < 4e-3
+    assert rel(res["one"][2], res["two"][2]) < 6e-3
+
+
 def test_graph_replayed_unet_evaluation_matches_eager():
     """DDIMSampler.graph_apply: the no-grad U-Net evaluations replayed from a captured hipGraph give the eager
     result, step after step (fresh inputs are copied into the static buffers), for both conditionings."""
