@@ -225,7 +225,9 @@ class DDIMSamplerGuidance(DDIMSampler):
     #: frames per VAE decoder forward/backward inside the guided step (1 = the reference's per-frame loop).  None = chosen from the
     #: latent size: a frame's saved decoder activations are ~4 GB at 72x128 latents (576x1024) and scale with the pixel count, and
     #: the groups are the fewest equal ones that keep them under `decode_budget_gb` -- 5 frames at 576x1024 (fills the chip on the
-    #: 72x128 / 144x256 stages; +16 GB), all 25 in one pass at the 320x448 train_guidedvd.py runs (344 -> 330 ms per guided step)
+    #: 72x128 / 144x256 stages; +16 GB), all 25 in one pass at the 320x448 train_guidedvd.py runs (344 -> 330 ms per guided step).
+    #: Measured around the rule: 576x1024 -- 2 / 3 / 4 / 5 frames 1196 / 1188 / 1193 / 1185 ms, 9 / 13 / 25 frames 1213 / 1333 / 1419 ms
+    #: (a group's saved activations past ~30 GB cost more than the fewer launches save); 320x448 -- 5 / 9 / 13 / 25 frames 299 / 289 / 289 / 287 ms
     decode_group = None
     decode_budget_gb = 25.0
 
