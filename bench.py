@@ -859,7 +859,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         with open(os.environ["GVD_BENCH_SHAPE_TABLE"], "w") as fh:
             json.dump({"legend": {"conv": ["conv", "mode (0 spatial, 1 temporal, 2 stride-2)", "N", "H", "W", "Cin", "Cout", "upsample"],
                                   "gemm": ["gemm", "batch", "M", "N", "K", "geglu", "layernorm_fold", "residual"]}, "rows": rows}, fh, indent=1)
-    dominant = r_conv if (r_conv and (not r_attn or r_conv["ms_per_step"] >= r_attn["ms_per_step"])) else r_attn
+    dominant = max((r for r in (r_conv, r_attn, r_gemm) if r), key=lambda r: r["ms_per_step"], default=None)   # the family with the most time per step
     unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
     line = {
         "metric": "viewcrafter_guided_ddim_steps_per_s" if guided else "viewcrafter_ddim_steps_per_s", "value": round(steps / elapsed, 4), "unit": "steps/s", "n_gpus": world,
