@@ -114,13 +114,18 @@ def _geglu_perm(n2, device):
 
 def _prepared(weights, biases, ln, geglu, dtype):
     """(W image [N, K] in `dtype`, bias / c vector fp32 [N] or None, col_sum fp32 [N] or None) for a list of Linear weights that
-    share their input: rows concatenated, LayerNorm `ln` folded in, GEGLU row order applied.  Cached on the first weight."""
+    share their input: rows concatenated, LayerNorm `ln` folded in, GEGLU row order applied.  Cached on the first weight, one
+    slot per VARIANT (which LayerNorm is folded in, GEGLU order or natural order, dtype): the Resampler's `to_kv` is used with two
+    different norms back to back (resampler.py:69) and a GEGLU projection is used in both row orders by the guided step (forward:
+    GEGLU order; backward: the gate recompute in natural order) -- a single slot rebuilt the image on every one of those calls."""
     w0 = weights[0]
-    key = (tuple(_tag(w) for w in weights), tuple(_tag(b) for b in biases), None if ln is None else (_tag(ln.weight), _tag(ln.bias)),
-           bool(geglu), dtype)
+    variant = (None if ln is None else (id(ln.weight), id(ln.bias)), bool(geglu), dtype, len(weights))
+    key = (tuple(_tag(w) for w in weights), tuple(_tag(b) for b in biases), None if ln is None else (_tag(ln.weight), _tag(ln.bias)))
     cache = getattr(w0, "_gvd_gemm", None)
-    if cache is not None and cache[0] == key:
-        return cache[1]
+    if isinstance(cache, dict):
+        hit = cache.get(variant)
+        if hit is not None and hit[0] == key:
+            return hit[1]
     with torch.no_grad():
         W = torch.cat([w.detach().reshape(w.shape[0], -1).float() for w in weights], dim=0)        # (1x1 conv weights flatten to [N, K])
         have_bias = any(b is not None for b in biases)
@@ -146,7 +151,11 @@ def _prepared(weights, biases, ln, geglu, dtype):
             Wd = F.pad(Wd, (0, pad))
         val = (Wd.contiguous(), None if c is None else c.contiguous(), None if s is None else s.contiguous())
     try:
-        w0._gvd_gemm = (key, val)
+        if not isinstance(cache, dict):
+            cache = w0._gvd_gemm = {}
+        if len(cache) >= 8:      # (a module rebuilt with fresh norm objects over and over: keep the table small)
+            cache.clear()
+        cache[variant] = (key, val)
     except AttributeError:
         pass
     return val
@@ -239,6 +248,25 @@ def _ln_kernel_ok(x, ln):
             and x.shape[-1] <= 2048 and not ln.weight.requires_grad and not ln.bias.requires_grad)
 
 
+def _padded8(weight, bias):
+    """Zero-padded [N8, K8] image (and bias) of a Linear / 1x1 convolution whose K or N is not a multiple of the GEMM's granule
+    of 8 -- the KL-VAE's `post_quant_conv` / `quant_conv` (4 -> 4 and 8 -> 8 channels, autoencoder.py:97-107).  Cached on the
+    weight until it is modified."""
+    tag = (_tag(weight), _tag(bias))
+    hit = getattr(weight, "_gvd_pad8", None)
+    if hit is None or hit[0] != tag:
+        with torch.no_grad():
+            W = weight.detach().reshape(weight.shape[0], -1)
+            W8 = F.pad(W, (0, (-W.shape[1]) % 8, 0, (-W.shape[0]) % 8)).contiguous()
+            b8 = None if bias is None else F.pad(bias.detach(), (0, (-bias.shape[0]) % 8)).contiguous()
+        hit = (tag, W8, b8)
+        try:
+            weight._gvd_pad8 = hit
+        except AttributeError:
+            pass
+    return hit[1], hit[2]
+
+
 def _hip_ok(x, weights):
     on_dev = ops._require_device(x, "linear")
     ok = on_dev and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0 and all(w.shape[0] % 8 == 0 for w in weights)
@@ -255,6 +283,14 @@ def linear(x, weight, bias=None, *, ln=None, residual=None, geglu=False):
     N = weight.shape[0]
     No = N // 2 if geglu else N
     lead = x.shape[:-1]
+    if (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (K % 8 or N % 8) and ln is None and residual is None and not geglu
+            and not weight.requires_grad and (bias is None or not bias.requires_grad)):
+        # narrow projections (K or N not a multiple of 8): zero-padded operands on the same MFMA GEMM; exact (the padding
+        # contributes zeros), and the only library convolution left on the guided path (MIOpen igemm for the VAE's 4 -> 4
+        # post_quant_conv) is gone with it
+        W8, b8 = _padded8(weight, bias)
+        xp = F.pad(x, (0, (-K) % 8)) if K % 8 else x
+        return linear(xp, W8, b8)[..., :N]
     if not _hip_ok(x, [weight]) or (geglu and N % 32):
         h = x if ln is None else F.layer_norm(x, (K,), ln.weight, ln.bias, ln.eps)
         y = F.linear(h, weight.reshape(N, -1).to(h.dtype), None if bias is None else bias.to(h.dtype))

@@ -291,16 +291,14 @@ def attention(q, k, v, heads, frame_major=False, accum=None, accum_scale=1.0):
             o = _FlashAttention.apply(q, k, v, heads, frame_major)
             return o if accum is None else accum + accum_scale * o
         return _hip_attention_fwd(q, k, v, heads, frame_major, accum=accum, accum_scale=accum_scale)
-    if on_dev and heads == 1 and not frame_major and accum is None:
-        from . import wide_attention      # single wide head (the VAE's d = 512 mid block): chunked MFMA GEMMs + row kernels
-        if wide_attention.supported(q, k, v):
-            return wide_attention.attention(q, k, v)
-    # fp32 tensors (parity tests) and shapes neither kernel family covers
+    if on_dev and q.dtype in (torch.float16, torch.bfloat16) and k.dtype == q.dtype and v.dtype == q.dtype and not _REFERENCE_MATH:
+        # every other 16-bit shape: one wide head (the VAE's d = 512 mid block) or heads of a width other than 64 (the reference's
+        # num_heads-style U-Net configurations: d = 40 / 80 / 160) -- chunked MFMA GEMMs + row kernels, any token count
+        from . import wide_attention
+        o = wide_attention.attention_heads(q, k, v, heads, frame_major)
+        return o if accum is None else accum + accum_scale * o
+    # fp32 tensors (the parity runs): the explicit form
     if on_dev:
-        if q.dtype in (torch.float16, torch.bfloat16) and not _REFERENCE_MATH:
-            raise RuntimeError(f"lvdm_amd.ops.attention: no kernel for 16-bit inputs with {heads} head(s) of {d} channels, Nq = "
-                               f"{q.shape[0 if frame_major else 1]}, Nk = {k.shape[0 if frame_major else 1]} (d = 64 heads: any "
-                               "shape; one wide head: d a multiple of 8, <= 16376 tokens)")
         _torch_form("attention", f"dtype {q.dtype}, head dim {d} (the MFMA kernels cover 16-bit inputs)")
     if k.shape[0 if not frame_major else 1] != q.shape[0 if not frame_major else 1]:
         bd = 1 if frame_major else 0

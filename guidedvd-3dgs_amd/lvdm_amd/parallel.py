@@ -143,6 +143,16 @@ def pixels_to_frames(t, shard, P):
     return torch.cat(blocks, dim=1)
 
 
+def plan_seed(user_seed, n_built):
+    """Replicated-noise seed of the `n_built`-th plan of a process whose torch seed is `user_seed` (splitmix64 finaliser over
+    the pair): a function of the user's seed only, never equal to it."""
+    m = (1 << 64) - 1
+    z = (int(user_seed) + (int(n_built) + 1) * 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return (z ^ (z >> 31)) % (1 << 63)
+
+
 class ParallelPlan:
     """cfg x frames layout over an initialised default process group, or over a SUB-GROUP of it.
 
@@ -191,11 +201,13 @@ class ParallelPlan:
         # The latent x is replicated: every rank must draw the same x_T / per-step noise whatever its own RNG state is.
         # One seed broadcast from the plan's first rank; the samplers draw from plan.generator(device).  The seed is that
         # rank's torch seed (torch.manual_seed / seed_everything, as the reference's ViewCrafter driver sets it --
-        # viewcrafter_wrapper.py:253-262), so user seeding governs the multi-GPU run exactly as it governs the single-GPU one:
-        # the first plan of a process draws the very stream a seeded single-GPU sampler draws from the device's global
-        # generator.  Later plans of the same process get a different (still seed-determined) stream.  `reseed()` is the
+        # viewcrafter_wrapper.py:253-262), so user seeding governs the multi-GPU run exactly as it governs the single-GPU one
+        # (same seed, same videos; a different seed, different videos).  The seed is passed through a fixed mix, for the first
+        # plan too: a generator seeded with initial_seed() itself would REPEAT the device generator's Philox stream from offset
+        # 0, so any earlier global draw of the same size (the VAE posterior sample of encode_first_stage, which runs before
+        # the sampler) would be value-identical to x_T.  Every plan of a process gets its own stream.  `reseed()` is the
         # explicit override.
-        seed = [(torch.initial_seed() + n_built * 0x9E3779B97F4A7C15) % (1 << 63) if rank == 0 else 0]
+        seed = [plan_seed(torch.initial_seed(), n_built) if rank == 0 else 0]
         dist.broadcast_object_list(seed, src=ranks[0], group=self.world_group)
         self.seed = int(seed[0])
 

@@ -232,9 +232,21 @@ class DDIMSamplerGuidance(DDIMSampler):
     decode_budget_gb = 25.0
 
     def _decode_group(self, n_frames, h, w, device):
+        """Chosen ONCE per (frames, latent size, device) and kept on the sampler: the grouping decides launch shapes and the order
+        of the GroupNorm statistics' fp64 atomics, so it must not follow the allocator's state from step to step (same seed, same
+        grouping, same result), and a driver memory query per guided step is a host stall.  The 4 GB per frame at 72x128 latents
+        are the saved decoder activations of the ViewCrafter KL-VAE (ch 128, ch_mult [1, 2, 4, 4], 2 blocks per level, fp16,
+        measured); they scale with the pixel count."""
         fixed = getattr(self, "decode_group", None)
         if fixed:
             return max(1, int(fixed))
+        key = (int(n_frames), int(h), int(w), str(device), float(self.decode_budget_gb))
+        cache = self.__dict__.setdefault("_decode_group_cache", {})
+        if key not in cache:
+            cache[key] = self._choose_decode_group(n_frames, h, w, device)
+        return cache[key]
+
+    def _choose_decode_group(self, n_frames, h, w, device):
         per_frame = 4.0 * 2 ** 30 * (h * w) / (72.0 * 128.0)
         budget = float(self.decode_budget_gb) * 2 ** 30
         if device.type == "cuda":

@@ -147,8 +147,11 @@ class CrossAttention(nn.Module):
                     out = out + s * ops.attention(q, k_ip, v_ip, self.heads) * (torch.tanh(self.alpha) + 1)
                 else:   # out + s * out_ip in the second attention's epilogue
                     out = ops.attention(q, k_ip, v_ip, self.heads, accum=out, accum_scale=float(s))
-        lo = self.to_out[0]
-        return self.to_out[1](gemm.linear(out, lo.weight, lo.bias, residual=residual))
+        lo, drop = self.to_out[0], self.to_out[1]
+        if residual is not None and drop.training and drop.p > 0:
+            # the reference drops the projection, not the residual stream: dropout(linear(out)) + x (attention.py:144, :241-244)
+            return drop(gemm.linear(out, lo.weight, lo.bias)) + residual
+        return gemm.linear(out, lo.weight, lo.bias, residual=residual)   # eval / p = 0: dropout is the identity, `+ x` in the epilogue
 
 
 class LayerNorm(nn.LayerNorm):

@@ -296,12 +296,20 @@ class AutoencoderKLDecoder(nn.Module):
     def encode(self, x, **kwargs):
         if not hasattr(self, "encoder"):
             raise RuntimeError("AutoencoderKLDecoder was built without the encoder (with_encoder=True)")
-        return DiagonalGaussianDistribution(self.quant_conv(self.encoder(x)))
+        return DiagonalGaussianDistribution(self._conv1x1(self.quant_conv, self.encoder(x)))
+
+    def _conv1x1(self, conv, z):
+        """A 1x1 convolution (`post_quant_conv` 4 -> 4, `quant_conv` 8 -> 8; autoencoder.py:97-107) as a per-token projection on
+        the MFMA GEMM (channels padded to its granule of 8) -- on the 16-bit device path no library convolution is called."""
+        if z.is_cuda and z.dtype in (torch.float16, torch.bfloat16) and z.dtype == conv.weight.dtype and not conv.weight.requires_grad:
+            y = gemm.linear(z.permute(0, 2, 3, 1), conv.weight, conv.bias).permute(0, 3, 1, 2)     # token rows [N, H, W, C]
+            return y.contiguous(memory_format=torch.channels_last) if self._token_major else y.contiguous()
+        return conv(z)
 
     def decode(self, z, **kwargs):
         if self._token_major:
             z = z.contiguous(memory_format=torch.channels_last)
-        return self.decoder(self.post_quant_conv(z))
+        return self.decoder(self._conv1x1(self.post_quant_conv, z))
 
     #: frames per decoder / encoder call under `perframe_ae` (None: as many as fit the bounds below)
     PERFRAME_GROUP_MAX = 32

@@ -51,13 +51,29 @@ def _inplace_ok(t):
     return t.stride(-1) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
 
 
-def _forward(q, k, v, want_lse):
+MAX_ROW = 16384          # keys per softmax row (gvd_softmax_rows keeps a row in registers); longer rows go in key chunks
+
+
+def _forward(q, k, v, want_lse, scale=None):
     """q [B, Nq, d], k / v [B, Nk, d] (token counts already multiples of 8 where it matters); nk_valid keys are real."""
     B, Nq, d = q.shape
+    scale = d ** -0.5 if scale is None else float(scale)
+    if k.shape[1] > MAX_ROW:
+        # more keys than one softmax row holds (a 1024 x 1024 image is exactly 16384 tokens and still takes the single-row path;
+        # anything above runs per key chunk and the chunks' normalised outputs are merged with their log-sum-exps in fp32)
+        outs, lses = [], []
+        for n0 in range(0, k.shape[1], MAX_ROW):
+            o_c, l_c = _forward(q, k[:, n0:n0 + MAX_ROW], v[:, n0:n0 + MAX_ROW], True, scale)
+            outs.append(o_c.float())
+            lses.append(l_c)
+        L = torch.stack(lses)                                       # [chunks, B, Nq]
+        lse = torch.logsumexp(L, dim=0)
+        w = torch.exp(L - lse).unsqueeze(-1)
+        out = sum(w[i] * outs[i] for i in range(len(outs))).to(q.dtype)
+        return out, (lse if want_lse else None)
     nk_valid = k.shape[1]
     k, v = _pad_tokens(k), _pad_tokens(v)
     Nk = k.shape[1]
-    scale = d ** -0.5
     vT = v.transpose(1, 2).contiguous()                    # [B, d, Nk]: the second product's W operand (K-contiguous)
     out = torch.empty((B, Nq, d), dtype=q.dtype, device=q.device)
     lse = torch.empty(B, Nq, dtype=torch.float32, device=q.device) if want_lse else None
@@ -74,10 +90,11 @@ def _forward(q, k, v, want_lse):
 
 class _WideAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, scale=None):
         q, k, v = (t if _inplace_ok(t) else t.contiguous() for t in (q, k, v))
-        out, lse = _forward(q, k, v, True)
+        out, lse = _forward(q, k, v, True, scale)
         ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale = scale
         return out
 
     @staticmethod
@@ -85,7 +102,7 @@ class _WideAttention(torch.autograd.Function):
         q, k, v, out, lse = ctx.saved_tensors
         B, nq_valid, d = q.shape
         nk_valid = k.shape[1]
-        scale = d ** -0.5
+        scale = d ** -0.5 if ctx.scale is None else float(ctx.scale)
         delta = (g.float() * out.float()).sum(-1)           # [B, Nq]
         # token counts to multiples of 8: padded keys are masked by n_valid, padded queries by lse = +inf (P = 0 there)
         q, g, k, v = _pad_tokens(q), _pad_tokens(g.contiguous()), _pad_tokens(k), _pad_tokens(v)
@@ -111,18 +128,44 @@ class _WideAttention(torch.autograd.Function):
             _ds_(St, dPt, lse, delta, Nq, n1 - n0, True)
             gemm.gemm_nt(St, gT, out=dv[:, n0:n1])          # P^T dO
             gemm.gemm_nt(dPt, qT, alpha=scale, out=dk[:, n0:n1])
-        return dq[:, :nq_valid], dk[:, :nk_valid], dv[:, :nk_valid]
+        return dq[:, :nq_valid], dk[:, :nk_valid], dv[:, :nk_valid], None
 
 
 def supported(q, k, v):
+    """Any token count (rows longer than MAX_ROW keys run in key chunks; the backward's element kernel has no row limit)."""
     d = q.shape[-1]
     return (q.is_cuda and q.dtype in (torch.float16, torch.bfloat16) and k.dtype == q.dtype and v.dtype == q.dtype and q.dim() == 3
-            and d % 8 == 0 and k.shape[1] <= 16376 and q.shape[1] <= 16376)
+            and d % 8 == 0)
 
 
-def attention(q, k, v):
-    """softmax(q k^T / sqrt(d)) v, one head.  q [B, Nq, d], k / v [B, Nk, d], 16-bit on a ROCm device; d a multiple of 8."""
+def attention(q, k, v, scale=None):
+    """softmax(q k^T * scale) v, one head (scale: 1 / sqrt(d) by default).  q [B, Nq, d], k / v [B, Nk, d], 16-bit on a ROCm
+    device; d a multiple of 8."""
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
-        return _WideAttention.apply(q, k, v)
+        return _WideAttention.apply(q, k, v, scale)
     q, k, v = (t if _inplace_ok(t) else t.contiguous() for t in (q, k, v))
-    return _forward(q, k, v, False)[0]
+    return _forward(q, k, v, False, scale)[0]
+
+
+def attention_heads(q, k, v, heads, frame_major=False):
+    """Every 16-bit shape the d = 64 flash kernels do not cover: `heads` heads of any width (the reference's `num_heads`-style
+    U-Net configurations have d = 40 / 80 / 160, openaimodel3d.py:404-412) as `B * heads` single-head problems on the chunked
+    GEMM path -- head channels split out (one copy per operand), padded with zero channels to the GEMM's K granule of 8 (the
+    softmax scale stays 1 / sqrt(d) of the true width).  q [B, Nq, h*d], k / v [B or 1, Nk, h*d]; frame_major: [N, B, h*d]."""
+    if frame_major:
+        q, k, v = (t.transpose(0, 1) for t in (q, k, v))
+    B, Nq, C = q.shape
+    d = C // heads
+    if k.shape[0] != B:
+        k, v = k.expand(B, -1, -1), v.expand(B, -1, -1)
+    if heads == 1 and d % 8 == 0:
+        o = attention(q, k, v)
+    else:
+        pad = (-d) % 8
+
+        def split(t):
+            t = t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(B * heads, t.shape[1], d)
+            return F.pad(t, (0, pad)) if pad else t.contiguous()
+        o = attention(split(q), split(k), split(v), scale=d ** -0.5)[..., :d]
+        o = o.reshape(B, heads, Nq, d).permute(0, 2, 1, 3).reshape(B, Nq, C)
+    return o.transpose(0, 1) if frame_major else o

@@ -104,16 +104,17 @@ def _worker(rank, world, cfg, port, q):
         sr.parallel = plan
         for _ in range(3):
             plan.check_replicated(sr._randn((1, 4, T, HL, WL), torch.device("cpu")), "sampler noise under a plan")
-        # user seeding governs (advisor finding, round 2): the first plan of a process draws the stream a seeded single-process
-        # sampler draws from the global generator -- rank 0's torch.manual_seed (here the 0 of _build()) -- and a later plan
-        # follows rank 0's seed too, whatever the other ranks were seeded with
-        assert plan.seed == 0, plan.seed
+        # user seeding governs (advisor finding, round 2): every plan's stream is a function of rank 0's torch.manual_seed (here
+        # the 0 of _build()), whatever the other ranks were seeded with -- but never the global generator's own stream (advisor
+        # finding, round 3: seeded with initial_seed() itself, x_T would repeat an earlier global draw of the same size, e.g. the
+        # VAE posterior sample of encode_first_stage)
+        assert plan.seed == parallel.plan_seed(0, 0) and plan.seed not in (0, 1000 + rank), plan.seed
         first = torch.randn((1, 4, T, HL, WL), generator=torch.Generator().manual_seed(plan.seed))
         torch.manual_seed(0)
-        assert torch.equal(first, torch.randn((1, 4, T, HL, WL)))
+        assert not torch.equal(first, torch.randn((1, 4, T, HL, WL)))
         torch.manual_seed(777 + 13 * rank)
         plan2 = parallel.ParallelPlan(T, cfg=cfg)
-        assert plan2.seed == (777 + 0x9E3779B97F4A7C15) % (1 << 63), plan2.seed
+        assert plan2.seed == parallel.plan_seed(777, 1) != parallel.plan_seed(777, 0), plan2.seed
         plan2.check_replicated(torch.randn((5, 7), generator=plan2.generator("cpu")), "second plan's noise")
         # the guidance term must actually be exercised: guided != plain
         moved = float((ref["guided_xprev"] - ref["plain_xprev"]).abs().max())

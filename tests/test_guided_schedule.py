@@ -288,7 +288,7 @@ def test_config4_co_residency_leaves_the_raster_loop_bit_identical():
     assert mem1 < 120.0
 
 
-def _gpu_worker(rank, world, port, deliver_after, q):
+def _gpu_worker(rank, world, port, deliver_after, q, layout="disjoint", cfg=1, T=T):
     try:
         import torch.distributed as dist
         import guided_schedule as gs
@@ -301,8 +301,8 @@ def _gpu_worker(rank, world, port, deliver_after, q):
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ["MASTER_PORT"] = str(port)
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        roles = gs.Roles.split("disjoint")
-        plan = parallel.ParallelPlan(T, cfg=1, ranks=roles.diffusion_ranks) if world > 1 else None
+        roles = gs.Roles.split(layout)
+        plan = parallel.ParallelPlan(T, cfg=cfg, ranks=roles.diffusion_ranks) if world > 1 else None
         raster = diffusion = None
         sc, traj = _gpu_scene(P=20_000)
         traj = traj[:T]
@@ -330,6 +330,8 @@ def _gpu_worker(rank, world, port, deliver_after, q):
         sched = gs.GuidedSchedule(roles, spec, (T, 3, 2 * HL, 2 * WL), dev, cadence=4, deliver_after=deliver_after)
         sched.run(9, raster=raster, diffusion=diffusion)
         out = {"events": sched.events, "role": (roles.is_raster, roles.is_diffusion)}
+        if plan is not None and plan.member:
+            out["plan"] = (plan.cfg, plan.F, plan.shard.counts[plan.shard.rank])
         if raster is not None:
             out["state"] = {k: v.cpu() for k, v in raster.state().items()}
             out["frames"] = torch.stack([f for _, f in raster.pseudo]).cpu()
@@ -377,3 +379,70 @@ def test_raster_rank_and_diffusion_rank_on_one_gpu_match_the_single_process_run(
     for k, v in ref["state"].items():
         scale = float(v.abs().max())
         assert float((two[0]["state"][k] - v).abs().max()) <= 1e-3 * scale, k
+
+
+
+def _run_gpu_ranks(world, deliver_after, layout="disjoint", cfg=1, n_frames=T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, deliver_after, q, layout, cfg, n_frames)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=1500) for _ in procs]
+    for p in procs:
+        p.join(timeout=180)
+    for _, out in res:
+        assert "exception" not in out, out["exception"]
+    for p in procs:
+        assert p.exitcode == 0
+    return {r: _from_value(o) for r, o in res}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,cfg,deliver_after", [("disjoint", 1, 2), ("shared", 2, 0)])
+def test_config5_eight_ranks_on_one_gpu_with_hip_kernels(layout, cfg, deliver_after):
+    """BASELINE configs[4] (train_guidedvd.py:83,101,521-549 placement; SURVEY 8e "Config 5") ON THE HIP PATH: eight processes on
+    the one GPU the test box has, gloo carrying every collective (the group / role / hand-off code is the RCCL run's).
+
+    disjoint: ranks 0-3 run the REAL rasterizer (replicated training loop; the guidance renders of a run sharded per view over
+    the four ranks with one all-gather), ranks 4-7 run the guided sampler on the fp16 HIP miniature as cfg 1 x 4 frame shards
+    (all-to-all around the temporal layers, two-phase GroupNorm, latent all-gather); raster leader -> diffusion group and
+    diffusion leader -> raster group hand-offs; D = 2.  shared: all eight ranks hold both roles -- diffusion as cfg 2 x frames 4,
+    raster replicated on eight ranks, guidance renders sharded eight ways (three ranks own no view) -- the layout DESIGN section 9
+    expects to be the faster use of an 8-GPU node; D = 0.
+
+    Against the same schedule in ONE process: identical event order on every raster rank; generated frames to fp16-kernel
+    reproducibility across different launch tilings (frame shards change which rows share a workgroup; bar 5e-3 of the [0, 1] range; the
+    measured figure is printed); Gaussians to what those frames imply; raster replicas BIT-IDENTICAL to each other."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    n_frames = T if layout == "disjoint" else 9      # shared: the decodes of a guided step are split over all 8 ranks (>= 1 frame each)
+    ref = _run_gpu_ranks(1, deliver_after, n_frames=n_frames)[0]
+    res = _run_gpu_ranks(8, deliver_after, layout, cfg, n_frames)
+    rasters = [r for r in sorted(res) if res[r]["role"][0]]
+    diffusers = [r for r in sorted(res) if res[r]["role"][1]]
+    if layout == "disjoint":
+        assert rasters == [0, 1, 2, 3] and diffusers == [4, 5, 6, 7]
+        for r in diffusers:
+            assert res[r]["events"] == [("generate", 1), ("generate", 5), ("generate", 9)]
+            assert res[r]["plan"][:2] == (1, 4)
+    else:
+        assert rasters == diffusers == list(range(8))
+        for r in diffusers:
+            assert res[r]["plan"][:2] == (2, 4)
+    assert sorted(res[r]["plan"][2] for r in diffusers[:4]) == ([1, 1, 1, 2] if n_frames == 5 else [2, 2, 2, 3])   # uneven frame shards
+    expect = [("trigger", 1), ("deliver", 1), ("trigger", 5), ("deliver", 5), ("trigger", 9), ("deliver", 9)]
+    assert ref["events"] == expect
+    worst = 0.0
+    for r in rasters:
+        out = res[r]
+        assert [e for e in out["events"] if e[0] != "generate"] == expect, (r, out["events"])
+        err = float((out["frames"] - ref["frames"]).abs().max())
+        worst = max(worst, err)
+        assert err < 5e-3, (r, err)
+        for k, v in ref["state"].items():
+            scale = float(v.abs().max())
+            assert float((out["state"][k] - v).abs().max()) <= 1e-3 * scale, (r, k)
+            assert torch.equal(out["state"][k], res[rasters[0]]["state"][k]), (r, k)    # replicas stay bit-identical
+    print(f"config5 on the HIP path ({layout}, cfg {cfg} x frames 4, D = {deliver_after}): frames max |diff| {worst:.2e} vs one process")

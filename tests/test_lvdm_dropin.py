@@ -169,8 +169,12 @@ def test_small_model_runs_the_reference_call_sequence_end_to_end():
 
 
 @pytest.mark.gpu
-def test_small_model_on_the_device_matches_its_cpu_reference_form_with_guidance():
-    """The same miniature class tree, built once, driven through `image_guided_synthesis` with the GUIDED lvdm sampler twice:
+def test_dropin_plumbing_on_the_device_agrees_with_the_packages_own_cpu_form():
+    """PLUMBING, not parity: a self-comparison of this package's two execution forms (the parity of the fp16 kernels against the
+    REFERENCE is tests/test_diffusion_parity_bars_gpu.py, test_diffusion_goldens_gpu.py and, over ten DDIM steps,
+    test_diffusion_trajectory_gpu.py).  What it pins: the drop-in class tree converts itself for the device (`_prepare_native`),
+    the guided sampler, the grouped decode and the batch-2 CFG pair are wired as on the CPU, and nothing is lost on the way.
+    The same miniature class tree, built once, driven through `image_guided_synthesis` with the GUIDED lvdm sampler twice:
     on the CPU with the reference formulation of every operator (fp32) and on the GPU through the product path
     (`_prepare_native`: fp16 token-major U-Net and VAE, MFMA convolutions with fused norms, flash attention at the 64-wide heads,
     grouped VAE decode + backward inside the step).  Same noise (drawn on the CPU generator), so the two videos agree to the
