@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_coef(const double* __restrict__ 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_gn_bwd_apply_ncs(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+__global__ void __launch_bounds__(256) k_gn_bwd_apply_ncs(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, T* __restrict__ dx,
                                                           const float2* __restrict__ coef, const float2* __restrict__ coef2,
                                                           long long S, int silu, long long total)
 {
@@ -699,26 +699,27 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply_ncs(const T* __restrict__ 
         const float2 ab = coef[i / S], kk = coef2[i / S];
         if (vec) {
             const vec8 vx = *reinterpret_cast<const vec8*>(x + i), vg = *reinterpret_cast<const vec8*>(dy + i);
-            vec8 r;
+            vec8 r, va = vec8{};
+            if (add) va = *reinterpret_cast<const vec8*>(add + i);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const float xf = to_f(vx[k]);
                 float dz = to_f(vg[k]);
                 if (silu) dz *= silu_grad_f(fmaf(xf, ab.x, ab.y));
-                r[k] = (T)fmaf(ab.x, dz, fmaf(kk.y, xf, kk.x));
+                r[k] = (T)(fmaf(ab.x, dz, fmaf(kk.y, xf, kk.x)) + to_f(va[k]));
             }
             *reinterpret_cast<vec8*>(dx + i) = r;
         } else {
             const float xf = to_f(x[i]);
             float dz = to_f(dy[i]);
             if (silu) dz *= silu_grad_f(fmaf(xf, ab.x, ab.y));
-            dx[i] = (T)fmaf(ab.x, dz, fmaf(kk.y, xf, kk.x));
+            dx[i] = (T)(fmaf(ab.x, dz, fmaf(kk.y, xf, kk.x)) + (add ? to_f(add[i]) : 0.f));
         }
     }
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_gn_bwd_apply_nsc(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+__global__ void __launch_bounds__(256) k_gn_bwd_apply_nsc(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, T* __restrict__ dx,
                                                           const float2* __restrict__ coef, const float2* __restrict__ coef2,
                                                           int C, long long S, int silu, int rows_per_block)
 {
@@ -742,13 +743,14 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply_nsc(const T* __restrict__ 
         for (long long r = r0 + lane_row; r < r1; r += rstep) {
             const long long i = base + r * C + o * 8;
             const vec8 vx = *reinterpret_cast<const vec8*>(x + i), vg = *reinterpret_cast<const vec8*>(dy + i);
-            vec8 rr;
+            vec8 rr, va = vec8{};
+            if (add) va = *reinterpret_cast<const vec8*>(add + i);   // (uniform) gradient arriving along the residual branch, see k_layer_norm_bwd
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const float xf = to_f(vx[k]);
                 float dz = to_f(vg[k]);
                 if (silu) dz *= silu_grad_f(fmaf(xf, a[k], b[k]));
-                rr[k] = (T)fmaf(a[k], dz, fmaf(k1[k], xf, k0[k]));
+                rr[k] = (T)(fmaf(a[k], dz, fmaf(k1[k], xf, k0[k])) + to_f(va[k]));
             }
             *reinterpret_cast<vec8*>(dx + i) = rr;
         }
@@ -834,7 +836,7 @@ __global__ void __launch_bounds__(256) k_geglu(const T* __restrict__ h, T* __res
 // dx = rstd (g - mean(g) - x_hat mean(g x_hat)).  One wave per row, statistics recomputed from the row in registers.
 template <typename T>
 __global__ void __launch_bounds__(256) k_layer_norm_bwd(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ gamma,
-                                                        T* __restrict__ dx, long long M, int C, float eps)
+                                                        const T* __restrict__ add, T* __restrict__ dx, long long M, int C, float eps)
 {
     typedef typename Tr<T>::vec8 vec8;
     const int lane = threadIdx.x & 63, oct = C >> 3;
@@ -887,13 +889,17 @@ __global__ void __launch_bounds__(256) k_layer_norm_bwd(const T* __restrict__ x,
     for (int off = 32; off; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgx += __shfl_xor(sgx, off, 64); }
     const float mg = sg / (float)C, mgx = sgx / (float)C;
     T* dr = dx + row * C;
+    // `add`: the gradient that reaches the same tensor along the residual branch (x feeds LayerNorm -> ... and `+ x`): summed here in
+    // fp32, one rounding, instead of a separate accumulation kernel over the two 16-bit gradients (3 more passes over [M, C])
+    const T* ar = add ? add + row * C : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int o = lane + 64 * j;
         if (o < oct) {
-            vec8 r;
+            vec8 r, av = vec8{};
+            if (ar) av = *reinterpret_cast<const vec8*>(ar + o * 8);
 #pragma unroll
-            for (int k = 0; k < 8; k++) r[k] = (T)(rstd * (gg[j][k] - mg - (to_f(v[j][k]) - mean) * rstd * mgx));
+            for (int k = 0; k < 8; k++) r[k] = (T)(rstd * (gg[j][k] - mg - (to_f(v[j][k]) - mean) * rstd * mgx) + to_f(av[k]));
             *reinterpret_cast<vec8*>(dr + o * 8) = r;
         }
     }
@@ -1116,29 +1122,35 @@ int gvd_group_norm_bwd_stats(const void* x, const void* dy, const float* gamma, 
     return 0;
 }
 
-int gvd_group_norm_bwd_apply(const void* x, const void* dy, void* dx, const double* fwd_stats, double* scratch, int N, int C,
+int gvd_group_norm_bwd_apply_add(const void* x, const void* dy, const void* add, void* dx, const double* fwd_stats, double* scratch, int N, int C,
                              long long S, long long S_total, int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = gn_check("gvd_group_norm_bwd_apply", x, dy, N, C, S, G, channels_last)) return rc;
-    if (!dx || ((uintptr_t)dx & 15) || !fwd_stats || !scratch || S_total < S) return fail(-1, "gvd_group_norm_bwd_apply: bad arguments");
+    if (!dx || (((uintptr_t)dx | (uintptr_t)add) & 15) || !fwd_stats || !scratch || S_total < S) return fail(-1, "gvd_group_norm_bwd_apply: bad arguments");
     const float2* coef = reinterpret_cast<const float2*>(fwd_stats + (size_t)N * G * 2);
     float2* coef2 = reinterpret_cast<float2*>(scratch + (size_t)N * G * 2);
     const long long total = (long long)N * C * S;
     const int ablocks = gn_apply_blocks(N, C, S, channels_last);
     hipLaunchKernelGGL(k_gn_bwd_coef, dim3((N * C + 255) / 256), dim3(256), 0, stream, fwd_stats, (const double*)scratch, coef2, N, C, G, S_total, eps);
     if (!channels_last) {
-        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, coef, (const float2*)coef2, S, silu, total);
-        else hipLaunchKernelGGL(k_gn_bwd_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)dx, coef, (const float2*)coef2, S, silu, total);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_ncs<__bf16>, dim3(ablocks), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (const __bf16*)add, (__bf16*)dx, coef, (const float2*)coef2, S, silu, total);
+        else hipLaunchKernelGGL(k_gn_bwd_apply_ncs<_Float16>, dim3(ablocks), dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (const _Float16*)add, (_Float16*)dx, coef, (const float2*)coef2, S, silu, total);
     } else {
         const int rows = gn_rows_per_block(N, S);
         dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
-        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_nsc<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, coef, (const float2*)coef2, C, S, silu, rows);
-        else hipLaunchKernelGGL(k_gn_bwd_apply_nsc<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)dx, coef, (const float2*)coef2, C, S, silu, rows);
+        if (is_bf16) hipLaunchKernelGGL(k_gn_bwd_apply_nsc<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (const __bf16*)add, (__bf16*)dx, coef, (const float2*)coef2, C, S, silu, rows);
+        else hipLaunchKernelGGL(k_gn_bwd_apply_nsc<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (const _Float16*)add, (_Float16*)dx, coef, (const float2*)coef2, C, S, silu, rows);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_bwd_apply_*", e);
     return 0;
+}
+
+int gvd_group_norm_bwd_apply(const void* x, const void* dy, void* dx, const double* fwd_stats, double* scratch, int N, int C,
+                             long long S, long long S_total, int G, float eps, int silu, int channels_last, int is_bf16, void* stream_)
+{
+    return gvd_group_norm_bwd_apply_add(x, dy, nullptr, dx, fwd_stats, scratch, N, C, S, S_total, G, eps, silu, channels_last, is_bf16, stream_);
 }
 
 int gvd_group_norm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const double* fwd_stats, double* scratch,
@@ -1176,18 +1188,24 @@ int gvd_geglu(const void* h, void* y, long long M, int C, int is_bf16, void* str
     return 0;
 }
 
-int gvd_layer_norm_bwd(const void* x, const void* dy, const void* gamma, void* dx, long long M, int C, float eps, int is_bf16,
-                       void* stream_)
+int gvd_layer_norm_bwd_add(const void* x, const void* dy, const void* gamma, const void* add, void* dx, long long M, int C, float eps,
+                           int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !dy || !gamma || !dx || M <= 0 || C <= 0 || (C % 8) || C > 2048) return fail(-1, "gvd_layer_norm_bwd: bad arguments (C % 8 == 0, C <= 2048)");
-    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx) & 15) return fail(-1, "gvd_layer_norm_bwd: pointers must be 16-byte aligned");
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)add) & 15) return fail(-1, "gvd_layer_norm_bwd: pointers must be 16-byte aligned");
     const dim3 grid((unsigned)((M + 3) / 4));
-    if (is_bf16) hipLaunchKernelGGL(k_layer_norm_bwd<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (const __bf16*)gamma, (__bf16*)dx, M, C, eps);
-    else hipLaunchKernelGGL(k_layer_norm_bwd<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (const _Float16*)gamma, (_Float16*)dx, M, C, eps);
+    if (is_bf16) hipLaunchKernelGGL(k_layer_norm_bwd<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (const __bf16*)gamma, (const __bf16*)add, (__bf16*)dx, M, C, eps);
+    else hipLaunchKernelGGL(k_layer_norm_bwd<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (const _Float16*)gamma, (const _Float16*)add, (_Float16*)dx, M, C, eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_layer_norm_bwd", e);
     return 0;
+}
+
+int gvd_layer_norm_bwd(const void* x, const void* dy, const void* gamma, void* dx, long long M, int C, float eps, int is_bf16,
+                       void* stream_)
+{
+    return gvd_layer_norm_bwd_add(x, dy, gamma, nullptr, dx, M, C, eps, is_bf16, stream_);
 }
 
 int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, int is_bf16, void* stream_)

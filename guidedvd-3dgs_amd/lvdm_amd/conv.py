@@ -207,9 +207,10 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
 FUSE_NORM_BACKWARD_STATS = os.environ.get("GVD_FUSE_NORM_BWD", "1") == "1"   # 0: separate statistics pass (k_gn_bwd_stats_*), for A/B runs and tests
 
 
-def _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cg, Cn):
+def _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cg, Cn, add=None):
     """gx = d/dx of conv(act(GroupNorm(x))) given g = d/d(conv output): the input-gradient convolution with the GroupNorm-backward
-    statistics in its epilogue (gvd_conv_mfma_norm_bwd), the replica merge, (sharded norms: a 2 G-double all-reduce) and the apply pass."""
+    statistics in its epilogue (gvd_conv_mfma_norm_bwd), the replica merge, (sharded norms: a 2 G-double all-reduce) and the apply pass.
+    add: the gradient x receives along a residual branch (ops.GradCell), summed in by the apply kernel."""
     P, LL = ctypes.c_void_p, ctypes.c_longlong
     x = x.contiguous()
     dev, bf = x.device, 1 if x.dtype == torch.bfloat16 else 0
@@ -227,9 +228,10 @@ def _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cg, Cn):
         if ns.group is not None:
             import torch.distributed as dist
             dist.all_reduce(scratch[:2 * ns.N * ns.G], group=ns.group)
-        ops._check(L.gvd_group_norm_bwd_apply(P(x.data_ptr()), P(d_act.data_ptr()), P(gx.data_ptr()), P(ns.buf.data_ptr()),
-                                              P(scratch.data_ptr()), ns.N, ns.C, LL(S), LL(ns.S if ns.group is not None else S), ns.G,
-                                              ctypes.c_float(ns.eps), int(bool(silu)), 1, bf, st))
+        ops._check(L.gvd_group_norm_bwd_apply_add(P(x.data_ptr()), P(d_act.data_ptr()), P(None if add is None else add.data_ptr()),
+                                                  P(gx.data_ptr()), P(ns.buf.data_ptr()), P(scratch.data_ptr()), ns.N, ns.C, LL(S),
+                                                  LL(ns.S if ns.group is not None else S), ns.G, ctypes.c_float(ns.eps),
+                                                  int(bool(silu)), 1, bf, st))
     return gx
 
 
@@ -270,9 +272,16 @@ class _FusedConvFn(torch.autograd.Function):
     """out = conv(act(x)) + bias + add_nc + residual; gradients w.r.t. x and residual only (weights frozen)."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, mode, upsample, ns, silu, add_nc, stats_groups):
+    def forward(ctx, x, residual, weight, bias, mode, upsample, ns, silu, add_nc, stats_groups, cells=(None, None)):
         out, part = _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, stats_groups)
         ctx.save_for_backward(x, weight)
+        # ops.GradCell hand-overs: grad_add is taken in backward and summed into d/dx by the GroupNorm-backward apply kernel;
+        # the residual's gradient goes into res_to (if its taker armed it) instead of to autograd's accumulation
+        grad_add, res_to = cells
+        if grad_add is not None:
+            grad_add.arm()
+        res_to = res_to if (res_to is not None and res_to.armed and residual is not None) else None
+        ctx.cells = (grad_add, res_to)
         ctx.cfg = (mode, upsample, ns, silu, residual is not None)
         ctx.mark_non_differentiable(*([] if part is None else [part.sums]))
         ctx.part = part
@@ -284,6 +293,12 @@ class _FusedConvFn(torch.autograd.Function):
         mode, upsample, ns, silu, has_res = ctx.cfg
         gout = gout.contiguous()
         gx = None
+        grad_add, res_to = ctx.cells
+        extra = None if grad_add is None else grad_add.take(like=x)
+        g_res = gout if has_res else None
+        if g_res is not None and res_to is not None and res_to.put(g_res):
+            g_res = None
+        tail = (None,) * 9
         if ctx.needs_input_grad[0]:
             N, H, W, Cin, H_in, W_in = _geometry(x, mode, upsample)
             Cout = weight.shape[0]
@@ -303,8 +318,8 @@ class _FusedConvFn(torch.autograd.Function):
                 wT = packed(weight, BN, True, pad, gout.dtype)
                 if ns is not None and not upsample and FUSE_NORM_BACKWARD_STATS:
                     # the GroupNorm-backward statistics come out of the input-gradient convolution's epilogue
-                    gx = _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cout + pad, Cin)
-                    return gx, (gout if has_res else None), None, None, None, None, None, None, None, None
+                    gx = _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cout + pad, Cin, add=extra)
+                    return (gx, g_res) + tail
                 d_act, _ = _launch(g, wT, Cin, mode, N, H, W, Cout + pad)
             if upsample:   # nearest x2 backward: each input pixel fed a 2x2 block
                 d_act = d_act.reshape(N, H // 2, 2, W // 2, 2, Cin).sum(dim=(2, 4))
@@ -313,8 +328,14 @@ class _FusedConvFn(torch.autograd.Function):
             else:
                 xs = x.reshape(ns.N, -1, ns.C)
                 gx = ops._hip_group_norm_bwd(xs, d_act.reshape(xs.shape), ns.gamma32, ns.buf, ns.G, ns.eps, silu, True,
-                                             ns.group, ns.S if ns.group is not None else None).reshape(x.shape)
-        return gx, (gout if has_res else None), None, None, None, None, None, None, None, None
+                                             ns.group, ns.S if ns.group is not None else None,
+                                             add=None if extra is None else extra.reshape(xs.shape)).reshape(x.shape)
+                extra = None
+            if extra is not None:
+                gx = gx + extra
+        elif extra is not None:
+            gx = extra
+        return (gx, g_res) + tail
 
 
 def _reference(x, weight, bias, mode, upsample, gn, silu, add_nc, residual, n_stat):
@@ -341,12 +362,14 @@ def _reference(x, weight, bias, mode, upsample, gn, silu, add_nc, residual, n_st
 
 
 def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_stat=None, silu=False, add_nc=None,
-               residual=None, stats_groups=0, group=None, S_total=None):
+               residual=None, stats_groups=0, group=None, S_total=None, grad_add=None, res_grad_to=None):
     """x token-major ([N, H, W, Cin] or, temporal, [T, pixels, Cin]); `conv` the nn.Conv2d(3x3, pad 1) / nn.Conv3d((3,1,1))
     module; mode STRIDE2 / STRIDE2_PAD_HI: the stride-2 Downsample convolutions of the U-Net / the VAE encoder.
     gn: GroupNorm module applied (with `silu`) in the kernel's prologue; norm: a NormState for it if the caller
     already has one (from a producer's statistics), else a statistics pass over x runs first; n_stat: samples the norm
     statistics span separately (frames for 2-D norms, 1 for the temporal ones).
+    grad_add / res_grad_to: ops.GradCell hand-overs under autograd (x feeds this convolution's norm AND a later `+ x`: the residual
+    side delivers its gradient into the cell, this side adds it inside the GroupNorm-backward apply kernel).
     Returns (out, PartialStats | None): the statistics of `out` for a following GroupNorm with `stats_groups` groups."""
     on_dev = ops._require_device(x, "fused_conv")
     if not on_dev or x.dtype not in (torch.float16, torch.bfloat16):
@@ -367,7 +390,8 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
         ns = norm if norm is not None else norm_state(gn, x=x.detach(), n_stat=n_stat, group=group, S_total=S_total)
     need_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
     if need_grad:
-        res = _FusedConvFn.apply(x, residual, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, stats_groups)
+        res = _FusedConvFn.apply(x, residual, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, stats_groups,
+                                 (grad_add if x.requires_grad else None, res_grad_to))
         out = res[0]
         part = None
         if stats_groups:

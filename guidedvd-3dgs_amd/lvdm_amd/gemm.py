@@ -191,16 +191,23 @@ class _FusedLinearFn(torch.autograd.Function):
     def forward(ctx, x2, r2, ln_w, ln_b, cfg, *wb):
         n = len(wb) // 2
         weights, biases = list(wb[:n]), list(wb[n:])
-        ln, geglu = cfg
+        ln, geglu = cfg[:2]
+        # GradCells (ops.GradCell): grad_add -- taken in backward and added to the input gradient; res_to / in_to -- the residual's /
+        # the input's gradient is put there instead of being returned to autograd (only into a cell its taker has armed)
+        grad_add, res_to, in_to = cfg[2] if len(cfg) > 2 else (None, None, None)
+        if grad_add is not None:
+            grad_add.arm()
+        res_to = res_to if (res_to is not None and res_to.armed and r2 is not None) else None
+        in_to = in_to if (in_to is not None and in_to.armed) else None
         Wd, c, s = _prepared(weights, biases, ln, geglu, x2.dtype)
         st = None if ln is None else row_stats(x2, ln.eps)
         ctx.save_for_backward(*([x2] if (ln is not None or geglu) else []))   # (x is only needed by the LayerNorm backward / the gate recompute)
-        ctx.cfg = (weights, biases, ln, geglu, r2 is not None)
+        ctx.cfg = (weights, biases, ln, geglu, r2 is not None, grad_add, res_to, in_to)
         return gemm_nt(x2, Wd, bias=c, row_stats=st, col_sum=s, residual=r2, geglu=geglu)
 
     @staticmethod
     def backward(ctx, gy):
-        weights, biases, ln, geglu, has_res = ctx.cfg
+        weights, biases, ln, geglu, has_res, grad_add, res_to, in_to = ctx.cfg
         x2 = ctx.saved_tensors[0] if (ln is not None or geglu) else None
         gy = gy if gy.stride(-1) == 1 else gy.contiguous()
         g = gy
@@ -217,17 +224,30 @@ class _FusedLinearFn(torch.autograd.Function):
         pad = Wt.shape[1] - g.shape[1]
         if pad:
             g = F.pad(g, (0, pad))
-        dh = gemm_nt(g, Wt)
-        if ln is not None:
+        extra = None if grad_add is None else grad_add.take()      # gradient of the same tensor along the residual branch, [M, K] rows
+        if extra is not None:
+            extra = extra.reshape(-1, extra.shape[-1])
+        if ln is None:
+            dh = gemm_nt(g, Wt, residual=extra)                     # `+ extra` in the dgrad GEMM's epilogue
+        else:
+            dh = gemm_nt(g, Wt)
             gx = torch.empty_like(dh)
             C = dh.shape[-1]
             x2c = x2 if x2.is_contiguous() else x2.contiguous()
+            if extra is not None and not extra.is_contiguous():
+                extra = extra.contiguous()
             with ops._on(dh.device):
-                ops._check(ops.lib().gvd_layer_norm_bwd(_P(x2c.data_ptr()), _P(dh.data_ptr()), _P(ln.weight.data_ptr()), _P(gx.data_ptr()),
-                                                        _LL(dh.shape[0]), C, ctypes.c_float(ln.eps),
-                                                        1 if dh.dtype == torch.bfloat16 else 0, _P(ops._stream())))
+                ops._check(ops.lib().gvd_layer_norm_bwd_add(_P(x2c.data_ptr()), _P(dh.data_ptr()), _P(ln.weight.data_ptr()),
+                                                            _P(None if extra is None else extra.data_ptr()), _P(gx.data_ptr()),
+                                                            _LL(dh.shape[0]), C, ctypes.c_float(ln.eps),
+                                                            1 if dh.dtype == torch.bfloat16 else 0, _P(ops._stream())))
             dh = gx
-        return (dh, gy if has_res else None, None, None, None) + (None,) * (2 * len(weights))
+        g_res = gy if has_res else None
+        if g_res is not None and res_to is not None and res_to.put(g_res):
+            g_res = None
+        if in_to is not None and in_to.put(dh):
+            dh = None
+        return (dh, g_res, None, None, None) + (None,) * (2 * len(weights))
 
 
 def _rows(x):
@@ -275,10 +295,13 @@ def _hip_ok(x, weights):
     return ok
 
 
-def linear(x, weight, bias=None, *, ln=None, residual=None, geglu=False):
+def linear(x, weight, bias=None, *, ln=None, residual=None, geglu=False, grad_add=None, res_grad_to=None, grad_to=None):
     """[geglu](LayerNorm?(x) W^T + b) [+ residual] over the last dim of x.  weight [N, K] (or a 1x1 conv weight [N, K, 1(, 1)]);
     ln: an nn.LayerNorm-like module (weight, bias, eps) applied to x first; residual: tensor of the output's shape; geglu: the
-    projection's two halves are value | gate (attention.py:415-423)."""
+    projection's two halves are value | gate (attention.py:415-423).  grad_add / res_grad_to / grad_to: ops.GradCell hand-overs
+    under autograd (add the cell's gradient to d/dx in the backward kernel; deliver d/d residual, or d/dx, into a cell instead of
+    to autograd's accumulation) -- ignored without autograd and on the torch-form branches."""
+    cells = (grad_add, res_grad_to, grad_to)
     K = x.shape[-1]
     N = weight.shape[0]
     No = N // 2 if geglu else N
@@ -303,16 +326,17 @@ def linear(x, weight, bias=None, *, ln=None, residual=None, geglu=False):
     if needs_grad:   # guided sampler: the same fused forward, input gradients through _FusedLinearFn
         if ln is not None and not _ln_kernel_ok(x, ln):
             h = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
-            return linear(h, weight, bias, residual=residual, geglu=geglu)
+            return linear(h, weight, bias, residual=residual, geglu=geglu, res_grad_to=res_grad_to)
         if geglu:
             # the gate stays a separate row kernel under autograd: its backward needs the pre-activation, and recomputing it
             # (measured: guided step 1331 -> 1355 ms) costs more than writing it once (the projection itself is still ONE launch
             # with the LayerNorm folded in)
-            h = _FusedLinearFn.apply(_rows(x), None, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, False), weight, bias)
+            h = _FusedLinearFn.apply(_rows(x), None, None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                     (ln, False, (grad_add, None, grad_to)), weight, bias)
             y = ops.geglu(h).reshape(*lead, No)
             return y if residual is None else y + residual
         r2 = None if residual is None else _rows(residual)
-        y = _FusedLinearFn.apply(_rows(x), r2, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, False), weight, bias)
+        y = _FusedLinearFn.apply(_rows(x), r2, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, False, cells), weight, bias)
         return y.reshape(*lead, No)
     x2 = _rows(x)
     Wd, c, s = _prepared([weight], [bias], ln, geglu, x.dtype)
@@ -321,7 +345,7 @@ def linear(x, weight, bias=None, *, ln=None, residual=None, geglu=False):
     return gemm_nt(x2, Wd, bias=c, row_stats=st, col_sum=s, residual=r2, geglu=geglu).reshape(*lead, No)
 
 
-def linear_cat(x, weights, biases=None, *, ln=None):
+def linear_cat(x, weights, biases=None, *, ln=None, grad_add=None):
     """Several Linears of ONE input as one launch: returns [..., sum N_i]; column block i is Linear_i(LayerNorm?(x)).  The caller
     slices views (the attention kernels read them in place through their row strides)."""
     biases = [None] * len(weights) if biases is None else biases
@@ -335,8 +359,8 @@ def linear_cat(x, weights, biases=None, *, ln=None):
         if ln is not None and not _ln_kernel_ok(x, ln):
             h = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
             return linear_cat(h, weights, biases)
-        y = _FusedLinearFn.apply(_rows(x), None, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, False),
-                                 *weights, *biases)
+        y = _FusedLinearFn.apply(_rows(x), None, None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                 (ln, False, (grad_add, None, None)), *weights, *biases)
         return y.reshape(*x.shape[:-1], y.shape[-1])
     x2 = _rows(x)
     Wd, c, s = _prepared(list(weights), list(biases), ln, False, x.dtype)

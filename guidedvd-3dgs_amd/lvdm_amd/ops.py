@@ -84,6 +84,44 @@ def _check(rc):
         raise RuntimeError(f"gvd_diffusion error {rc}: {lib().gvd_diff_last_error().decode()}")
 
 
+GRAD_CELLS = os.environ.get("GVD_GRAD_CELLS", "1") == "1"   # 0: leave every fan-in sum to autograd (A/B runs, tests)
+
+
+class GradCell:
+    """Hand-over of a gradient between two autograd nodes that both received the SAME tensor x: one as the input of a
+    normalisation (x -> LayerNorm / GroupNorm -> ...), one as a residual (`... + x`).  Autograd would sum their two gradients with
+    an elementwise kernel where the branches rejoin -- 3 passes over the activation per fork, ~170 forks per differentiable U-Net
+    evaluation, ~5 % of a guided DDIM step.  Instead the residual-side node PUTS its gradient into the cell (and reports no
+    gradient to autograd) and the norm-side node, whose backward necessarily runs later, TAKES it and adds it inside its last
+    kernel (gvd_layer_norm_bwd_add, gvd_group_norm_bwd_apply_add, the dgrad GEMM's residual epilogue): fp32 sum, one rounding.
+
+    Protocol (never loses a gradient): the taker ARMS the cell in its forward -- only when it is on the kernel path that will
+    take in backward; a putter that finds the cell unarmed at forward time, or already taken at backward time (a second backward
+    pass over a retained graph), returns its gradient to autograd as usual."""
+    __slots__ = ("g", "armed", "taken")
+
+    def __init__(self):
+        self.g, self.armed, self.taken = None, False, False
+
+    def arm(self):
+        self.armed = GRAD_CELLS
+        return self
+
+    def put(self, g):
+        if not self.armed or self.taken:
+            return False
+        self.g = g if self.g is None else self.g + g
+        return True
+
+    def take(self, like=None):
+        self.taken = True
+        g, self.g = self.g, None
+        if g is not None and like is not None:
+            g = g.reshape(like.shape)
+            g = g if g.is_contiguous() else g.contiguous()
+        return g
+
+
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -397,7 +435,8 @@ def _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=Fals
     return (y, x, g, stats, S_total) if keep else y
 
 
-def _hip_group_norm_bwd(x, gy, gamma32, stats, groups, eps, silu, channels_last, group=None, S_total=None):
+def _hip_group_norm_bwd(x, gy, gamma32, stats, groups, eps, silu, channels_last, group=None, S_total=None, add=None):
+    """add: a gradient of x's shape summed into the result inside the apply kernel (GradCell)."""
     gy = gy.contiguous()
     N, C, S = _gn_dims(x, channels_last)
     gx = torch.empty_like(x)
@@ -405,18 +444,15 @@ def _hip_group_norm_bwd(x, gy, gamma32, stats, groups, eps, silu, channels_last,
     P, LL = ctypes.c_void_p, ctypes.c_longlong
     bf = 1 if x.dtype == torch.bfloat16 else 0
     with _on(x.device):
-        if group is None:
-            rc = lib().gvd_group_norm_bwd(P(x.data_ptr()), P(gy.data_ptr()), P(gx.data_ptr()), P(gamma32.data_ptr()),
-                                          P(stats.data_ptr()), P(scratch.data_ptr()), N, C, LL(S), groups,
-                                          ctypes.c_float(eps), int(bool(silu)), int(bool(channels_last)), bf, P(_stream()))
-        else:
+        _check(lib().gvd_group_norm_bwd_stats(P(x.data_ptr()), P(gy.data_ptr()), P(gamma32.data_ptr()), P(stats.data_ptr()),
+                                              P(scratch.data_ptr()), N, C, LL(S), groups, int(bool(silu)),
+                                              int(bool(channels_last)), bf, P(_stream())))
+        if group is not None:
             import torch.distributed as dist
-            _check(lib().gvd_group_norm_bwd_stats(P(x.data_ptr()), P(gy.data_ptr()), P(gamma32.data_ptr()), P(stats.data_ptr()),
-                                                  P(scratch.data_ptr()), N, C, LL(S), groups, int(bool(silu)),
-                                                  int(bool(channels_last)), bf, P(_stream())))
             dist.all_reduce(scratch[:2 * N * groups], group=group)
-            rc = lib().gvd_group_norm_bwd_apply(P(x.data_ptr()), P(gy.data_ptr()), P(gx.data_ptr()), P(stats.data_ptr()),
-                                                P(scratch.data_ptr()), N, C, LL(S), LL(S_total), groups, ctypes.c_float(eps),
+        rc = lib().gvd_group_norm_bwd_apply_add(P(x.data_ptr()), P(gy.data_ptr()), P(None if add is None else add.data_ptr()),
+                                                P(gx.data_ptr()), P(stats.data_ptr()), P(scratch.data_ptr()), N, C, LL(S),
+                                                LL(S if group is None else S_total), groups, ctypes.c_float(eps),
                                                 int(bool(silu)), int(bool(channels_last)), bf, P(_stream()))
     _check(rc)
     return gx
@@ -427,24 +463,26 @@ class _GroupNormFn(torch.autograd.Function):
     autograd user is the guided sampler, which differentiates w.r.t. x_t with frozen weights."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, silu, channels_last, group, S_total):
+    def forward(ctx, x, weight, bias, groups, eps, silu, channels_last, group, S_total, grad_add=None):
         y, xc, g32, stats, S_total = _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, keep=True,
                                                      group=group, S_total=S_total)
         ctx.save_for_backward(xc, g32, stats)
-        ctx.cfg = (groups, eps, silu, channels_last, group, S_total)
+        ctx.cfg = (groups, eps, silu, channels_last, group, S_total, None if grad_add is None else grad_add.arm())
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, g32, stats = ctx.saved_tensors
-        groups, eps, silu, cl, group, S_total = ctx.cfg
-        return (_hip_group_norm_bwd(x, gy, g32, stats, groups, eps, silu, cl, group, S_total),) + (None,) * 8
+        groups, eps, silu, cl, group, S_total, cell = ctx.cfg
+        add = None if cell is None else cell.take(like=x)
+        return (_hip_group_norm_bwd(x, gy, g32, stats, groups, eps, silu, cl, group, S_total, add=add),) + (None,) * 9
 
 
-def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False, group=None, S_total=None):
+def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=False, group=None, S_total=None, grad_add=None):
     """GroupNorm with fp32 statistics + optional fused SiLU.  channels_last: x is [N, ..., C].
     group / S_total: statistics span the slices held by the ranks of `group` (S_total = global elements per
-    (sample, channel); computed with one tiny all-reduce when omitted)."""
+    (sample, channel); computed with one tiny all-reduce when omitted).  grad_add: a GradCell whose content (the gradient x
+    receives along a residual branch) is added to the input gradient inside the backward kernel."""
     on_dev = _require_device(x, "group_norm")
     C = x.shape[-1] if channels_last else x.shape[1]
     if (on_dev and x.dtype in (torch.float16, torch.bfloat16) and weight is not None and bias is not None
@@ -452,7 +490,7 @@ def group_norm(x, groups, weight, bias, eps=1e-5, silu=False, channels_last=Fals
         if torch.is_grad_enabled() and x.requires_grad:
             if weight.requires_grad or bias.requires_grad:
                 raise RuntimeError("lvdm_amd.ops.group_norm: only the input gradient is implemented (freeze the weights)")
-            return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last, group, S_total)
+            return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, channels_last, group, S_total, grad_add)
         return _hip_group_norm(x, groups, weight, bias, eps, silu, channels_last, group=group, S_total=S_total)
     if on_dev:
         _torch_form("group_norm", f"dtype {x.dtype}, C = {C} (the kernels cover 16-bit inputs with affine parameters, C % 8 == 0 token-major)")

@@ -62,12 +62,17 @@ def _img(tok):
     return tok.permute(0, 3, 1, 2)
 
 
-def _gn_tokens(gn, tok, n_stat, silu=False, shard=None, tokens_total=None):
+def _cell(t):
+    """A gradient hand-over cell (ops.GradCell) for a tensor that feeds a norm AND a later `+ t`, when a gradient will flow."""
+    return ops.GradCell() if (torch.is_grad_enabled() and t.requires_grad) else None
+
+
+def _gn_tokens(gn, tok, n_stat, silu=False, shard=None, tokens_total=None, grad_add=None):
     """GroupNorm over token-major data; statistics span tok.numel() / (n_stat * C) tokens per group -- completed
     across the frame-shard group when `shard` is given (tokens_total = tokens per sample over all ranks)."""
     C = tok.shape[-1]
     y = ops.group_norm(tok.reshape(n_stat, -1, C), gn.num_groups, gn.weight, gn.bias, gn.eps, silu=silu, channels_last=True,
-                       group=None if shard is None else shard.group, S_total=tokens_total)
+                       group=None if shard is None else shard.group, S_total=tokens_total, grad_add=grad_add)
     return y.reshape(tok.shape)
 
 
@@ -128,17 +133,19 @@ class CrossAttention(nn.Module):
 
     def forward(self, x, context=None, shared_frames=1, frame_major=False, norm=None, residual=None):
         """norm: the LayerNorm in front of this attention (attention.py:283-285) -- folded into the q / k / v GEMMs instead of
-        being applied; residual: the block's `+ x`, added in to_out's epilogue."""
+        being applied; residual: the block's `+ x`, added in to_out's epilogue.  Under autograd the gradient of that `+ x` is
+        handed to the q / k / v projection's backward through a GradCell and summed inside its LayerNorm-backward kernel."""
         C = self.to_q.weight.shape[0]
+        cell = _cell(x) if residual is x else None
         if context is None:
-            qkv = gemm.linear_cat(x, [self.to_q.weight, self.to_k.weight, self.to_v.weight], ln=norm)   # one launch, LayerNorm folded
+            qkv = gemm.linear_cat(x, [self.to_q.weight, self.to_k.weight, self.to_v.weight], ln=norm, grad_add=cell)   # one launch, LayerNorm folded
             # q | k | v are read in place as column blocks (and, under autograd, their gradients written in place)
             if frame_major:  # x [b, T, pixels, C]: one T-long sequence per pixel, read in place
                 out = ops.self_attention_packed(qkv, self.heads, frame_major=True)   # [b, T, pixels, 3 C]: samples looped inside the op
             else:
                 out = ops.self_attention_packed(qkv, self.heads)
         else:
-            q = gemm.linear(x, self.to_q.weight, ln=norm)
+            q = gemm.linear(x, self.to_q.weight, ln=norm, grad_add=cell)
             k, v, k_ip, v_ip = self._kv(context, shared_frames)
             out = ops.attention(q, k, v, self.heads)
             if k_ip is not None:
@@ -151,7 +158,7 @@ class CrossAttention(nn.Module):
         if residual is not None and drop.training and drop.p > 0:
             # the reference drops the projection, not the residual stream: dropout(linear(out)) + x (attention.py:144, :241-244)
             return drop(gemm.linear(out, lo.weight, lo.bias)) + residual
-        return gemm.linear(out, lo.weight, lo.bias, residual=residual)   # eval / p = 0: dropout is the identity, `+ x` in the epilogue
+        return gemm.linear(out, lo.weight, lo.bias, residual=residual, res_grad_to=cell)   # eval / p = 0: dropout is the identity, `+ x` in the epilogue
 
 
 class LayerNorm(nn.LayerNorm):
@@ -166,8 +173,8 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
-    def forward(self, x, norm=None):
-        return gemm.linear(x, self.proj.weight, self.proj.bias, ln=norm, geglu=True)   # LayerNorm fold + gate in ONE launch
+    def forward(self, x, norm=None, grad_add=None):
+        return gemm.linear(x, self.proj.weight, self.proj.bias, ln=norm, geglu=True, grad_add=grad_add)   # LayerNorm fold + gate in ONE launch
 
 
 class FeedForward(nn.Module):
@@ -177,8 +184,9 @@ class FeedForward(nn.Module):
 
     def forward(self, x, norm=None, residual=None):
         """norm: the LayerNorm in front (folded into the projection); residual: the block's `+ x` (second GEMM's epilogue)."""
-        h = self.net[1](self.net[0](x, norm=norm))
-        return gemm.linear(h, self.net[2].weight, self.net[2].bias, residual=residual)
+        cell = _cell(x) if residual is x else None
+        h = self.net[1](self.net[0](x, norm=norm, grad_add=cell))
+        return gemm.linear(h, self.net[2].weight, self.net[2].bias, residual=residual, res_grad_to=cell)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -223,11 +231,12 @@ class SpatialTransformer(nn.Module):
     def forward(self, x, context=None, shared_frames=1):
         n, c, h, w = x.shape
         tok = _tok(x)
-        t = _gn_tokens(self.norm, tok, n).reshape(n, h * w, c)
+        cell = _cell(tok)     # tok feeds the norm and the closing `+ x_in`: one fused gradient sum (ops.GradCell)
+        t = _gn_tokens(self.norm, tok, n, grad_add=cell).reshape(n, h * w, c)
         t = gemm.linear(t, self.proj_in.weight, self.proj_in.bias)     # (a 1x1 Conv2d is a Linear with weight [out, in, 1, 1])
         for blk in self.transformer_blocks:
             t = blk(t, context, shared_frames)
-        t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias, residual=tok.reshape(n, h * w, c))   # `+ x_in` in the epilogue
+        t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias, residual=tok.reshape(n, h * w, c), res_grad_to=cell)   # `+ x_in` in the epilogue
         return _img(t.reshape(n, h, w, c))
 
 
@@ -252,8 +261,9 @@ class TemporalTransformer(nn.Module):
         b, T = batch_size, bt // batch_size
         tok = _tok(x)
         shard = parallel.active()
+        cell = _cell(tok) if shard is None else None
         if shard is None:
-            t = _gn_tokens(self.norm, tok, b).reshape(b, T, h * w, c)  # statistics over (C/32, T, h, w) per sample
+            t = _gn_tokens(self.norm, tok, b, grad_add=cell).reshape(b, T, h * w, c)  # statistics over (C/32, T, h, w) per sample
         else:  # frames are sharded: finish the statistics across the group, then re-shard frames -> pixels
             t = _gn_tokens(self.norm, tok, b, shard=shard, tokens_total=shard.T * h * w)
             t = parallel.frames_to_pixels(t.reshape(T, h * w, c), shard)[None]  # [1, all T, this rank's pixels, c]
@@ -264,7 +274,7 @@ class TemporalTransformer(nn.Module):
             t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias)
             t = parallel.pixels_to_frames(t[0], shard, h * w)
             return _img(t.reshape(bt, h, w, c) + tok)
-        t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias, residual=tok.reshape(t.shape[:-1] + (c,)))
+        t = gemm.linear(t, self.proj_out.weight, self.proj_out.bias, residual=tok.reshape(t.shape[:-1] + (c,)), res_grad_to=cell)
         return _img(t.reshape(bt, h, w, c))
 
 
@@ -347,6 +357,7 @@ class TemporalConvBlock(nn.Module):
         outs = []
         for x0 in samples:
             h, part = x0, (stats if b == 1 else None)
+            cell = _cell(x0)          # x0 feeds conv1's norm and the closing identity add
             seqs = (self.conv1, self.conv2, self.conv3, self.conv4)
             for k, seq in enumerate(seqs):
                 gn, conv = seq[0], seq[-1]
@@ -356,7 +367,8 @@ class TemporalConvBlock(nn.Module):
                     ns = mconv.norm_state(gn, partial=part, merge=part.N, group=group, S_total=total)
                 last = k == len(seqs) - 1
                 h, part = mconv.fused_conv(h, conv, mode=mconv.TEMPORAL, gn=gn, norm=ns, silu=True,
-                                           residual=x0 if last else None, stats_groups=0 if last else gn.num_groups)
+                                           residual=x0 if last else None, stats_groups=0 if last else gn.num_groups,
+                                           grad_add=cell if k == 0 else None, res_grad_to=cell if last else None)
             outs.append(h)
         if shard is not None:
             return parallel.pixels_to_frames(outs[0], shard, hh * ww).reshape(bt, hh, ww, c)
@@ -419,15 +431,19 @@ class ResBlock(nn.Module):
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, conv2 = self.out_layers[0], self.out_layers[3]
         emb_out = gemm.linear(F.silu(emb), self.emb_layers[1].weight, self.emb_layers[1].bias).to(tok.dtype)
-        h, part = mconv.fused_conv(tok, conv1, gn=gn1, silu=True, add_nc=emb_out, stats_groups=gn2.num_groups)
+        # tok feeds conv1's norm and the skip path: the skip side hands its gradient to conv1's backward (ops.GradCell), which sums
+        # it inside the GroupNorm-backward apply kernel -- no accumulation kernel where the two branches meet
+        cell = _cell(tok)
+        h, part = mconv.fused_conv(tok, conv1, gn=gn1, silu=True, add_nc=emb_out, stats_groups=gn2.num_groups, grad_add=cell)
         ns2 = mconv.norm_state(gn2, partial=part)
-        if isinstance(self.skip_connection, nn.Identity):
+        identity = isinstance(self.skip_connection, nn.Identity)
+        if identity:
             skip = tok
         else:  # 1x1 convolution == per-token GEMM on the same bytes
             sc = self.skip_connection
-            skip = gemm.linear(tok, sc.weight, sc.bias)
+            skip = gemm.linear(tok, sc.weight, sc.bias, grad_to=cell)
         temporal = self.use_temporal_conv and batch_size
-        h, part = mconv.fused_conv(h, conv2, gn=gn2, norm=ns2, silu=True, residual=skip,
+        h, part = mconv.fused_conv(h, conv2, gn=gn2, norm=ns2, silu=True, residual=skip, res_grad_to=cell if identity else None,
                                    stats_groups=self.temopral_conv.conv1[0].num_groups if temporal else 0)
         if temporal:
             h = self.temopral_conv.forward_tokens(h, batch_size, stats=part)

@@ -61,13 +61,16 @@ class ResnetBlock(nn.Module):
         """tok [N, H, W, C] -> (out tokens, statistics of out for the next norm | None).  Two MFMA convolution launches:
         norm + swish in the operand load, the shortcut add in the second epilogue (ae_modules.py:186-210)."""
         ns1 = mconv.norm_state(self.norm1, partial=stats) if stats is not None else None
-        h, part = mconv.fused_conv(tok, self.conv1, gn=self.norm1, norm=ns1, silu=True, stats_groups=32)
+        # tok feeds norm1 and the shortcut: the shortcut side's gradient is summed inside conv1's GroupNorm-backward kernel (ops.GradCell)
+        cell = ops.GradCell() if (torch.is_grad_enabled() and tok.requires_grad) else None
+        h, part = mconv.fused_conv(tok, self.conv1, gn=self.norm1, norm=ns1, silu=True, stats_groups=32, grad_add=cell)
         ns2 = mconv.norm_state(self.norm2, partial=part)
-        if hasattr(self, "nin_shortcut"):
-            skip = gemm.linear(tok, self.nin_shortcut.weight, self.nin_shortcut.bias)
+        nin = hasattr(self, "nin_shortcut")
+        if nin:
+            skip = gemm.linear(tok, self.nin_shortcut.weight, self.nin_shortcut.bias, grad_to=cell)
         else:
             skip = tok
-        return mconv.fused_conv(h, self.conv2, gn=self.norm2, norm=ns2, silu=True, residual=skip,
+        return mconv.fused_conv(h, self.conv2, gn=self.norm2, norm=ns2, silu=True, residual=skip, res_grad_to=None if nin else cell,
                                 stats_groups=32 if want_stats else 0)
 
     def forward(self, x):
@@ -90,12 +93,13 @@ class AttnBlock(nn.Module):
         """tok [N, H, W, C]: norm -> q/k/v (1x1 convolutions == per-token GEMMs) -> single-head attention -> proj_out -> + x."""
         n, h, w, c = tok.shape
         t = tok.reshape(n, h * w, c)
-        hn = ops.group_norm(t, 32, self.norm.weight, self.norm.bias, self.norm.eps, silu=False, channels_last=True)
+        cell = ops.GradCell() if (torch.is_grad_enabled() and t.requires_grad) else None
+        hn = ops.group_norm(t, 32, self.norm.weight, self.norm.bias, self.norm.eps, silu=False, channels_last=True, grad_add=cell)
         # q | k | v as ONE MFMA GEMM (column blocks read in place), the wide single-head attention (ops.attention -> flash kernel
         # at d = 64, chunked GEMMs at d = 512: wide_attention.py), proj_out with the `+ x` in its epilogue
         qkv = gemm.linear_cat(hn, [self.q.weight, self.k.weight, self.v.weight], [self.q.bias, self.k.bias, self.v.bias])
         o = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], heads=1)
-        return gemm.linear(o, self.proj_out.weight, self.proj_out.bias, residual=t).reshape(n, h, w, c)
+        return gemm.linear(o, self.proj_out.weight, self.proj_out.bias, residual=t, res_grad_to=cell).reshape(n, h, w, c)
 
     def forward(self, x):
         if _fused(x, self):

@@ -108,6 +108,13 @@ int gvd_group_norm_bwd_stats(const void* x, const void* dy, const float* gamma, 
 int gvd_group_norm_bwd_apply(const void* x, const void* dy, void* dx, const double* fwd_stats, double* scratch,
                              int N, int C, long long S, long long S_total, int G, float eps, int silu, int channels_last,
                              int is_bf16, void* stream);
+/* ... with the gradient that reaches the same tensor along a RESIDUAL branch added in (fp32 sum, one rounding):
+ * dx = GroupNorm-backward(x, dy) + add.  `add` has dx's layout (nullptr: none).  The reference leaves this sum to autograd's
+ * accumulation where a tensor feeds both a norm and a `+ x` (openaimodel3d.py:232-236,270-279; attention.py:296-310): a separate
+ * elementwise kernel over two 16-bit gradients per fork. */
+int gvd_group_norm_bwd_apply_add(const void* x, const void* dy, const void* add, void* dx, const double* fwd_stats, double* scratch,
+                                 int N, int C, long long S, long long S_total, int G, float eps, int silu, int channels_last,
+                                 int is_bf16, void* stream);
 
 /* LayerNorm over the last dim of [M, C] 16-bit rows, fp32 statistics, gamma/beta in the same 16-bit type as x.
  * Replaces nn.LayerNorm in BasicTransformerBlock (lvdm/modules/attention.py:283-285).  C % 8 == 0, C <= 2048. */
@@ -124,6 +131,10 @@ int gvd_geglu(const void* h, void* y, long long M, int C, int is_bf16, void* str
 int gvd_layer_norm_bwd(const void* x, const void* dy, const void* gamma, void* dx, long long M, int C, float eps,
                        int is_bf16, void* stream);
 int gvd_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int C, int is_bf16, void* stream);
+/* gvd_layer_norm_bwd with the residual branch's gradient added in: dx = LayerNorm-backward(x, dy) + add  (`x + attn(LN(x))`,
+ * attention.py:241-244; nullptr: none). */
+int gvd_layer_norm_bwd_add(const void* x, const void* dy, const void* gamma, const void* add, void* dx, long long M, int C,
+                           float eps, int is_bf16, void* stream);
 
 /* ---- implicit-GEMM convolutions on MFMA (csrc/conv_mfma.hip) -------------------------------------------------------
  * One kernel family for the 3x3 convolutions of the U-Net ResBlock / Upsample (openaimodel3d.py:51-106,210-236), the VAE
