@@ -38,6 +38,9 @@
 
 #include "diffusion_common.h"
 
+#ifndef GVD_CONV_WPF
+#define GVD_CONV_WPF 2   // weight-slab prefetch distance in loop steps (1 = the round-2/3 kernel, for A/B builds)
+#endif
 #ifndef GVD_CONV_DBG
 #define GVD_CONV_DBG 0   // experiments only (tests/scripts/run_conv_lds_hunt.sh): 1 = no patch ds_writes in the loop, 2 = no weight ds_writes in the loop,
 #endif                   // 4 = no epilogue staging writes, 8 = no epilogue staging reads, 16 = no MFMA operand reads of the patch, 32 = ... of the weights
@@ -63,6 +66,8 @@ struct ConvArgs {
     int nchunks;
     int cpg, G, R;
     int PB;               // temporal: pixels per tile
+    int NS;               // temporal: samples in this launch (x / out / res / bx are [NS][N frames][W pixels][C]; coef, statistics and
+                          // bcoef are indexed by the sample when coef_per_n / bcoef_per_n are set); tiles never straddle samples
     int coef_per_n;       // 1: coef is [N][Cin], 0: one [Cin] vector for all n (temporal, batch 1)
     // Input-gradient launches whose OUTPUT is the gradient w.r.t. silu(GroupNorm(bx)): `stats` then receives the two sums the
     // GroupNorm backward needs per (sample, group) instead of sum / sum of squares (see the epilogue).
@@ -153,9 +158,11 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         ty0 = (rem / a.tiles_x) * G_::TH;
         tx0 = (rem % a.tiles_x) * G_::TW;
     } else {
-        p0 = blockIdx.x * a.PB;
+        n = blockIdx.x / a.tiles_x;                       // sample: the (3,1,1) convolution treats pixels independently, so the samples of
+        p0 = (blockIdx.x - n * a.tiles_x) * a.PB;         // a batch are just more pixel tiles of ONE launch (per-sample norms via coef_per_n)
     }
     const int PB = a.PB;
+    const size_t sample_in = SPATIAL ? 0 : (size_t)n * a.N * a.W * a.Cin, sample_out = SPATIAL ? 0 : (size_t)n * a.N * a.W * a.Cout;
 
     // ---- patch staging map (piece = 16 bytes = 8 channels of one patch pixel) ----
     const int k8 = tid & 3;   // 256 % 4 == 0: a thread always stages the same channel octet of the chunk
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
             } else {
                 const int tt = pixel / PB - 1, pp = pixel - (tt + 1) * PB, gp = p0 + pp;
                 loff[i] = pixel * PIX_BYTES + k8 * 16;
-                if (tt >= 0 && tt < a.N && gp < a.W) goff[i] = (tt * a.W + gp) * Cin;
+                if (tt >= 0 && tt < a.N && gp < a.W) goff[i] = (int)sample_in + (tt * a.W + gp) * Cin;
             }
         } else {
             loff[i] = -1;
@@ -258,24 +265,31 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     typedef std::integral_constant<int, 1> H1;
 
     // ---- weight staging (linear copy of the pre-swizzled slab) ----
+    // Slab it + 2 is fetched while slab it is multiplied (two register sets, the loop below is unrolled by two): with the fetch only
+    // ONE step ahead every step waited out a full L2 / fabric round trip behind its 16-40 MFMAs whenever a CU held a single
+    // workgroup -- the under-filled launches of the small levels (the 5x7 / 10x14 latents of a 320x448 video: 40-280 workgroups on
+    // 256 CUs) ran at 0.9 us per step against 0.13 us of matrix work.
     const T* __restrict__ wt = (const T*)a.w + (size_t)co_tile * a.nchunks * NTAPS * (BN * BK);
-    vec8 wreg[WPT];
-    auto load_w = [&](int it) {
+    constexpr int NSET = (MI >= 5) ? 1 : GVD_CONV_WPF;   // (the 5-block tiles sit at the 256-register cap: one set, fetch one step ahead)
+    vec8 wreg[NSET][WPT];
+    auto load_w = [&](int it, auto set_tag) {
+        constexpr int SET = NSET == 2 ? decltype(set_tag)::value : 0;
         const T* src = wt + (size_t)it * (BN * BK);
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int q = tid + i * 256;
-            wreg[i] = *reinterpret_cast<const vec8*>(src + (q < NWP ? q : NWP - 1) * 8);   // unconditional (see the note above)
+            wreg[SET][i] = *reinterpret_cast<const vec8*>(src + (q < NWP ? q : NWP - 1) * 8);   // unconditional (see the note above)
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, auto set_tag) {
+        constexpr int SET = NSET == 2 ? decltype(set_tag)::value : 0;
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int q = tid + i * 256;
 #if GVD_CONV_DBG & 2
-            if (wreg[i][0] == (T)123.456f)
+            if (wreg[SET][i][0] == (T)123.456f)
 #endif
-            if (q < NWP) *reinterpret_cast<vec8*>(wbuf + buf * WBYTES + q * 16) = wreg[i];
+            if (q < NWP) *reinterpret_cast<vec8*>(wbuf + buf * WBYTES + q * 16) = wreg[SET][i];
         }
     };
     // ---- MFMA operand addresses ----
@@ -299,25 +313,31 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         for (int ni = 0; ni < NI; ni++) acc[mi][ni] = f16v{};
 
     const int total = a.nchunks * NTAPS;
-    load_w(0);
+    load_w(0, H0{});
     load_cf(0);
     load_p(0, H0{});
-    store_w(0);
+    store_w(0, H0{});
+    if (NSET == 2 && total > 1) load_w(1, H1{});
     store_p(0, H0{});
     load_p(0, H1{});
     store_p(0, H1{});
     int chunk = 0, tap = 0;
     // taps at which the next chunk's patch halves are fetched / written (3-tap temporal form: everything one tap apart)
     constexpr int T_L0 = NTAPS >= 9 ? NTAPS - 4 : 0, T_S0 = NTAPS >= 9 ? NTAPS - 3 : 1, T_S1 = NTAPS - 1;
-    for (int it = 0; it < total; it++) {
+    // one step; SET = it & 1: slab it + 2 goes into the register set slab it came from, slab it + 1 is written from the other set
+    auto step = [&](int it, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        typedef std::integral_constant<int, SET ^ 1> Other;
         __syncthreads();
         const bool more_w = it + 1 < total, more_p = chunk + 1 < a.nchunks;
-        if (more_w) load_w(it + 1);
+        if (NSET == 2) { if (it + 2 < total) load_w(it + 2, set_tag); }
+        else if (more_w) load_w(it + 1, Other{});
         if (more_p) {
             if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); }
         }
 
-        const unsigned char* wb = wbuf + (it & 1) * WBYTES;
+        const int cur = NSET == 2 ? SET : (it & 1);          // LDS weight buffer holding slab `it`
+        const unsigned char* wb = wbuf + cur * WBYTES;
         int shift;
         if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
         else shift = tap * PB * PIX_BYTES;
@@ -347,12 +367,64 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
         }
 
-        if (more_w) store_w((it + 1) & 1);
+        if (more_w) store_w(cur ^ 1, Other{});
         if (more_p) {
             if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
             if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
         }
         if (++tap == NTAPS) { tap = 0; chunk++; }
+    };
+    if constexpr (NSET == 2) {
+        int it = 0;
+        for (; it + 1 < total; it += 2) { step(it, H0{}); step(it + 1, H1{}); }
+        if (it < total) step(it, H0{});
+    } else {
+        // (the 5-block tiles: the round-2 loop as it was -- any restructuring of it costs them registers they do not have)
+        for (int it = 0; it < total; it++) {
+            __syncthreads();
+            const bool more_w = it + 1 < total, more_p = chunk + 1 < a.nchunks;
+            if (more_w) load_w(it + 1, H0{});
+            if (more_p) {
+                if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); }
+            }
+
+            const unsigned char* wb = wbuf + (it & 1) * WBYTES;
+            int shift;
+            if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
+            else shift = tap * PB * PIX_BYTES;
+            const unsigned char* pb = pbuf + (chunk & 1) * PBYTES + shift;
+    #pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                vec8 af[MI], bf[NI];
+    #pragma unroll
+                for (int mi = 0; mi < MI; mi++) {
+    #if GVD_CONV_DBG & 32
+                    af[mi] = vec8{}; af[mi][0] = (T)(float)(it + mi);
+    #else
+                    af[mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048);
+    #endif
+                }
+    #pragma unroll
+                for (int ni = 0; ni < NI; ni++) {
+    #if GVD_CONV_DBG & 16
+                    bf[ni] = vec8{}; bf[ni][0] = (T)(float)(it + ni);
+    #else
+                    bf[ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32);
+    #endif
+                }
+    #pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+    #pragma unroll
+                    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
+            }
+
+            if (more_w) store_w((it + 1) & 1, H0{});
+            if (more_p) {
+                if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
+                if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
+            }
+            if (++tap == NTAPS) { tap = 0; chunk++; }
+        }
     }
     __syncthreads();   // all operand reads retired: the LDS is reused by the epilogue
 
@@ -413,7 +485,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 if (MODE == 2) {
                     const int tt = m / PB, pp = m - tt * PB;
                     valid = tt < a.N && p0 + pp < a.W;
-                    off = ((size_t)tt * a.W + p0 + pp) * Cout;
+                    off = sample_out + ((size_t)tt * a.W + p0 + pp) * Cout;
                 } else {
                     const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
                     valid = ty0 + ty < a.H && tx0 + tx < a.W;
@@ -516,7 +588,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 double s = 0.0, q = 0.0;
                 for (int c = c_lo; c < c_hi; c++) { s += (double)red[c - cb]; q += (double)red[EP_ROWS * BN + c - cb]; }
                 const int rep = blockIdx.x % a.R;
-                const int nstat = SPATIAL ? n : 0, Nstat = SPATIAL ? a.N : 1;
+                const int nstat = n, Nstat = SPATIAL ? a.N : a.NS;
                 double* dst = a.stats + (((size_t)rep * Nstat + nstat) * a.G + g) * 2;
                 atomicAdd(dst, s);
                 atomicAdd(dst + 1, q);
@@ -646,7 +718,7 @@ void choose(int mode, int N, int H, int W, int Cout, int* cfg, int* tw32)
     auto groups = [&](int c) {
         const int pix = CFG_PIX[c], bn = CFG_BN[c];
         long long tiles;
-        if (mode == 1) { int pb = pix / N; pb = pb < 1 ? 1 : (pb > PB_MAX ? PB_MAX : pb); tiles = (W + pb - 1) / pb; }
+        if (mode == 1) { int pb = pix / N; pb = pb < 1 ? 1 : (pb > PB_MAX ? PB_MAX : pb); tiles = (long long)((W + pb - 1) / pb) * H; }   // (temporal: H = samples)
         else tiles = (mode >= 2 ? padded(pix, 32) : padded(pix, width32(pix) ? 32 : 16)) / pix * N;
         return tiles * ((Cout + bn - 1) / bn);
     };
@@ -692,12 +764,14 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
         return fail(-1, "gvd_conv_mfma: bad arguments");
     if ((Cin & 7) || (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)residual) & 15))
         return fail(-1, "gvd_conv_mfma: Cin must be a multiple of 8 and tensors 16-byte aligned");
-    if (mode == 1 && (H != 1 || upsample)) return fail(-1, "gvd_conv_mfma: temporal mode takes N = frames, H = 1, W = pixels per frame");
+    if (mode == 1 && (H < 1 || upsample)) return fail(-1, "gvd_conv_mfma: temporal mode takes N = frames, H = samples (>= 1), W = pixels per frame");
+    const int NS = mode == 1 ? H : 1;     // temporal: the samples of a batch are more pixel tiles of one launch (ConvArgs::NS)
     if (upsample < 0 || upsample > 2 || (upsample && mode != 0)) return fail(-1, "gvd_conv_mfma: upsample is 0, 1 (nearest) or 2 (zero-stuffed), stride-1 spatial mode only");
     if (stats && (groups <= 0 || Cout % groups || stats_replicas <= 0)) return fail(-1, "gvd_conv_mfma: bad statistics arguments");
     int cfg, tw32;
     choose(mode, N, H, W, Cout, &cfg, &tw32);
     const int BN = CFG_BN[cfg], PIX = CFG_PIX[cfg];
+    if (mode == 1) H = 1;
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.coef = reinterpret_cast<const float2*>(coef); a.bias = bias; a.add_nc = add_nc; a.res = residual;
     a.out = out; a.stats = stats;
@@ -713,7 +787,8 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
     } else {
         a.Hin = H; a.Win = W;
     }
-    const long long in_elems = (long long)N * a.Hin * a.Win * Cin, out_elems = (long long)N * H * W * Cout;
+    const long long in_elems = (long long)NS * N * a.Hin * a.Win * Cin, out_elems = (long long)NS * N * H * W * Cout;
+    a.NS = NS;
     if (in_elems >= (1LL << 31) || out_elems >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
     a.nchunks = (Cin + BK - 1) / BK;
     a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
@@ -736,7 +811,7 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
         if (pb > PB_MAX) pb = PB_MAX;
         a.PB = pb;
         a.tiles_x = (W + pb - 1) / pb; a.tiles_y = 1;
-        grid.x = (unsigned)a.tiles_x;
+        grid.x = (unsigned)(a.tiles_x * NS);
         e = is_bf16 ? launch_cfg<__bf16, 2>(cfg, a, grid, stream) : launch_cfg<_Float16, 2>(cfg, a, grid, stream);
     }
     if (e != hipSuccess) return fail(-2, "launch k_conv_mfma", e);

@@ -2,7 +2,8 @@
 
     fused_conv(x, conv, ...)     out = conv(silu?(GroupNorm(x))) + bias + add_nc + residual   (+ statistics for the next norm)
 
-`x` / `out` are token-major [N, H, W, C] 16-bit tensors; the temporal (3,1,1) form takes [T, pixels, C].  The weights stay
+`x` / `out` are token-major [N, H, W, C] 16-bit tensors; the temporal (3,1,1) form takes [T, pixels, C] or, for a batch,
+[samples, T, pixels, C] (the samples are extra pixel tiles of ONE launch; norms and statistics stay per sample).  The weights stay
 the module's `nn.Conv2d` / `nn.Conv3d` parameters (reference state-dict keys); the packed MFMA image is cached on the
 parameter.  Forward and input gradient (the guided sampler differentiates w.r.t. x_t with frozen weights) run the same
 kernel -- the input gradient is the convolution with the transposed, tap-flipped weights.
@@ -175,17 +176,18 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
     output is the gradient w.r.t. silu?(GroupNorm(norm_x)); the returned sums are then the GroupNorm-BACKWARD statistics
     (gvd_conv_mfma_norm_bwd) instead of the forward ones."""
     P = ctypes.c_void_p
-    out = torch.empty((N, W, Cout) if mode == TEMPORAL else (N, H, W, Cout), dtype=x.dtype, device=x.device)
+    # (temporal: N = frames, H = samples, W = pixels per frame -- the samples of a batch are extra pixel tiles of ONE launch)
+    out = torch.empty(((N, W, Cout) if H == 1 else (H, N, W, Cout)) if mode == TEMPORAL else (N, H, W, Cout), dtype=x.dtype, device=x.device)
     sums = None
     if stats_groups:
-        n_stat = 1 if mode == TEMPORAL else N
+        n_stat = H if mode == TEMPORAL else N
         sums = _ZeroArena.take((STATS_REPLICAS, n_stat, stats_groups, 2), x.device)
     if norm_bwd is not None:
         nx, ns, nsilu = norm_bwd
         with ops._on(x.device):
             rc = ops.lib().gvd_conv_mfma_norm_bwd(P(x.data_ptr()), P(wpk.data_ptr()), P(out.data_ptr()), P(sums.data_ptr()),
                                                   STATS_REPLICAS, stats_groups, mode, N, H, W, Cin, Cout, P(nx.data_ptr()),
-                                                  P(ns.coef_ptr), 0 if mode == TEMPORAL else 1, P(ns.gamma32.data_ptr()),
+                                                  P(ns.coef_ptr), 1, P(ns.gamma32.data_ptr()),
                                                   int(bool(nsilu)), 1 if x.dtype == torch.bfloat16 else 0, P(ops._stream()))
         ops._check(rc)
         return out, PartialStats(sums, STATS_REPLICAS, sums.shape[1], stats_groups, 0)
@@ -215,7 +217,7 @@ def _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cg, Cn, add=Non
     x = x.contiguous()
     dev, bf = x.device, 1 if x.dtype == torch.bfloat16 else 0
     gx = torch.empty_like(x)
-    n_stat = 1 if mode == TEMPORAL else N
+    n_stat = H if mode == TEMPORAL else N
     if n_stat != ns.N:
         raise RuntimeError(f"fused_conv backward: norm state spans {ns.N} samples, the convolution {n_stat}")
     d_act, partial = _launch(g, wT, Cn, mode, N, H, W, Cg, stats_groups=ns.G, norm_bwd=(x, ns, silu))
@@ -237,9 +239,9 @@ def _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cg, Cn, add=Non
 
 def _geometry(x, mode, upsample):
     """(N, H, W, Cin, H_in, W_in): output geometry of the convolution of x, and the input's for the stride-2 modes."""
-    if mode == TEMPORAL:
-        T, Pp, Cin = x.shape
-        return T, 1, Pp, Cin, 0, 0
+    if mode == TEMPORAL:      # [T, pixels, C], or [samples, T, pixels, C]: frames, samples, pixels per frame
+        T, Pp, Cin = x.shape[-3:]
+        return T, (x.shape[0] if x.dim() == 4 else 1), Pp, Cin, 0, 0
     N, Hin, Win, Cin = x.shape
     if mode == SPATIAL:
         return N, (2 * Hin if upsample else Hin), (2 * Win if upsample else Win), Cin, 0, 0
@@ -258,11 +260,11 @@ def _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, st
     BN, _, _ = config(mode, N, H, W, Cin + pad, Cout)
     wpk = packed(weight, BN, False, pad, x.dtype)
     b32 = None if bias is None else ops._f32_param(bias)
-    n_norm = 1 if mode == TEMPORAL else N
+    n_norm = H if mode == TEMPORAL else N
     if ns is not None and (ns.C != Cin or ns.N != n_norm):
         raise RuntimeError(f"fused_conv: norm state is for {ns.N} x {ns.C} channels, input has {n_norm} x {Cin}")
     return _launch(x.contiguous(), wpk, Cout, mode, N, H, W, Cin + pad,
-                   coef_ptr=None if ns is None else ns.coef_ptr, coef_per_n=0 if mode == TEMPORAL else 1,
+                   coef_ptr=None if ns is None else ns.coef_ptr, coef_per_n=1,
                    silu=silu, bias=b32, add_nc=None if add_nc is None else add_nc.contiguous(),
                    residual=None if residual is None else residual.contiguous(), stats_groups=stats_groups,
                    upsample=NEAREST if upsample else 0, H_in=H_in, W_in=W_in)
@@ -353,6 +355,9 @@ def _reference(x, weight, bias, mode, upsample, gn, silu, add_nc, residual, n_st
                      padding=0 if mode == STRIDE2_PAD_HI else 1).permute(0, 2, 3, 1)
         if add_nc is not None:
             y = y + add_nc.to(y.dtype)[:, None, None, :]
+    elif x.dim() == 4:                                                             # [samples, T, P, C]
+        xi = x.permute(0, 3, 1, 2)[..., None]                                      # [S, C, T, P, 1]
+        y = F.conv3d(xi, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1)
     else:
         xi = x.permute(2, 0, 1)[None, :, :, :, None]                              # [1, C, T, P, 1]
         y = F.conv3d(xi, weight.to(x.dtype), None if bias is None else bias.to(x.dtype), padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0)
@@ -377,7 +382,7 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
             raise RuntimeError(f"fused_conv: unsupported dtype {x.dtype}")
         if on_dev:
             ops._torch_form("fused_conv", f"dtype {x.dtype}")
-        n_stat = n_stat if n_stat is not None else (1 if mode == TEMPORAL else x.shape[0])
+        n_stat = n_stat if n_stat is not None else ((x.shape[0] if x.dim() == 4 else 1) if mode == TEMPORAL else x.shape[0])
         return _reference(x, conv.weight, conv.bias, mode, upsample, gn, silu, add_nc, residual, n_stat), None
     if torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)):
         raise RuntimeError("fused_conv: only the input gradient is implemented (freeze the weights)")
@@ -386,7 +391,7 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
                            "or differentiate w.r.t. x only, as the guided sampler does")
     ns = None
     if gn is not None:
-        n_stat = n_stat if n_stat is not None else (1 if mode == TEMPORAL else x.shape[0])
+        n_stat = n_stat if n_stat is not None else ((x.shape[0] if x.dim() == 4 else 1) if mode == TEMPORAL else x.shape[0])
         ns = norm if norm is not None else norm_state(gn, x=x.detach(), n_stat=n_stat, group=group, S_total=S_total)
     need_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))
     if need_grad:
@@ -396,7 +401,7 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
         part = None
         if stats_groups:
             N = x.shape[0]
-            S = out.shape[0] * out.shape[1] if mode == TEMPORAL else out.shape[1] * out.shape[2]
+            S = out.shape[-3] * out.shape[-2] if mode == TEMPORAL else out.shape[1] * out.shape[2]
             part = PartialStats(res[1], STATS_REPLICAS, res[1].shape[1], stats_groups, S)
         return out, part
     return _run_forward(x, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, residual, stats_groups)

@@ -339,7 +339,7 @@ class TemporalConvBlock(nn.Module):
         return out
 
     def _forward_tokens_fused(self, tok, b, stats=None):
-        """Four launches of the temporal MFMA kernel per sample: GroupNorm+SiLU in the operand load, the identity add in the
+        """Four launches of the temporal MFMA kernel (all samples of the batch in each): GroupNorm+SiLU in the operand load, the identity add in the
         last epilogue, and each convolution leaves the statistics its successor's norm needs (openaimodel3d.py:270-278).
         Frame-sharded (parallel.py): the block works on [all T, this rank's pixels] between one all-to-all each way, and
         the per-video norm statistics are completed across the shard group by a 2 G-double all-reduce per norm."""
@@ -350,21 +350,24 @@ class TemporalConvBlock(nn.Module):
             group, total = shard.group, shard.T * hh * ww
             samples = [x_all]
         else:
+            # all samples of the batch in ONE launch per convolution ([b, T, pixels, c]: the samples are extra pixel tiles; the 5-D
+            # norms and the statistics stay per sample) -- the batch-2 CFG pair at 320x448 launches 140-1100 workgroups per
+            # convolution instead of twice 70-560, and no per-sample split / concatenation nodes exist under autograd
             T = bt // b
             group = total = None
-            samples = [tk.reshape(T, hh * ww, c) for tk in (_SplitSamples.apply(tok, b) if b > 1 and tok.requires_grad else
-                                                            [tok[bi * T:(bi + 1) * T] for bi in range(b)])]
+            samples = [tok.reshape(b, T, hh * ww, c) if b > 1 else tok.reshape(T, hh * ww, c)]
         outs = []
         for x0 in samples:
-            h, part = x0, (stats if b == 1 else None)
+            h, part = x0, (stats if (shard is None or b == 1) else None)
             cell = _cell(x0)          # x0 feeds conv1's norm and the closing identity add
             seqs = (self.conv1, self.conv2, self.conv3, self.conv4)
+            n_stat = b if (shard is None and b > 1) else 1
             for k, seq in enumerate(seqs):
                 gn, conv = seq[0], seq[-1]
                 if part is None:
-                    ns = mconv.norm_state(gn, x=h.detach(), n_stat=1, group=group, S_total=total)
+                    ns = mconv.norm_state(gn, x=h.detach(), n_stat=n_stat, group=group, S_total=total)
                 else:  # per-frame sums of a 2-D producer merge into the per-video statistics of this 5-D norm
-                    ns = mconv.norm_state(gn, partial=part, merge=part.N, group=group, S_total=total)
+                    ns = mconv.norm_state(gn, partial=part, merge=part.N // n_stat, group=group, S_total=total)
                 last = k == len(seqs) - 1
                 h, part = mconv.fused_conv(h, conv, mode=mconv.TEMPORAL, gn=gn, norm=ns, silu=True,
                                            residual=x0 if last else None, stats_groups=0 if last else gn.num_groups,
@@ -372,8 +375,7 @@ class TemporalConvBlock(nn.Module):
             outs.append(h)
         if shard is not None:
             return parallel.pixels_to_frames(outs[0], shard, hh * ww).reshape(bt, hh, ww, c)
-        out = outs[0] if b == 1 else torch.cat(outs, 0)
-        return out.reshape(bt, hh, ww, c)
+        return outs[0].reshape(bt, hh, ww, c)
 
     def forward_tokens(self, tok, b, stats=None):  # tok [(b t), H, W, C] contiguous
         if _fused(tok, self):

@@ -148,7 +148,9 @@ int gvd_layer_norm_bwd_add(const void* x, const void* dy, const void* gamma, con
  *        derived (pass 0).  upsample = 1: H_in = H/2, W_in = W/2 and the input is nearest-upsampled x2 on the fly (Upsample,
  *        openaimodel3d.py:80-106); upsample = 2: the input is ZERO-STUFFED x2 (odd rows / columns are zero) -- with the
  *        transposed, tap-flipped weights this is the input gradient of a stride-2 convolution.
- * mode 1 (temporal 3 taps, pad 1 in t):   x [T = N][W = pixels][Cin], out [T][pixels][Cout]; H must be 1; batch 1.
+ * mode 1 (temporal 3 taps, pad 1 in t):   x [H = samples][T = N][W = pixels][Cin], out [samples][T][pixels][Cout] (H = 1: one
+ *        video).  The (3,1,1) convolution treats pixels independently, so the samples of a batch (the CFG pair) are extra pixel
+ *        tiles of ONE launch; coef (coef_per_n = 1: [samples][Cin]) and the statistics stay per sample.
  * mode 2 (spatial 3x3, stride 2, pad 1: U-Net Downsample, openaimodel3d.py:51-77) and
  * mode 3 (spatial 3x3, stride 2 on an input padded by one zero row / column at the bottom / right only: VAE Downsample,
  *        ae_modules.py:90-109):  x [N][H_in][W_in][Cin] with H = (H_in + pad_lo - 2) / 2 + 1 (pad_lo = 1 / 0), same for W.
@@ -161,7 +163,7 @@ int gvd_layer_norm_bwd_add(const void* x, const void* dy, const void* gamma, con
  * bias fp32 [Cout] | NULL;  add_nc 16-bit [N][Cout] | NULL (mode 0 only: ResBlock `h + emb_out[:, :, None, None]`);
  * residual: 16-bit, layout of out | NULL.
  * stats: NULL, or fp64 accumulators [stats_replicas][Nstat][groups][2] (zeroed by the caller) that receive the sum and
- *        sum of squares of the ROUNDED outputs per (sample, group) -- Nstat = N in mode 0, 1 in mode 1 -- i.e. the first pass
+ *        sum of squares of the ROUNDED outputs per (sample, group) -- Nstat = N in mode 0, the samples H in mode 1 -- i.e. the first pass
  *        of the next GroupNorm, spread over `stats_replicas` copies to keep the atomics apart (block b adds to copy b % R).
  * Cin % 8 == 0.  16-bit element type: fp16 or bf16 (is_bf16), fp32 accumulation either way. */
 int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
