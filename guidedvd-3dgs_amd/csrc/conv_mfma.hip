@@ -49,6 +49,15 @@ using namespace gvdd;
 
 namespace {
 
+#ifdef GVD_CONV_TRACE
+// experiments (tests/scripts/r4_conv_trace.py): s_memtime stamps of the first 2048 workgroups' wave 0 -- start, first barrier (staging of
+// chunk 0 done), end of the K loop, end of the epilogue -- plus the XCC / CU the workgroup ran on
+__device__ unsigned long long g_ctrace[2048 * 6];
+#define GVD_CSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048) g_ctrace[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GVD_CSTAMP(i) do { } while (0)
+#endif
+
 struct ConvArgs {
     const void* x;        // input activations
     const void* w;        // packed weights
@@ -138,6 +147,16 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     // (the launcher sizes the dynamic LDS as the larger of the main-loop buffers and this epilogue staging: lds_bytes())
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    GVD_CSTAMP(0);
+#ifdef GVD_CONV_TRACE
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_ctrace[blockIdx.x * 6 + 4] = hwid;
+        g_ctrace[blockIdx.x * 6 + 5] = xcc;
+    }
+#endif
     unsigned char* const wbuf = lds;                    // [2][WBYTES]
     unsigned char* const pbuf = lds + 2 * WBYTES;       // [2][PBYTES]
 
@@ -374,6 +393,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         }
         if (++tap == NTAPS) { tap = 0; chunk++; }
     };
+    GVD_CSTAMP(1);
     if constexpr (NSET == 2) {
         int it = 0;
         for (; it + 1 < total; it += 2) { step(it, H0{}); step(it + 1, H1{}); }
@@ -427,6 +447,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         }
     }
     __syncthreads();   // all operand reads retired: the LDS is reused by the epilogue
+    GVD_CSTAMP(2);
 
     // ---- epilogue ----
     unsigned char* const ep = lds;                                         // [EP_PIX][EP_PITCH] fp32
@@ -456,7 +477,39 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         ? reinterpret_cast<const float4*>(a.bcoef + (a.bcoef_per_n ? (size_t)n * Cout : 0) + cout0) : nullptr;
 
     constexpr int NPASS = PIX / EP_PIX;
+    // Rows of a pass this thread finishes: pl = prow + k EP_ROWS.  Their residual / norm-input octets are fetched BEFORE the pass's
+    // accumulators go through LDS (unconditional loads, clamped addresses), so the HBM / L2 round trip sits under the staging and its
+    // barrier instead of in front of every row: a tile of the VAE's 128-channel stage made 16 such dependent trips (~0.7 us each
+    // against ~10 us of matrix work; the residual form cost +10 %, the norm-backward form +37 % -- tests/scripts/r4_conv_ablate.py).
+    constexpr int NROW = (EP_PIX + EP_ROWS - 1) / EP_ROWS;
+    constexpr bool PREFETCH = MI <= 4;   // (the 5-block tiles have no registers to spare next to their 160 accumulators)
+    auto row_geometry = [&](int pass, int pl, bool& valid, size_t& off) {
+        const int m = pass * EP_PIX + pl;
+        if (MODE == 2) {
+            const int tt = m / PB, pp = m - tt * PB;
+            valid = tt < a.N && p0 + pp < a.W;
+            off = sample_out + ((size_t)tt * a.W + p0 + pp) * Cout;
+        } else {
+            const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
+            valid = ty0 + ty < a.H && tx0 + tx < a.W;
+            off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
+        }
+        valid = valid && pl < EP_PIX;
+    };
     for (int pass = 0; pass < NPASS; pass++) {
+        vec8 pre[PREFETCH ? NROW : 1];   // (a launch has a residual OR a norm input, never both: gvd_conv_mfma / gvd_conv_mfma_norm_bwd)
+        if constexpr (PREFETCH) {
+            const T* __restrict__ psrc = res ? res : bx;
+            if (ep_thread && full_oct && psrc) {
+#pragma unroll
+                for (int k = 0; k < NROW; k++) {
+                    bool valid;
+                    size_t off;
+                    row_geometry(pass, prow + k * EP_ROWS, valid, off);
+                    pre[k] = *reinterpret_cast<const vec8*>(psrc + (valid ? off : 0) + cout0);
+                }
+            }
+        }
         // accumulators of this pass's pixel blocks -> LDS [pixel][channel] fp32 (a lane owns 4 consecutive channels per quad)
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
@@ -478,19 +531,13 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         }
         __syncthreads();
         if (ep_thread) {
-            for (int pl = prow; pl < EP_PIX; pl += EP_ROWS) {
-                const int m = pass * EP_PIX + pl;
+#pragma unroll(PREFETCH ? NROW : 1)
+            for (int k = 0; k < NROW; k++) {
+                const int pl = prow + k * EP_ROWS;
+                if (pl >= EP_PIX) break;
                 bool valid;
                 size_t off;
-                if (MODE == 2) {
-                    const int tt = m / PB, pp = m - tt * PB;
-                    valid = tt < a.N && p0 + pp < a.W;
-                    off = sample_out + ((size_t)tt * a.W + p0 + pp) * Cout;
-                } else {
-                    const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
-                    valid = ty0 + ty < a.H && tx0 + tx < a.W;
-                    off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
-                }
+                row_geometry(pass, pl, valid, off);
                 if (!valid || cout0 >= Cout) continue;
                 // a thread reads 32 contiguous bytes as two ds_read_b128; threads oct and oct + 8 of a 16-lane read group are 256
                 // bytes apart (the same banks), so the upper eight read their halves in the opposite order: the 2-way conflict on
@@ -507,9 +554,9 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 vec8 o;
                 if (full_oct) {
                     vec8 rv = vec8{};
-                    if (res) rv = *reinterpret_cast<const vec8*>(res + off + cout0);
+                    if (res) rv = PREFETCH ? pre[PREFETCH ? k : 0] : *reinterpret_cast<const vec8*>(res + off + cout0);
                     if (bx) {   // wave-uniform (kernel argument): sums of dz and dz * x, dz = d_out * silu'(a x + b); gamma applied per column below
-                        const vec8 xv = *reinterpret_cast<const vec8*>(bx + off + cout0);
+                        const vec8 xv = PREFETCH ? pre[PREFETCH ? k : 0] : *reinterpret_cast<const vec8*>(bx + off + cout0);
                         float sg[8];
 #pragma unroll
                         for (int j = 0; j < 8; j++) sg[j] = 1.f;
@@ -556,6 +603,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         __syncthreads();
     }
 
+    GVD_CSTAMP(3);
     // ---- GroupNorm statistics of the (rounded) outputs for the next norm ----
     if (a.stats) {
         if (ep_thread) {
@@ -730,6 +778,8 @@ void choose(int mode, int N, int H, int W, int Cout, int* cfg, int* tw32)
     // small problems (the 9x16 level, the 72x128 VAE stage, the temporal form at 144 pixels): the big tiles launch fewer
     // workgroups than the chip has CU slots (2 x 256) -- take the 128 x 128 tile when it at least fills one slot per CU better
     if (mode < 2 && Cout >= 128 && c != 4 && groups(c) < 384 && groups(4) > groups(c)) c = 4;
+    static const int forced = [] { const char* e = getenv("GVD_CONV_FORCE_CFG"); return e ? atoi(e) : -1; }();   // experiments: one tile configuration for every stride-1 launch with Cout > 32
+    if (forced >= 0 && forced <= 4 && forced != 3 && mode < 2 && Cout > 32) c = forced;
     *cfg = c;
     *tw32 = 1;
     if (mode == 0) *tw32 = width32(CFG_PIX[c]);
@@ -833,6 +883,13 @@ int gvd_conv_mfma_norm_bwd(const void* g, const void* w_packed_bwd, void* d_act,
     return conv_launch(g, w_packed_bwd, nullptr, 0, nullptr, nullptr, nullptr, d_act, bwd_stats, stats_replicas, groups, mode, N, H, W,
                        0, 0, Cin, Cout, 0, 0, is_bf16, stream, norm_x, norm_coef, norm_coef_per_n, norm_gamma, norm_silu);
 }
+
+#ifdef GVD_CONV_TRACE
+int gvd_conv_trace_read(unsigned long long* host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ctrace), sizeof(unsigned long long) * (n < 2048 * 6 ? n : 2048 * 6)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int gvd_group_norm_merge(double* stats, const double* partial, int replicas, int merge, int N, int G, void* stream_)
 {

@@ -281,20 +281,6 @@ class TemporalTransformer(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # convolutional side (openaimodel3d.py)
 # ------------------------------------------------------------------------------------------------
-class _SplitSamples(torch.autograd.Function):
-    """[(b t), ...] -> b views [t, ...].  Under autograd plain slices would each bring a zero-fill of the WHOLE tensor, a copy of the
-    slice's gradient into it and an accumulation add between the b results; this node's backward is one concatenation."""
-
-    @staticmethod
-    def forward(ctx, tok, b):
-        T = tok.shape[0] // b
-        return tuple(tok[i * T:(i + 1) * T] for i in range(b))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        return torch.cat(grads, 0), None
-
-
 class TemporalConvBlock(nn.Module):
     """openaimodel3d.py:239-279: 4 x [GN32 -> SiLU -> (Dropout) -> Conv3d k=(3,1,1) pad (1,0,0)] + identity.
 

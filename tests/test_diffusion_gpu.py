@@ -380,9 +380,9 @@ def test_layer_norm_and_geglu_input_gradients_match_fp32_autograd(dtype, M, C):
 def test_batch_two_unet_evaluation_matches_two_single_sample_calls():
     """The batched CFG pair (samplers._batched_pair): one batch-2 evaluation of the fp16 token-major U-Net against two batch-1
     evaluations, forward and input gradient.  Every layer is per sample; the temporal attention loops the samples inside its autograd
-    node (ops._PackedSelfAttention on [b, T, pixels, 3 C]) and the temporal convolution blocks split them with one node
-    (unet._SplitSamples) -- so the graph has no per-sample select / slice / stack nodes.  Agreement is to fp16 rounding (the batch-2
-    launches tile differently), not bitwise."""
+    node (ops._PackedSelfAttention on [b, T, pixels, 3 C]) and the temporal convolution blocks take all samples in ONE launch per
+    convolution ([b, T, pixels, C]: the samples are extra pixel tiles, norms / statistics per sample) -- so the graph has no
+    per-sample select / slice / split / stack / cat nodes.  Agreement is to fp16 rounding (the batch-2 launches tile differently), not bitwise."""
     from lvdm_amd.model import DiffusionWrapper
     from lvdm_amd.unet import UNetModel
     cfg = dict(in_channels=8, out_channels=4, model_channels=64, attention_resolutions=[1, 2], num_res_blocks=1,
@@ -422,8 +422,7 @@ def test_batch_two_unet_evaluation_matches_two_single_sample_calls():
             stack.extend(n_ for n_, _ in node.next_functions)
         (gx,) = torch.autograd.grad((e1.float() * probe).sum() + 0.7 * (e2.float() * probe).sum(), xs)
         res[name] = (e1.detach().float(), e2.detach().float(), gx.detach(), names)
-    assert not ({"SelectBackward0", "StackBackward0"} & res["one"][3]), res["one"][3]
-    assert "_SplitSamplesBackward" in res["one"][3] and "_SplitSamplesBackward" not in res["two"][3]
+    assert not ({"SelectBackward0", "StackBackward0", "_SplitSamplesBackward", "SliceBackward0"} & res["one"][3]), res["one"][3]
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     assert rel(res["one"][0], res["two"][0]) < 4e-3 and rel(res["one"][1], res["two"][1]) < 4e-3
     assert rel(res["one"][2], res["two"][2]) < 6e-3
