@@ -38,6 +38,9 @@
 
 #include "diffusion_common.h"
 
+#ifndef GVD_CONV_WHOLE
+#define GVD_CONV_WHOLE 1    // temporal form: fetch the whole next patch at tap 0, write it at tap 2 (0 = the two-halves schedule, for A/B builds)
+#endif
 #ifndef GVD_CONV_WPF
 #define GVD_CONV_WPF 2   // weight-slab prefetch distance in loop steps (1 = the round-2/3 kernel, for A/B builds)
 #endif
@@ -229,7 +232,13 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     // The next chunk's patch is fetched and written in two halves (pieces [0, PH0) then [PH0, PPT)) so that at most half of
     // the staging registers are live next to the 160 accumulators.
     constexpr int PH0 = (PPT + 1) / 2;
-    vec8 preg[PH0];
+    // Temporal form (3 taps per chunk): the WHOLE next patch is fetched at tap 0 and written at tap 2 -- with the two-halves schedule
+    // (fetch at tap 0 / write at tap 1 + fetch, write at tap 2) two of every three loop steps waited out a full memory round trip
+    // (~1400 clocks against 256-640 clocks of matrix work per step: the timeline of tests/scripts/r4_conv_trace.py), which is what
+    // held every temporal launch at 150-600 TFLOP/s.  It costs PPT - PH0 (1-2) more staging registers x 4.
+    constexpr bool WHOLE = (MODE == 2) && GVD_CONV_WHOLE;
+    constexpr int NPREG = WHOLE ? PPT : PH0;
+    vec8 preg[NPREG];
     float2 cf[8];
     bool chan_ok = false;
     // NOTE on the staging loads: every global load below is UNCONDITIONAL (out-of-image / out-of-range pieces read a valid
@@ -255,7 +264,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         const int c0s = c0 < Cin ? c0 : 0;
 #pragma unroll
         for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++)
-            preg[i - HALF * PH0] = *reinterpret_cast<const vec8*>(x + (size_t)(goff[i] >= 0 ? goff[i] : 0) + c0s);
+            preg[WHOLE ? i : i - HALF * PH0] = *reinterpret_cast<const vec8*>(x + (size_t)(goff[i] >= 0 ? goff[i] : 0) + c0s);
     };
     auto store_p = [&](int buf, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
@@ -263,7 +272,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 #pragma unroll
         for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++) {
             if (loff[i] < 0) continue;
-            vec8 v = preg[i - HALF * PH0];
+            vec8 v = preg[WHOLE ? i : i - HALF * PH0];
             const bool ok = goff[i] >= 0 && chan_ok;
             if (coef) {
 #pragma unroll
@@ -352,7 +361,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         if (NSET == 2) { if (it + 2 < total) load_w(it + 2, set_tag); }
         else if (more_w) load_w(it + 1, Other{});
         if (more_p) {
-            if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); }
+            if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); if (WHOLE) load_p(chunk + 1, H1{}); }
         }
 
         const int cur = NSET == 2 ? SET : (it & 1);          // LDS weight buffer holding slab `it`
@@ -388,8 +397,12 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 
         if (more_w) store_w(cur ^ 1, Other{});
         if (more_p) {
-            if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
-            if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
+            if (WHOLE) {
+                if (tap == T_S1) { store_p((chunk + 1) & 1, H0{}); store_p((chunk + 1) & 1, H1{}); }
+            } else {
+                if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
+                if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
+            }
         }
         if (++tap == NTAPS) { tap = 0; chunk++; }
     };
@@ -405,7 +418,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
             const bool more_w = it + 1 < total, more_p = chunk + 1 < a.nchunks;
             if (more_w) load_w(it + 1, H0{});
             if (more_p) {
-                if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); }
+                if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); if (WHOLE) load_p(chunk + 1, H1{}); }
             }
 
             const unsigned char* wb = wbuf + (it & 1) * WBYTES;
@@ -440,8 +453,12 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 
             if (more_w) store_w((it + 1) & 1, H0{});
             if (more_p) {
-                if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
-                if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
+                if (WHOLE) {
+                    if (tap == T_S1) { store_p((chunk + 1) & 1, H0{}); store_p((chunk + 1) & 1, H1{}); }
+                } else {
+                    if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
+                    if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
+                }
             }
             if (++tap == NTAPS) { tap = 0; chunk++; }
         }
