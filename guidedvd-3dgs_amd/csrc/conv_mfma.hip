@@ -41,12 +41,9 @@
 #ifndef GVD_CONV_WHOLE
 #define GVD_CONV_WHOLE 1    // temporal form: fetch the whole next patch at tap 0, write it at tap 2 (0 = the two-halves schedule, for A/B builds)
 #endif
-#ifndef GVD_CONV_WPF
-#define GVD_CONV_WPF 2   // weight-slab prefetch distance in loop steps (1 = the round-2/3 kernel, for A/B builds)
-#endif
 #ifndef GVD_CONV_DBG
-#define GVD_CONV_DBG 0   // experiments only (tests/scripts/run_conv_lds_hunt.sh): 1 = no patch ds_writes in the loop, 2 = no weight ds_writes in the loop,
-#endif                   // 4 = no epilogue staging writes, 8 = no epilogue staging reads, 16 = no MFMA operand reads of the patch, 32 = ... of the weights
+#define GVD_CONV_DBG 0   // experiments only (round 3, profiles/r03_conv_lds_hunt.txt; the in-loop bits 1 / 2 / 16 / 32 went with the round-4 loop):
+#endif                   // 4 = no epilogue staging writes, 8 = no epilogue staging reads
 
 using namespace gvdd;
 
@@ -125,13 +122,14 @@ template <int MI, int NI, int WM, int WN, int MODE>
 constexpr int lds_bytes()
 {
     constexpr int BN = WM * MI * 32, PIX = WN * NI * 32;
-    constexpr int main_loop = 2 * BN * 64 + 2 * ((Geo<MODE, PIX>::PATCH_BYTES + 15) & ~15);
+    constexpr int main_loop = 2 * BN * 64 + 2 * ((Geo<MODE, PIX>::PATCH_BYTES + 15) & ~15) + 16;   // (+ the dummy slot)
     constexpr int ep_pix = (BN > 160) ? 32 : (BN > 32 ? 64 : PIX);
     constexpr int epilogue = ep_pix * (BN * 4 + 16) + 2 * (256 / (BN / 8)) * BN * 4;
     return main_loop > epilogue ? main_loop : epilogue;
 }
 
-template <typename T, int MI, int NI, int WM, int WN, int MODE>
+// PRO: the fused prologue is a template argument, not a branch in the loop (0: plain, 1: GroupNorm affine, SiLU by a select)
+template <typename T, int MI, int NI, int WM, int WN, int MODE, int PRO>
 __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const ConvArgs a)   // (stride 2: one workgroup per CU, its patch fills the LDS)
 {
     typedef typename Tr<T>::vec8 vec8;
@@ -229,95 +227,81 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     }
     const float2* __restrict__ coef = a.coef ? a.coef + (a.coef_per_n ? (size_t)n * Cin : 0) : nullptr;
 
-    // The next chunk's patch is fetched and written in two halves (pieces [0, PH0) then [PH0, PPT)) so that at most half of
-    // the staging registers are live next to the 160 accumulators.
-    constexpr int PH0 = (PPT + 1) / 2;
-    // Temporal form (3 taps per chunk): the WHOLE next patch is fetched at tap 0 and written at tap 2 -- with the two-halves schedule
-    // (fetch at tap 0 / write at tap 1 + fetch, write at tap 2) two of every three loop steps waited out a full memory round trip
-    // (~1400 clocks against 256-640 clocks of matrix work per step: the timeline of tests/scripts/r4_conv_trace.py), which is what
-    // held every temporal launch at 150-600 TFLOP/s.  It costs PPT - PH0 (1-2) more staging registers x 4.
-    constexpr bool WHOLE = (MODE == 2) && GVD_CONV_WHOLE;
+    // ---- staging + main loop --------------------------------------------------------------------------------------------------
+    // STRAIGHT-LINE by construction (round 4).  The loop over a chunk's taps is unrolled, so "which tap fetches / writes the next
+    // patch" is resolved at compile time; every global load and LDS store of the loop is UNCONDITIONAL (the last step re-fetches the
+    // last slab / patch, pieces past the end of a stage go to a dummy LDS slot); the GroupNorm(+SiLU) prologue is a template argument
+    // of the loop, not a branch in it.  Why: hipcc's s_waitcnt insertion counts outstanding loads exactly only along straight-line
+    // code.  With `if (more_w) load`, `if (tap == T_L0) load`, `if (coef)`, `if (loff < 0) continue` in the body (rounds 2-3) the ISA
+    // had `s_waitcnt vmcnt(0)` in front of every weight fetch and behind the coefficient fetch of every chunk -- each loop step waited
+    // out a whole memory round trip (~1300 clocks per step against 256-640 clocks of matrix work: tests/scripts/r4_conv_trace.py),
+    // hidden only as far as the CU's second workgroup could fill in.
+    constexpr int PH0 = (PPT + 1) / 2;     // the next patch travels in two halves (pieces [0, PH0), [PH0, PPT)): half the staging registers
+    constexpr bool WHOLE = (MODE == 2) && GVD_CONV_WHOLE;   // temporal (3 taps): whole patch fetched at tap 0, written at tap 2
     constexpr int NPREG = WHOLE ? PPT : PH0;
     vec8 preg[NPREG];
-    float2 cf[8];
+    float4 cfr[4];                         // (a, b) pairs of this thread's 8 channels of the next chunk, as loaded (no repacking: a
+                                           // register move right behind the load would wait for it)
     bool chan_ok = false;
-    // NOTE on the staging loads: every global load below is UNCONDITIONAL (out-of-image / out-of-range pieces read a valid
-    // dummy address and are zeroed or dropped at store time).  A per-piece `cond ? load : 0` makes hipcc branch around each
-    // load and wait vmcnt(0) in between -- the loads of a stage then complete one L2 round trip after the other instead of
-    // all being in flight together (measured: the first version of this kernel).
+    unsigned char* const dummy = lds + 2 * WBYTES + 2 * PBYTES;   // 16-byte slot for the stores of pieces past the end of a stage
+#pragma unroll
+    for (int i = 0; i < PPT; i++) loff[i] = loff[i] < 0 ? 2 * PBYTES : loff[i];      // (relative to pbuf: pbuf + 2 PBYTES == dummy)
     auto load_cf = [&](int chunk) {
         const int c0 = chunk * BK + k8 * 8;
-        chan_ok = c0 < Cin;
-        if (coef) {   // wave-uniform (kernel argument)
-            const float4* cp = reinterpret_cast<const float4*>(coef + (chan_ok ? c0 : 0));
+        const float4* cp = reinterpret_cast<const float4*>(coef + (c0 < Cin ? c0 : 0));
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4 v = cp[j];
-                cf[2 * j] = make_float2(v.x, v.y);
-                cf[2 * j + 1] = make_float2(v.z, v.w);
-            }
-        }
+        for (int j = 0; j < 4; j++) cfr[j] = cp[j];
     };
     auto load_p = [&](int chunk, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
         const int c0 = chunk * BK + k8 * 8;
         const int c0s = c0 < Cin ? c0 : 0;
+        if (HALF == 0) chan_ok = c0 < Cin;       // (both halves of a patch are written before the next patch's first half is fetched)
 #pragma unroll
         for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++)
             preg[WHOLE ? i : i - HALF * PH0] = *reinterpret_cast<const vec8*>(x + (size_t)(goff[i] >= 0 ? goff[i] : 0) + c0s);
     };
+    const bool do_silu = a.silu != 0;
     auto store_p = [&](int buf, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
         unsigned char* pb = pbuf + buf * PBYTES;
 #pragma unroll
         for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++) {
-            if (loff[i] < 0) continue;
+            if (PRO && MI >= 5) __builtin_amdgcn_sched_barrier(0);   // (one piece at a time: interleaved, their fp32 temporaries spill the 5-block tiles)
             vec8 v = preg[WHOLE ? i : i - HALF * PH0];
             const bool ok = goff[i] >= 0 && chan_ok;
-            if (coef) {
+            if (PRO) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    float f = fmaf((float)v[j], cf[j].x, cf[j].y);
-                    if (a.silu) f = silu32(f);
-                    v[j] = (T)f;
+                    const float4 ab = cfr[j >> 1];
+                    const float f = (j & 1) ? fmaf((float)v[j], ab.z, ab.w) : fmaf((float)v[j], ab.x, ab.y);
+                    v[j] = (T)(do_silu ? silu32(f) : f);      // (a select, not a branch: every norm on this path carries SiLU)
                 }
             }
             if (!ok) v = vec8{};   // conv zero padding applies to the ACTIVATED tensor (and dummy reads are dropped here)
-#if GVD_CONV_DBG & 1
-            if (buf < 2 && v[0] == (T)123.456f)
-#endif
-            *reinterpret_cast<vec8*>(pb + loff[i]) = v;
+            *reinterpret_cast<vec8*>((loff[i] == 2 * PBYTES ? pbuf : pb) + loff[i]) = v;
         }
     };
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
 
-    // ---- weight staging (linear copy of the pre-swizzled slab) ----
-    // Slab it + 2 is fetched while slab it is multiplied (two register sets, the loop below is unrolled by two): with the fetch only
-    // ONE step ahead every step waited out a full L2 / fabric round trip behind its 16-40 MFMAs whenever a CU held a single
-    // workgroup -- the under-filled launches of the small levels (the 5x7 / 10x14 latents of a 320x448 video: 40-280 workgroups on
-    // 256 CUs) ran at 0.9 us per step against 0.13 us of matrix work.
+    // ---- weight staging (linear copy of the pre-swizzled slab), one step ahead ----
     const T* __restrict__ wt = (const T*)a.w + (size_t)co_tile * a.nchunks * NTAPS * (BN * BK);
-    constexpr int NSET = (MI >= 5) ? 1 : GVD_CONV_WPF;   // (the 5-block tiles sit at the 256-register cap: one set, fetch one step ahead)
-    vec8 wreg[NSET][WPT];
-    auto load_w = [&](int it, auto set_tag) {
-        constexpr int SET = NSET == 2 ? decltype(set_tag)::value : 0;
-        const T* src = wt + (size_t)it * (BN * BK);
+    const int total = a.nchunks * NTAPS;
+    vec8 wreg[WPT];
+    auto load_w = [&](int it) {
+        const T* src = wt + (size_t)(it < total ? it : total - 1) * (BN * BK);
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int q = tid + i * 256;
-            wreg[SET][i] = *reinterpret_cast<const vec8*>(src + (q < NWP ? q : NWP - 1) * 8);   // unconditional (see the note above)
+            wreg[i] = *reinterpret_cast<const vec8*>(src + (q < NWP ? q : NWP - 1) * 8);
         }
     };
-    auto store_w = [&](int buf, auto set_tag) {
-        constexpr int SET = NSET == 2 ? decltype(set_tag)::value : 0;
+    auto store_w = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int q = tid + i * 256;
-#if GVD_CONV_DBG & 2
-            if (wreg[SET][i][0] == (T)123.456f)
-#endif
-            if (q < NWP) *reinterpret_cast<vec8*>(wbuf + buf * WBYTES + q * 16) = wreg[SET][i];
+            *reinterpret_cast<vec8*>(q < NWP ? wbuf + buf * WBYTES + q * 16 : dummy) = wreg[i];
         }
     };
     // ---- MFMA operand addresses ----
@@ -340,127 +324,63 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) acc[mi][ni] = f16v{};
 
-    const int total = a.nchunks * NTAPS;
-    load_w(0, H0{});
-    load_cf(0);
-    load_p(0, H0{});
-    store_w(0, H0{});
-    if (NSET == 2 && total > 1) load_w(1, H1{});
-    store_p(0, H0{});
-    load_p(0, H1{});
-    store_p(0, H1{});
-    int chunk = 0, tap = 0;
-    // taps at which the next chunk's patch halves are fetched / written (3-tap temporal form: everything one tap apart)
+    // taps at which the next chunk's patch halves are fetched / written (two-halves schedule)
     constexpr int T_L0 = NTAPS >= 9 ? NTAPS - 4 : 0, T_S0 = NTAPS >= 9 ? NTAPS - 3 : 1, T_S1 = NTAPS - 1;
-    // one step; SET = it & 1: slab it + 2 goes into the register set slab it came from, slab it + 1 is written from the other set
-    auto step = [&](int it, auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
-        typedef std::integral_constant<int, SET ^ 1> Other;
-        __syncthreads();
-        const bool more_w = it + 1 < total, more_p = chunk + 1 < a.nchunks;
-        if (NSET == 2) { if (it + 2 < total) load_w(it + 2, set_tag); }
-        else if (more_w) load_w(it + 1, Other{});
-        if (more_p) {
-            if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); if (WHOLE) load_p(chunk + 1, H1{}); }
-        }
-
-        const int cur = NSET == 2 ? SET : (it & 1);          // LDS weight buffer holding slab `it`
-        const unsigned char* wb = wbuf + cur * WBYTES;
-        int shift;
-        if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
-        else shift = tap * PB * PIX_BYTES;
-        const unsigned char* pb = pbuf + (chunk & 1) * PBYTES + shift;
+    {
+        load_w(0);
+        if (PRO) load_cf(0);
+        load_p(0, H0{});
+        if (WHOLE) load_p(0, H1{});
+        store_w(0);
+        store_p(0, H0{});
+        if (!WHOLE) load_p(0, H1{});
+        store_p(0, H1{});
+        GVD_CSTAMP(1);
+        const int last = a.nchunks - 1;
+        for (int chunk = 0; chunk < a.nchunks; chunk++) {
+            const int nxt = chunk < last ? chunk + 1 : last;      // (the last chunk re-fetches itself: never read)
+            const int pcur = chunk & 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            vec8 af[MI], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-#if GVD_CONV_DBG & 32
-                af[mi] = vec8{}; af[mi][0] = (T)(float)(it + mi);
-#else
-                af[mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048);
-#endif
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-#if GVD_CONV_DBG & 16
-                bf[ni] = vec8{}; bf[ni][0] = (T)(float)(it + ni);
-#else
-                bf[ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32);
-#endif
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
-        }
-
-        if (more_w) store_w(cur ^ 1, Other{});
-        if (more_p) {
-            if (WHOLE) {
-                if (tap == T_S1) { store_p((chunk + 1) & 1, H0{}); store_p((chunk + 1) & 1, H1{}); }
-            } else {
-                if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
-                if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
-            }
-        }
-        if (++tap == NTAPS) { tap = 0; chunk++; }
-    };
-    GVD_CSTAMP(1);
-    if constexpr (NSET == 2) {
-        int it = 0;
-        for (; it + 1 < total; it += 2) { step(it, H0{}); step(it + 1, H1{}); }
-        if (it < total) step(it, H0{});
-    } else {
-        // (the 5-block tiles: the round-2 loop as it was -- any restructuring of it costs them registers they do not have)
-        for (int it = 0; it < total; it++) {
-            __syncthreads();
-            const bool more_w = it + 1 < total, more_p = chunk + 1 < a.nchunks;
-            if (more_w) load_w(it + 1, H0{});
-            if (more_p) {
-                if (tap == T_L0) { load_cf(chunk + 1); load_p(chunk + 1, H0{}); if (WHOLE) load_p(chunk + 1, H1{}); }
-            }
-
-            const unsigned char* wb = wbuf + (it & 1) * WBYTES;
-            int shift;
-            if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
-            else shift = tap * PB * PIX_BYTES;
-            const unsigned char* pb = pbuf + (chunk & 1) * PBYTES + shift;
-    #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                vec8 af[MI], bf[NI];
-    #pragma unroll
-                for (int mi = 0; mi < MI; mi++) {
-    #if GVD_CONV_DBG & 32
-                    af[mi] = vec8{}; af[mi][0] = (T)(float)(it + mi);
-    #else
-                    af[mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048);
-    #endif
+            for (int tap = 0; tap < NTAPS; tap++) {
+                const int it = chunk * NTAPS + tap, wcur = it & 1;
+                __builtin_amdgcn_sched_barrier(0);   // (nothing moves between taps: the unrolled body must not be scheduled as one block --
+                __syncthreads();                     //  hoisting a later tap's loads over this one's MFMAs spills the big tiles)
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(it + 1);
+                if (tap == T_L0) {
+                    if (PRO) load_cf(nxt);
+                    load_p(nxt, H0{});
+                    if (WHOLE) load_p(nxt, H1{});
                 }
-    #pragma unroll
-                for (int ni = 0; ni < NI; ni++) {
-    #if GVD_CONV_DBG & 16
-                    bf[ni] = vec8{}; bf[ni][0] = (T)(float)(it + ni);
-    #else
-                    bf[ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32);
-    #endif
+                // (the fetches above stay above, the LDS writes below stay below: left alone, the machine scheduler sinks every
+                //  global load to right in front of the ds_write that consumes it -- shortest live range, whole latency exposed)
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* wb = wbuf + wcur * WBYTES;
+                int shift;
+                if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
+                else shift = tap * PB * PIX_BYTES;
+                const unsigned char* pb = pbuf + pcur * PBYTES + shift;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    vec8 af[MI], bf[NI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) bf[ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32);
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
                 }
-    #pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-    #pragma unroll
-                    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
-            }
-
-            if (more_w) store_w((it + 1) & 1, H0{});
-            if (more_p) {
+                __builtin_amdgcn_sched_barrier(0);
+                store_w(wcur ^ 1);
                 if (WHOLE) {
-                    if (tap == T_S1) { store_p((chunk + 1) & 1, H0{}); store_p((chunk + 1) & 1, H1{}); }
+                    if (tap == T_S1) { store_p(pcur ^ 1, H0{}); store_p(pcur ^ 1, H1{}); }
                 } else {
-                    if (tap == T_S0) { store_p((chunk + 1) & 1, H0{}); load_p(chunk + 1, H1{}); }
-                    if (tap == T_S1) store_p((chunk + 1) & 1, H1{});
+                    if (tap == T_S0) { store_p(pcur ^ 1, H0{}); load_p(nxt, H1{}); }
+                    if (tap == T_S1) store_p(pcur ^ 1, H1{});
                 }
             }
-            if (++tap == NTAPS) { tap = 0; chunk++; }
         }
     }
     __syncthreads();   // all operand reads retired: the LDS is reused by the epilogue
@@ -730,11 +650,11 @@ __global__ void __launch_bounds__(64) k_gn_merge_coef(const double* __restrict__
 // (Measured alternative, not kept: staging the weight slabs with LDS-DMA (global_load_lds) instead of through registers was
 //  within +-3 % on every U-Net / VAE shape -- two workgroups per CU already cover the ds_write pass.)
 
-template <typename T, int MI, int NI, int WM, int WN, int MODE>
-hipError_t launch_one(const ConvArgs& a, dim3 grid, hipStream_t stream)
+template <typename T, int MI, int NI, int WM, int WN, int MODE, int PRO>
+hipError_t launch_pro(const ConvArgs& a, dim3 grid, hipStream_t stream)
 {
     constexpr int smem = lds_bytes<MI, NI, WM, WN, MODE>();
-    auto kern = k_conv_mfma<T, MI, NI, WM, WN, MODE>;
+    auto kern = k_conv_mfma<T, MI, NI, WM, WN, MODE, PRO>;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -745,6 +665,12 @@ hipError_t launch_one(const ConvArgs& a, dim3 grid, hipStream_t stream)
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
     return hipGetLastError();
+}
+
+template <typename T, int MI, int NI, int WM, int WN, int MODE>
+hipError_t launch_one(const ConvArgs& a, dim3 grid, hipStream_t stream)
+{
+    return a.coef ? launch_pro<T, MI, NI, WM, WN, MODE, 1>(a, grid, stream) : launch_pro<T, MI, NI, WM, WN, MODE, 0>(a, grid, stream);
 }
 
 template <typename T, int MODE>
