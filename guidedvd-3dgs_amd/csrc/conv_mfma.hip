@@ -124,7 +124,10 @@ constexpr int lds_bytes()
     constexpr int BN = WM * MI * 32, PIX = WN * NI * 32;
     constexpr int main_loop = 2 * BN * 64 + 2 * ((Geo<MODE, PIX>::PATCH_BYTES + 15) & ~15) + 16;   // (+ the dummy slot)
     constexpr int ep_pix = (BN > 160) ? 32 : (BN > 32 ? 64 : PIX);
-    constexpr int epilogue = ep_pix * (BN * 4 + 16) + 2 * (256 / (BN / 8)) * BN * 4;
+    // epilogue: MI >= 2 -- four wave-private fp32 staging areas of SP pixel rows (pitch MI * 128 + 16), overlaid after a barrier by the
+    // statistics scratch [2][WN * pixels per sweep][BN]; MI == 1 -- the shared pass-by-pass staging + scratch of rounds 2-3
+    constexpr int w_stage = WM * WN * (MI >= 5 ? 16 : 32) * (MI * 128 + 16), w_red = 2 * (WN * (64 / (MI * 4))) * BN * 4;
+    constexpr int epilogue = MI >= 2 ? (w_stage > w_red ? w_stage : w_red) : ep_pix * (BN * 4 + 16) + 2 * (256 / (BN / 8)) * BN * 4;
     return main_loop > epilogue ? main_loop : epilogue;
 }
 
@@ -387,173 +390,318 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     GVD_CSTAMP(2);
 
     // ---- epilogue ----
-    unsigned char* const ep = lds;                                         // [EP_PIX][EP_PITCH] fp32
-    float* const red = reinterpret_cast<float*>(lds + EP_PIX * EP_PITCH);  // [2][EP_ROWS][BN]
     T* __restrict__ out = (T*)a.out;
     const T* __restrict__ res = (const T*)a.res;
-    const int oct = tid % NOCT, prow = tid / NOCT;
-    const bool ep_thread = tid < EP_ACTIVE;
-    const int cout0 = co_tile * BN + oct * 8;
-    const bool full_oct = (cout0 + 8 <= Cout) && ((Cout & 7) == 0);
-    float badd[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        badd[j] = 0.f;
-        if (ep_thread && cout0 + j < Cout) {
-            if (a.bias) badd[j] = a.bias[cout0 + j];
-            if (SPATIAL && a.add_nc) badd[j] += (float)((const T*)a.add_nc)[(size_t)n * Cout + cout0 + j];
-        }
-    }
+    const T* __restrict__ bx = (const T*)a.bx;
     float ssum[8], ssq[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { ssum[j] = 0.f; ssq[j] = 0.f; }
-    // GroupNorm-backward statistics mode: the forward affine of this thread's 8 channels (needed through silu' only) is
-    // re-read per pixel row from L1 -- held in registers it would cost 16 VGPRs in every mode of the 256-register tiles
-    const T* __restrict__ bx = (const T*)a.bx;
-    const float4* __restrict__ bcp = (bx && a.bsilu && full_oct)
-        ? reinterpret_cast<const float4*>(a.bcoef + (a.bcoef_per_n ? (size_t)n * Cout : 0) + cout0) : nullptr;
-
-    constexpr int NPASS = PIX / EP_PIX;
-    // Rows of a pass this thread finishes: pl = prow + k EP_ROWS.  Their residual / norm-input octets are fetched BEFORE the pass's
-    // accumulators go through LDS (unconditional loads, clamped addresses), so the HBM / L2 round trip sits under the staging and its
-    // barrier instead of in front of every row: a tile of the VAE's 128-channel stage made 16 such dependent trips (~0.7 us each
-    // against ~10 us of matrix work; the residual form cost +10 %, the norm-backward form +37 % -- tests/scripts/r4_conv_ablate.py).
-    constexpr int NROW = (EP_PIX + EP_ROWS - 1) / EP_ROWS;
-    constexpr bool PREFETCH = MI <= 4;   // (the 5-block tiles have no registers to spare next to their 160 accumulators)
-    auto row_geometry = [&](int pass, int pl, bool& valid, size_t& off) {
-        const int m = pass * EP_PIX + pl;
-        if (MODE == 2) {
-            const int tt = m / PB, pp = m - tt * PB;
-            valid = tt < a.N && p0 + pp < a.W;
-            off = sample_out + ((size_t)tt * a.W + p0 + pp) * Cout;
-        } else {
-            const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
-            valid = ty0 + ty < a.H && tx0 + tx < a.W;
-            off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
-        }
-        valid = valid && pl < EP_PIX;
-    };
-    for (int pass = 0; pass < NPASS; pass++) {
-        vec8 pre[PREFETCH ? NROW : 1];   // (a launch has a residual OR a norm input, never both: gvd_conv_mfma / gvd_conv_mfma_norm_bwd)
-        if constexpr (PREFETCH) {
-            const T* __restrict__ psrc = res ? res : bx;
-            if (ep_thread && full_oct && psrc) {
+    constexpr bool WEPI = MI >= 2;
+    // statistics scratch of the final reduction: [2][RROWS][BN] fp32 at the start of the LDS (written after a barrier)
+    constexpr int W_NOCT = MI * 4;                          // 16-byte output chunks (8 channels) per pixel row of a wave
+    constexpr int W_PPS = 64 / W_NOCT;                      // pixels a wave finishes per sweep (4 / 8; 3 for the 5-block tiles: 60 lanes)
+    constexpr int RROWS = WEPI ? WN * W_PPS : (256 / (BN / 8));
+    float* const red = reinterpret_cast<float*>(WEPI ? lds : lds + ((BN > 160) ? 32 : (BN > 32 ? 64 : PIX)) * (BN * 4 + 16));
+    int red_row = 0, red_col = 0;
+    bool red_on = false;
+    if constexpr (WEPI) {
+        // WAVE-PRIVATE (round 4).  A wave owns MI * 32 channels x NI * 32 pixels of the tile; it transposes them through its OWN fp32
+        // staging area -- pixel rows of MI * 128 + 16 bytes, SP pixels at a time -- and finishes them itself: lane = (pixel in sweep,
+        // channel octet), 32 bytes read back, bias / add_nc / residual added in fp32, ONE rounding, a 16-byte store in which the
+        // lanes of a pixel cover MI * 64 contiguous bytes, statistics of the rounded values.  No workgroup barrier: the four waves
+        // run their epilogues in parallel.  (Rounds 2-3 went pass by pass through one shared staging area: per pass ONE wave wrote,
+        // a barrier, all threads read, a barrier -- 8 barriers per tile, three waves idle during every write; the timeline of
+        // tests/scripts/r4_conv_trace.py had 25-35 % of a workgroup's life in there on the short-K tiles: the VAE's 128-channel
+        // stage, the temporal form.)  Same arithmetic as before, to the bit.
+        constexpr int SP = MI >= 5 ? 16 : 32;               // pixels staged at a time (the 5-block rows are 656 bytes: 4 x 16 rows = 42 KB)
+        constexpr int WP = MI * 128 + 16;                   // staging pitch (bytes): = 16 mod 128, conflict-free for the 8-lane write groups
+        constexpr int LPS = W_PPS * W_NOCT;                 // lanes that take part in a sweep
+        constexpr int NSW = (SP + W_PPS - 1) / W_PPS;       // sweeps per staged block
+        unsigned char* const wep = lds + wave * (SP * WP);
+        const int oc = lane % W_NOCT, pofs = lane / W_NOCT;
+        const bool lane_on = lane < LPS;
+        const int cout0 = co_tile * BN + wm * MI * 32 + oc * 8;
+        const bool full_oct = (cout0 + 8 <= Cout) && ((Cout & 7) == 0);
+        float badd[8];
 #pragma unroll
-                for (int k = 0; k < NROW; k++) {
-                    bool valid;
-                    size_t off;
-                    row_geometry(pass, prow + k * EP_ROWS, valid, off);
-                    pre[k] = *reinterpret_cast<const vec8*>(psrc + (valid ? off : 0) + cout0);
-                }
+        for (int j = 0; j < 8; j++) {
+            badd[j] = 0.f;
+            if (lane_on && cout0 + j < Cout) {
+                if (a.bias) badd[j] = a.bias[cout0 + j];
+                if (SPATIAL && a.add_nc) badd[j] += (float)((const T*)a.add_nc)[(size_t)n * Cout + cout0 + j];
             }
         }
-        // accumulators of this pass's pixel blocks -> LDS [pixel][channel] fp32 (a lane owns 4 consecutive channels per quad)
+        const float4* __restrict__ bcp = (bx && a.bsilu && full_oct)
+            ? reinterpret_cast<const float4*>(a.bcoef + (a.bcoef_per_n ? (size_t)n * Cout : 0) + cout0) : nullptr;
+        const T* __restrict__ psrc = res ? res : bx;        // (a launch has a residual OR a norm input, never both)
+        auto pixel = [&](int m, bool& valid, size_t& off) {
+            if (MODE == 2) {
+                const int tt = m / PB, pp = m - tt * PB;
+                valid = tt < a.N && p0 + pp < a.W;
+                off = sample_out + ((size_t)tt * a.W + p0 + pp) * Cout;
+            } else {
+                const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
+                valid = ty0 + ty < a.H && tx0 + tx < a.W;
+                off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
+            }
+        };
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
-            const int pblk = wn * NI + ni;
-            if ((pblk * 32) / EP_PIX != pass) continue;
-            const int pl = pblk * 32 - pass * EP_PIX + r32;
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
+            for (int h = 0; h < 32 / SP; h++) {
+                const int m0 = (wn * NI + ni) * 32 + h * SP;       // first tile pixel of this staged block
+                // residual / norm-input octets of the block's sweeps: fetched before the staging, consumed after it
+                constexpr bool PREF = MI <= 4;             // (no registers for it next to the 160 accumulators of the 5-block tiles)
+                vec8 pre[PREF ? NSW : 1];
+                if (PREF && full_oct && psrc && lane_on) {
 #pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    const int cl = (wm * MI + mi) * 32 + 8 * rg + 4 * hi;
-                    const float4 v = make_float4(acc[mi][ni][4 * rg], acc[mi][ni][4 * rg + 1], acc[mi][ni][4 * rg + 2], acc[mi][ni][4 * rg + 3]);
-#if GVD_CONV_DBG & 4
-                    if (v.x == 123.456f)
-#endif
-                    *reinterpret_cast<float4*>(ep + pl * EP_PITCH + cl * 4) = v;
+                    for (int sw = 0; sw < NSW; sw++) {
+                        bool valid;
+                        size_t off;
+                        const int pl = sw * W_PPS + pofs;
+                        pixel(m0 + pl, valid, off);
+                        pre[sw] = *reinterpret_cast<const vec8*>(psrc + ((valid && pl < SP) ? off : 0) + cout0);
+                    }
+                }
+                if ((r32 / SP) == h || SP == 32) {
+                    const int pl = r32 - h * SP;
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++)
+                            *reinterpret_cast<float4*>(wep + pl * WP + (mi * 32 + 8 * rg + 4 * hi) * 4) =
+                                make_float4(acc[mi][ni][4 * rg], acc[mi][ni][4 * rg + 1], acc[mi][ni][4 * rg + 2], acc[mi][ni][4 * rg + 3]);
+                }
+                if (lane_on && cout0 < Cout) {
+#pragma unroll(PREF ? NSW : 1)
+                    for (int sw = 0; sw < NSW; sw++) {
+                        const int pl = sw * W_PPS + pofs;
+                        bool valid;
+                        size_t off;
+                        pixel(m0 + pl, valid, off);
+                        if (!valid || pl >= SP) continue;
+                        const float4 v0 = *reinterpret_cast<const float4*>(wep + pl * WP + oc * 32);
+                        const float4 v1 = *reinterpret_cast<const float4*>(wep + pl * WP + oc * 32 + 16);
+                        const float v[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+                        vec8 o;
+                        if (full_oct) {
+                            vec8 rv = vec8{};
+                            if (res) rv = PREF ? pre[PREF ? sw : 0] : *reinterpret_cast<const vec8*>(res + off + cout0);
+                            if (bx) {   // (uniform) sums of dz and dz * x, dz = d_out * silu'(a x + b); gamma applied per column below
+                                const vec8 xv = PREF ? pre[PREF ? sw : 0] : *reinterpret_cast<const vec8*>(bx + off + cout0);
+                                float sg[8];
+#pragma unroll
+                                for (int j = 0; j < 8; j++) sg[j] = 1.f;
+                                if (bcp) {
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) {
+                                        const float4 ab = bcp[j];
+                                        sg[2 * j] = silu_grad32(fmaf((float)xv[2 * j], ab.x, ab.y));
+                                        sg[2 * j + 1] = silu_grad32(fmaf((float)xv[2 * j + 1], ab.z, ab.w));
+                                    }
+                                }
+#pragma unroll
+                                for (int j = 0; j < 8; j++) {
+                                    o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
+                                    const float dz = (float)o[j] * sg[j];
+                                    ssum[j] += dz;
+                                    ssq[j] = fmaf(dz, (float)xv[j], ssq[j]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; j++) {
+                                    o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
+                                    const float f = (float)o[j];
+                                    ssum[j] += f;
+                                    ssq[j] = fmaf(f, f, ssq[j]);
+                                }
+                            }
+                            *reinterpret_cast<vec8*>(out + off + cout0) = o;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                if (cout0 + j >= Cout) continue;
+                                float f = v[j] + badd[j];
+                                if (res) f += (float)res[off + cout0 + j];
+                                const T hh = (T)f;
+                                out[off + cout0 + j] = hh;
+                                f = (float)hh;
+                                ssum[j] += f;
+                                ssq[j] = fmaf(f, f, ssq[j]);
+                            }
+                        }
+                    }
                 }
             }
         }
-        __syncthreads();
-        if (ep_thread) {
-#pragma unroll(PREFETCH ? NROW : 1)
-            for (int k = 0; k < NROW; k++) {
-                const int pl = prow + k * EP_ROWS;
-                if (pl >= EP_PIX) break;
-                bool valid;
-                size_t off;
-                row_geometry(pass, pl, valid, off);
-                if (!valid || cout0 >= Cout) continue;
-                // a thread reads 32 contiguous bytes as two ds_read_b128; threads oct and oct + 8 of a 16-lane read group are 256
-                // bytes apart (the same banks), so the upper eight read their halves in the opposite order: the 2-way conflict on
-                // these reads was the 16-33 % SQ_LDS_BANK_CONFLICT of the round-2 counters (the operand reads are conflict free)
-                const int sw = (oct >> 3) & 1;
-#if GVD_CONV_DBG & 8
-                const float4 va = make_float4((float)pl, 0.f, 1.f, 2.f), vb = va;
-#else
-                const float4 va = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 16 : 0));
-                const float4 vb = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 0 : 16));
-#endif
-                const float4 v0 = sw ? vb : va, v1 = sw ? va : vb;
-                float v[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
-                vec8 o;
-                if (full_oct) {
-                    vec8 rv = vec8{};
-                    if (res) rv = PREFETCH ? pre[PREFETCH ? k : 0] : *reinterpret_cast<const vec8*>(res + off + cout0);
-                    if (bx) {   // wave-uniform (kernel argument): sums of dz and dz * x, dz = d_out * silu'(a x + b); gamma applied per column below
-                        const vec8 xv = PREFETCH ? pre[PREFETCH ? k : 0] : *reinterpret_cast<const vec8*>(bx + off + cout0);
-                        float sg[8];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) sg[j] = 1.f;
-                        if (bcp) {
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const float4 ab = bcp[j];
-                                sg[2 * j] = silu_grad32(fmaf((float)xv[2 * j], ab.x, ab.y));
-                                sg[2 * j + 1] = silu_grad32(fmaf((float)xv[2 * j + 1], ab.z, ab.w));
+        red_row = wn * W_PPS + pofs;
+        red_col = wm * MI * 32 + oc * 8;
+        red_on = lane_on;
+        __syncthreads();   // every wave is out of its staging area: the statistics scratch below may overlay it
+    } else {
+        unsigned char* const ep = lds;                                         // [EP_PIX][EP_PITCH] fp32
+        const int oct = tid % NOCT, prow = tid / NOCT;
+        const bool ep_thread = tid < EP_ACTIVE;
+        const int cout0 = co_tile * BN + oct * 8;
+        const bool full_oct = (cout0 + 8 <= Cout) && ((Cout & 7) == 0);
+        float badd[8];
+    #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            badd[j] = 0.f;
+            if (ep_thread && cout0 + j < Cout) {
+                if (a.bias) badd[j] = a.bias[cout0 + j];
+                if (SPATIAL && a.add_nc) badd[j] += (float)((const T*)a.add_nc)[(size_t)n * Cout + cout0 + j];
+            }
+        }
+        // GroupNorm-backward statistics mode: the forward affine of this thread's 8 channels (needed through silu' only) is
+        // re-read per pixel row from L1 -- held in registers it would cost 16 VGPRs in every mode of the 256-register tiles
+        const float4* __restrict__ bcp = (bx && a.bsilu && full_oct)
+            ? reinterpret_cast<const float4*>(a.bcoef + (a.bcoef_per_n ? (size_t)n * Cout : 0) + cout0) : nullptr;
+
+        constexpr int NPASS = PIX / EP_PIX;
+        // Rows of a pass this thread finishes: pl = prow + k EP_ROWS.  Their residual / norm-input octets are fetched BEFORE the pass's
+        // accumulators go through LDS (unconditional loads, clamped addresses), so the HBM / L2 round trip sits under the staging and its
+        // barrier instead of in front of every row: a tile of the VAE's 128-channel stage made 16 such dependent trips (~0.7 us each
+        // against ~10 us of matrix work; the residual form cost +10 %, the norm-backward form +37 % -- tests/scripts/r4_conv_ablate.py).
+        constexpr int NROW = (EP_PIX + EP_ROWS - 1) / EP_ROWS;
+        constexpr bool PREFETCH = MI <= 4;   // (the 5-block tiles have no registers to spare next to their 160 accumulators)
+        auto row_geometry = [&](int pass, int pl, bool& valid, size_t& off) {
+            const int m = pass * EP_PIX + pl;
+            if (MODE == 2) {
+                const int tt = m / PB, pp = m - tt * PB;
+                valid = tt < a.N && p0 + pp < a.W;
+                off = sample_out + ((size_t)tt * a.W + p0 + pp) * Cout;
+            } else {
+                const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
+                valid = ty0 + ty < a.H && tx0 + tx < a.W;
+                off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
+            }
+            valid = valid && pl < EP_PIX;
+        };
+        for (int pass = 0; pass < NPASS; pass++) {
+            vec8 pre[PREFETCH ? NROW : 1];   // (a launch has a residual OR a norm input, never both: gvd_conv_mfma / gvd_conv_mfma_norm_bwd)
+            if constexpr (PREFETCH) {
+                const T* __restrict__ psrc = res ? res : bx;
+                if (ep_thread && full_oct && psrc) {
+    #pragma unroll
+                    for (int k = 0; k < NROW; k++) {
+                        bool valid;
+                        size_t off;
+                        row_geometry(pass, prow + k * EP_ROWS, valid, off);
+                        pre[k] = *reinterpret_cast<const vec8*>(psrc + (valid ? off : 0) + cout0);
+                    }
+                }
+            }
+            // accumulators of this pass's pixel blocks -> LDS [pixel][channel] fp32 (a lane owns 4 consecutive channels per quad)
+    #pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int pblk = wn * NI + ni;
+                if ((pblk * 32) / EP_PIX != pass) continue;
+                const int pl = pblk * 32 - pass * EP_PIX + r32;
+    #pragma unroll
+                for (int mi = 0; mi < MI; mi++) {
+    #pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const int cl = (wm * MI + mi) * 32 + 8 * rg + 4 * hi;
+                        const float4 v = make_float4(acc[mi][ni][4 * rg], acc[mi][ni][4 * rg + 1], acc[mi][ni][4 * rg + 2], acc[mi][ni][4 * rg + 3]);
+    #if GVD_CONV_DBG & 4
+                        if (v.x == 123.456f)
+    #endif
+                        *reinterpret_cast<float4*>(ep + pl * EP_PITCH + cl * 4) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (ep_thread) {
+    #pragma unroll(PREFETCH ? NROW : 1)
+                for (int k = 0; k < NROW; k++) {
+                    const int pl = prow + k * EP_ROWS;
+                    if (pl >= EP_PIX) break;
+                    bool valid;
+                    size_t off;
+                    row_geometry(pass, pl, valid, off);
+                    if (!valid || cout0 >= Cout) continue;
+                    // a thread reads 32 contiguous bytes as two ds_read_b128; threads oct and oct + 8 of a 16-lane read group are 256
+                    // bytes apart (the same banks), so the upper eight read their halves in the opposite order: the 2-way conflict on
+                    // these reads was the 16-33 % SQ_LDS_BANK_CONFLICT of the round-2 counters (the operand reads are conflict free)
+                    const int sw = (oct >> 3) & 1;
+    #if GVD_CONV_DBG & 8
+                    const float4 va = make_float4((float)pl, 0.f, 1.f, 2.f), vb = va;
+    #else
+                    const float4 va = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 16 : 0));
+                    const float4 vb = *reinterpret_cast<const float4*>(ep + pl * EP_PITCH + oct * 32 + (sw ? 0 : 16));
+    #endif
+                    const float4 v0 = sw ? vb : va, v1 = sw ? va : vb;
+                    float v[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+                    vec8 o;
+                    if (full_oct) {
+                        vec8 rv = vec8{};
+                        if (res) rv = PREFETCH ? pre[PREFETCH ? k : 0] : *reinterpret_cast<const vec8*>(res + off + cout0);
+                        if (bx) {   // wave-uniform (kernel argument): sums of dz and dz * x, dz = d_out * silu'(a x + b); gamma applied per column below
+                            const vec8 xv = PREFETCH ? pre[PREFETCH ? k : 0] : *reinterpret_cast<const vec8*>(bx + off + cout0);
+                            float sg[8];
+    #pragma unroll
+                            for (int j = 0; j < 8; j++) sg[j] = 1.f;
+                            if (bcp) {
+    #pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const float4 ab = bcp[j];
+                                    sg[2 * j] = silu_grad32(fmaf((float)xv[2 * j], ab.x, ab.y));
+                                    sg[2 * j + 1] = silu_grad32(fmaf((float)xv[2 * j + 1], ab.z, ab.w));
+                                }
+                            }
+    #pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
+                                const float dz = (float)o[j] * sg[j];
+                                ssum[j] += dz;
+                                ssq[j] = fmaf(dz, (float)xv[j], ssq[j]);
+                            }
+                        } else {
+    #pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
+                                const float f = (float)o[j];
+                                ssum[j] += f;
+                                ssq[j] = fmaf(f, f, ssq[j]);
                             }
                         }
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
-                            const float dz = (float)o[j] * sg[j];
-                            ssum[j] += dz;
-                            ssq[j] = fmaf(dz, (float)xv[j], ssq[j]);
-                        }
+                        *reinterpret_cast<vec8*>(out + off + cout0) = o;
                     } else {
-#pragma unroll
+    #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            o[j] = (T)(v[j] + badd[j] + (float)rv[j]);
-                            const float f = (float)o[j];
+                            if (cout0 + j >= Cout) continue;
+                            float f = v[j] + badd[j];
+                            if (res) f += (float)res[off + cout0 + j];
+                            const T h = (T)f;
+                            out[off + cout0 + j] = h;
+                            f = (float)h;
                             ssum[j] += f;
                             ssq[j] = fmaf(f, f, ssq[j]);
                         }
                     }
-                    *reinterpret_cast<vec8*>(out + off + cout0) = o;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (cout0 + j >= Cout) continue;
-                        float f = v[j] + badd[j];
-                        if (res) f += (float)res[off + cout0 + j];
-                        const T h = (T)f;
-                        out[off + cout0 + j] = h;
-                        f = (float)h;
-                        ssum[j] += f;
-                        ssq[j] = fmaf(f, f, ssq[j]);
-                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+        red_row = prow;
+        red_col = oct * 8;
+        red_on = ep_thread;
     }
-
     GVD_CSTAMP(3);
     // ---- GroupNorm statistics of the (rounded) outputs for the next norm ----
     if (a.stats) {
-        if (ep_thread) {
+        if (red_on) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                red[prow * BN + oct * 8 + j] = ssum[j];
-                red[(EP_ROWS + prow) * BN + oct * 8 + j] = ssq[j];
+                red[red_row * BN + red_col + j] = ssum[j];
+                red[(RROWS + red_row) * BN + red_col + j] = ssq[j];
             }
         }
         __syncthreads();
         for (int c = tid; c < BN; c += 256) {   // per-channel totals into row 0 (column-private: no race)
             float s = 0.f, q = 0.f;
-            for (int rr = 0; rr < EP_ROWS; rr++) { s += red[rr * BN + c]; q += red[(EP_ROWS + rr) * BN + c]; }
+            for (int rr = 0; rr < RROWS; rr++) { s += red[rr * BN + c]; q += red[(RROWS + rr) * BN + c]; }
             if (bx) {   // backward statistics carry the norm's weight: sum gamma dz, sum gamma dz x
                 const int cg = co_tile * BN + c;
                 const float gm = cg < Cout ? a.bgamma[cg] : 0.f;
@@ -561,7 +709,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 q *= gm;
             }
             red[c] = s;
-            red[EP_ROWS * BN + c] = q;
+            red[RROWS * BN + c] = q;
         }
         __syncthreads();
         const int cb = co_tile * BN, ce = (cb + BN < Cout) ? cb + BN : Cout;
@@ -571,7 +719,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
             if (g <= g_last) {
                 const int c_lo = (g * a.cpg > cb) ? g * a.cpg : cb, c_hi = ((g + 1) * a.cpg < ce) ? (g + 1) * a.cpg : ce;
                 double s = 0.0, q = 0.0;
-                for (int c = c_lo; c < c_hi; c++) { s += (double)red[c - cb]; q += (double)red[EP_ROWS * BN + c - cb]; }
+                for (int c = c_lo; c < c_hi; c++) { s += (double)red[c - cb]; q += (double)red[RROWS * BN + c - cb]; }
                 const int rep = blockIdx.x % a.R;
                 const int nstat = n, Nstat = SPATIAL ? a.N : a.NS;
                 double* dst = a.stats + (((size_t)rep * Nstat + nstat) * a.G + g) * 2;
@@ -716,11 +864,16 @@ void choose(int mode, int N, int H, int W, int Cout, int* cfg, int* tw32)
     int c;
     if (mode >= 2) c = (Cout % 160 == 0) ? 1 : 4;          // stride 2
     else if (Cout <= 32) c = 3;
-    else if (Cout % 160 == 0) c = (mode == 1 || pixels >= 40000) ? 0 : 1;
+    else if (Cout % 160 == 0) c = (mode == 0 && pixels >= 40000) ? 0 : 1;    // (temporal: 320 x 128 measured 2-7 % ahead of 160 x 256 at every level)
     else c = 2;
-    // small problems (the 9x16 level, the 72x128 VAE stage, the temporal form at 144 pixels): the big tiles launch fewer
-    // workgroups than the chip has CU slots (2 x 256) -- take the 128 x 128 tile when it at least fills one slot per CU better
-    if (mode < 2 && Cout >= 128 && c != 4 && groups(c) < 384 && groups(4) > groups(c)) c = 4;
+    // small problems (the 9x16 level, the 72x128 VAE stage, the temporal form at 35 / 144 pixels): the big tiles launch fewer
+    // workgroups than the chip has CU slots (2 x 256) -- take the 128 x 128 tile when it at least fills one slot per CU better.
+    // Temporal: only when the big tile leaves most CUs empty (tests/scripts/r4_tile_sweep.py: 224 workgroups of 320 x 128 beat 560 of
+    // 128 x 128 -- two rounds -- by 20 %; at 56 / 116 workgroups the small tile wins by 25-35 %).
+    if (mode < 2 && Cout >= 128 && c != 4 && groups(c) < (mode == 1 ? 160 : 384) && groups(4) > groups(c)) c = 4;
+    // images that fit ONE 16 x 16 tile but not an 8 x 16 one (the 10 x 14 latents of a 320 x 448 video): 128 x 256 -- a single round
+    // of workgroups with the shortest loop step that covers the image (391 against 446-467 us for the other three)
+    if (mode == 0 && H <= 16 && W <= 16 && H * W > 128 && Cout % 128 == 0 && groups(2) <= 512 && groups(2) > 256) c = 2;
     static const int forced = [] { const char* e = getenv("GVD_CONV_FORCE_CFG"); return e ? atoi(e) : -1; }();   // experiments: one tile configuration for every stride-1 launch with Cout > 32
     if (forced >= 0 && forced <= 4 && forced != 3 && mode < 2 && Cout > 32) c = forced;
     *cfg = c;
