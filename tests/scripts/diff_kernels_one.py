@@ -18,6 +18,11 @@ go = torch.randn_like(o)
 for _ in range(2):   # the guided step's backward pair (k_attn_bwd_dkv, k_attn_bwd_dq)
     ops._hip_attention_bwd(q, k, v, o, go, lse, 5, False)
 del q, k, v, o, go, lse
+# temporal self-attention at level 0: the 25 frames of each of the 9216 pixels, read in place from the token-major tensor (bandwidth-bound)
+qt, kt, vt = (torch.randn(25, 9216, 320, device=dev, generator=g).half() for _ in range(3))
+for _ in range(3):
+    ops._hip_attention_fwd(qt, kt, vt, 5, True)
+del qt, kt, vt
 
 
 def conv_case(N, H, W, Cin, Cout, prologue):

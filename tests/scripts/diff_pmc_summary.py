@@ -10,6 +10,7 @@ import os
 import sys
 
 a_dir, b_dir, out = sys.argv[1:4]
+traffic_dirs = sys.argv[4:6]          # optional: the FETCH_SIZE and WRITE_SIZE passes
 
 
 def rows_of(d):
@@ -21,7 +22,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(set))
 dur = collections.defaultdict(dict)
 GEMM_CASES = ["L0 ff-in 230400x2560x320 LN+GEGLU", "L0 out-proj 230400x320x320 +residual", "L2 ff-in 14400x10240x1280 LN+GEGLU", "L1 qkv 57600x1920x640 LN"]
-for rows in (rows_of(a_dir), rows_of(b_dir)):
+for rows in [rows_of(a_dir), rows_of(b_dir)] + [rows_of(d) for d in traffic_dirs]:
     # the persistent GEMM launches one grid for every shape: tell the cases of diff_kernels_one.py apart by launch order (3 each)
     gemm_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "k_gemm_nt" in r["Kernel_Name"]})
     gemm_case = {d: GEMM_CASES[min(i // 3, len(GEMM_CASES) - 1)] for i, d in enumerate(gemm_ids)}
@@ -63,6 +64,14 @@ with open(out + ".csv", "w", newline="") as f:
         for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_WAVES"):
             if c in per:
                 entry[c.lower()] = int(per[c])
+        # HBM-side bytes per launch (KB counters): FETCH_SIZE doubled -- on gfx950 it reports half the bytes of wide coalesced
+        # streaming reads (MI355X_MICROARCH.md, "HBM"), which is what these kernels' 16-byte-per-lane loads / LDS-DMA are; WRITE_SIZE raw
+        if "FETCH_SIZE" in per or "WRITE_SIZE" in per:
+            entry["fetch_bytes_x2"] = int(2 * 1024 * per.get("FETCH_SIZE", 0.0))
+            entry["write_bytes"] = int(1024 * per.get("WRITE_SIZE", 0.0))
+            entry["traffic_bytes"] = entry["fetch_bytes_x2"] + entry["write_bytes"]
+            if d_ns:
+                entry["traffic_tb_per_s_in_counter_pass"] = round(entry["traffic_bytes"] / d_ns / 1e3, 3)
         res[key] = entry
 json.dump(res, open(out + ".json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:6000])
