@@ -774,7 +774,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         o = orig_attn(q, k, v, heads, frame_major, want_lse, **kw)
         b.record()
         nb, nq, nk = (q.shape[1], q.shape[0], k.shape[0]) if frame_major else (q.shape[0], q.shape[1], k.shape[1])
-        ev_attn.append((a, b, 4.0 * nb * heads * nq * nk * 64))
+        ev_attn.append((a, b, 4.0 * nb * heads * nq * nk * 64, bool(frame_major), 2.0 * heads * 64 * nb * (2 * nq + 2 * nk)))
         return o
 
     def timed_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw):
@@ -910,6 +910,27 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         r_hbm = {"bound": "hbm", "kernel": f"k_gemm_nt {shp[2]} x {shp[3]} x {shp[4]}" + (" + residual" if shp[7] else ""), "achieved": round(ach, 1),
                  "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_from": t_from,
                  "alg_bytes": int(byt), "launches_per_step": round(n_ / n_inst, 1), "ms_per_step": round(ms_ / n_inst, 3)}
+    # ... and the temporal self-attention (the T frames of each pixel: 4 x N^2 x 64 flops against q, k, v, out once = 25 flop/byte)
+    r_hbm_attn = None
+    ta = [e for e in ev_attn if len(e) > 3 and e[3]]
+    if ta and n_inst:
+        ms_ = sum(e[0].elapsed_time(e[1]) for e in ta)
+        byt = sum(e[4] for e in ta)
+        ach = byt / (ms_ * 1e-3) / 1e9
+        traffic, t_from = None, None
+        pmc = os.path.join(ROOT, "profiles", "r04_mfma_pmc.json")
+        if os.path.exists(pmc) and (args.ddim_height, args.ddim_width, T) == (576, 1024, 25):
+            try:
+                pj = json.load(open(pmc))
+                key = [k_ for k_ in pj if k_.startswith("attn i1ELi1E")]
+                if key:
+                    traffic = pj[key[0]].get("traffic_bytes")
+                    t_from = "profiles/r04_mfma_pmc.json: per LAUNCH of the level-0 shape (25 frames x 9216 pixels x 320 channels; 590 MB algorithmic), separate rocprofv3 --pmc passes; NOT observed in this run"
+            except Exception:
+                traffic = None
+        r_hbm_attn = {"bound": "hbm", "kernel": "k_attn_fwd<1,1> (temporal self-attention, frames of a pixel read in place)", "achieved": round(ach, 1),
+                      "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_from": t_from,
+                      "alg_bytes_per_step": int(byt / n_inst), "launches_per_step": round(len(ta) / n_inst, 1), "ms_per_step": round(ms_ / n_inst, 3)}
     dominant = max((r for r in (r_conv, r_attn, r_gemm) if r), key=lambda r: r["ms_per_step"], default=None)   # the family with the most time per step
     unet_tflop = {(576, 1024): 82.76, (320, 448): 17.59, (320, 512): 20.19}.get((args.ddim_height, args.ddim_width))
     line = {
@@ -927,7 +948,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
                    "baseline_note": "vs_baseline = steps/s over the ViewCrafter README A100 figure 0.42 steps/s (120 s / 50 steps, "
                                     "whole pipeline incl. VAE/CLIP; third_party/ViewCrafter/README.md:116-118)"},
         "roofline": dominant,
-        "roofline_conv": r_conv, "roofline_attention": r_attn, "roofline_hbm_bound_linear": r_hbm, "roofline_gemm": r_gemm,
+        "roofline_conv": r_conv, "roofline_attention": r_attn, "roofline_hbm_bound_linear": r_hbm, "roofline_hbm_bound_attention": r_hbm_attn, "roofline_gemm": r_gemm,
         "unet_achieved_tflops": (round(2 * unet_tflop * steps / elapsed, 1) if unet_tflop and not guided else None),
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
