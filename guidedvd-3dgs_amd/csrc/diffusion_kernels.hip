@@ -356,6 +356,133 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Short rows (Nq, Nk <= 32: the TEMPORAL attention, 25 frames of one pixel -- lvdm/modules/attention.py:313-412): the whole problem
+// of one (batch entry, head) is 3 x 25 x 128 bytes in, 25 x 128 bytes out and 8 MFMAs, i.e. pure HBM traffic.  The general kernel
+// above ran it as one single-wave workgroup per item with 36 KB of (double-buffered 64-key) LDS -- four waves per CU, each waiting
+// for its own 9.6 KB before doing anything, always through the optimistic softmax's redo path: 2.6 TB/s.  Here a WAVE walks items
+// (grid-stride, ~11 per wave at level 0): Q and K are loaded straight into their MFMA operand registers (no LDS), V goes through a
+// wave-private 5 KB transposition, the softmax is the exact one-tile form, and the NEXT item's twelve 16-byte loads per lane are
+// issued as soon as the S product has consumed the registers -- they fly under the softmax, P V, and the row-contiguous stores
+// (O^T is transposed back through wave-private LDS: full 128-byte rows per 8 lanes).  No barriers anywhere.
+template <typename T>
+__global__ void __launch_bounds__(256) k_attn_short_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        T* __restrict__ out, float* __restrict__ lse, int H, int Nq, int Nk, int items,
+                                                        float scale_log2e, long long q_bs, long long q_rs, long long kv_bs,
+                                                        long long kv_rs, long long o_bs, long long o_rs)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int VT_PITCH = 40, O_PITCH = 72;                         // 80 / 144-byte rows: 16-byte aligned fragment reads
+    __shared__ __attribute__((aligned(16))) T sVt[4][64][VT_PITCH];    // V^T [channel][key] of the wave's current item
+    __shared__ __attribute__((aligned(16))) T sO[4][32][O_PITCH];      // O [query][channel] on its way out
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, r32 = lane & 31;
+    const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    // rows past the end are CLAMPED (a second copy of the last row): their keys are masked before the softmax, their queries are
+    // never stored -- no zero fill, no branch around a load
+    const size_t qoff = (size_t)(r32 < Nq ? r32 : Nq - 1) * (size_t)q_rs + 8 * hi;
+    const size_t koff = (size_t)(r32 < Nk ? r32 : Nk - 1) * (size_t)kv_rs + 8 * hi;
+    const int kp = lane & 15, vo = lane >> 4;                           // V staging: key pair (2 kp, 2 kp + 1), channel octets vo, vo + 4
+    const size_t voff0 = (size_t)(2 * kp < Nk ? 2 * kp : Nk - 1) * (size_t)kv_rs + 8 * vo;
+    const size_t voff1 = (size_t)(2 * kp + 1 < Nk ? 2 * kp + 1 : Nk - 1) * (size_t)kv_rs + 8 * vo;
+    vec8 qf[4], kf[4], va[2], vb[2];
+    auto load = [&](int it) {
+        const int b = it / H, h = it - b * H;
+        const T* qb = q + (size_t)b * q_bs + (size_t)h * 64 + qoff;
+        const T* kb = k + (size_t)b * kv_bs + (size_t)h * 64;
+        const T* vp = v + (size_t)b * kv_bs + (size_t)h * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            qf[ks] = *reinterpret_cast<const vec8*>(qb + 16 * ks);
+            kf[ks] = *reinterpret_cast<const vec8*>(kb + koff + 16 * ks);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            va[ps] = *reinterpret_cast<const vec8*>(vp + voff0 + 32 * ps);
+            vb[ps] = *reinterpret_cast<const vec8*>(vp + voff1 + 32 * ps);
+        }
+    };
+    if (gw >= items) return;
+    load(gw);
+    for (int it = gw; it < items; it += nw) {
+        // ---- V^T into the wave's LDS: the two keys of a channel packed into one dword ----
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const T2 pr = { va[ps][i], vb[ps][i] };
+                *reinterpret_cast<T2*>(&sVt[wave][(vo + 4 * ps) * 8 + i][2 * kp]) = pr;
+            }
+        // ---- S^T = K Q^T (keys in the rows: a lane owns ONE query's 16 + 16 scores) ----
+        f16v s = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) s = Tr<T>::mfma(kf[ks], qf[ks], s);
+        // ---- the next item's operands (this lane's twelve registers are free again) ----
+        const int b = it / H, h = it - b * H;
+        {
+            const int nx = it + nw < items ? it + nw : items - 1;
+            load(nx);
+        }
+        // ---- exact softmax over the <= 32 keys ----
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if ((r & 3) + 8 * (r >> 2) + 4 * hi >= Nk) s[r] = -3.0e38f;
+        float mt = max3f(s[0], s[1], s[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mt = max3f(mt, s[r], s[r + 1]);
+        mt = fmaxf(mt, s[15]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m = mt * scale_log2e;
+        unsigned pk[8];
+        float rsa = 0.f;
+        f2 rs2 = { 0.f, 0.f };
+        const f2 c2 = { scale_log2e, scale_log2e }, nm2 = { -m, -m };
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            f2 a0 = { s[2 * j], s[2 * j + 1] };
+            a0 = __builtin_elementwise_fma(a0, c2, nm2);
+            const f2 p0 = exp2_pair(a0);
+            pk[j] = Tr<T>::pack2(p0.x, p0.y);
+            if (Tr<T>::kHasDot2) rsa = Tr<T>::add_pair(pk[j], rsa);
+            else rs2 += p0;
+        }
+        float l = Tr<T>::kHasDot2 ? rsa : rs2.x + rs2.y;
+        l += __shfl_xor(l, 32, 64);
+        // ---- O^T = V^T P^T ----
+        f16v o0 = {}, o1 = {};
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+            const vec8 pf = packed_c_to_b_operand<T>(pk, k2);
+            const vec8 a0 = *reinterpret_cast<const vec8*>(&sVt[wave][r32][16 * k2 + 8 * hi]);
+            const vec8 a1 = *reinterpret_cast<const vec8*>(&sVt[wave][32 + r32][16 * k2 + 8 * hi]);
+            o0 = Tr<T>::mfma(a0, pf, o0);
+            o1 = Tr<T>::mfma(a1, pf, o1);
+        }
+        // ---- O = O^T / l, back to [query][channel] through LDS, stored as whole 128-byte rows ----
+        if (lse && hi == 0 && r32 < Nq) lse[(size_t)it * Nq + r32] = m + __builtin_amdgcn_logf(l);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int d0 = 8 * rg + 4 * hi;
+            uint2 w0, w1;
+            w0.x = Tr<T>::pack2(o0[4 * rg] * inv, o0[4 * rg + 1] * inv);
+            w0.y = Tr<T>::pack2(o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
+            w1.x = Tr<T>::pack2(o1[4 * rg] * inv, o1[4 * rg + 1] * inv);
+            w1.y = Tr<T>::pack2(o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+            *reinterpret_cast<uint2*>(&sO[wave][r32][d0]) = w0;
+            *reinterpret_cast<uint2*>(&sO[wave][r32][32 + d0]) = w1;
+        }
+        T* ob = out + (size_t)b * o_bs + (size_t)h * 64 + 8 * (lane & 7);
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            const int row = (lane >> 3) + 8 * ps;
+            const uint4 w = *reinterpret_cast<const uint4*>(&sO[wave][row][8 * (lane & 7)]);
+            if (row < Nq) *reinterpret_cast<uint4*>(ob + (size_t)row * (size_t)o_rs) = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum_d(double v)
 {
 #pragma unroll
@@ -966,6 +1093,34 @@ int gvd_attention_fwd_ex(const void* q, const void* k, const void* v, void* out,
     if (D != 64) return fail(-1, "gvd_attention_fwd: head dim must be 64");
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(-1, "gvd_attention_fwd: pointers must be 16-byte aligned");
     const float sl2 = scale * 1.4426950408889634f;
+    const char* no_short = getenv("GVD_ATTN_NO_SHORT");   // (A/B switch: 1 = short rows on the general kernel, as before round 4)
+    if (Nq <= 32 && Nk <= 32 && !accum && !(no_short && no_short[0] != '0')) {
+        // short rows (temporal attention): a wave per (batch entry, head) item, grid-stride; 4 workgroups of 4 waves per CU
+        const long long items = (long long)B * H;
+        if (items > 0x7fffffffLL) return fail(-1, "gvd_attention_fwd: too many (batch, head) items");
+        // grid = what is RESIDENT at once (the occupancy the compiler reached x 256 CUs): a second round of workgroups would start
+        // when the first ends, i.e. with a tail as long as a wave's whole ~11-item walk
+        static int s_res[2] = { 0, 0 };
+        if (!s_res[is_bf16 ? 1 : 0]) {
+            int per_cu = 0, dev = 0, cus = 256;
+            hipError_t eo = is_bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_short_fwd<__bf16>, 256, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_short_fwd<_Float16>, 256, 0);
+            if (eo != hipSuccess || per_cu < 1) per_cu = 2;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            s_res[is_bf16 ? 1 : 0] = per_cu * (cus > 0 ? cus : 256);
+        }
+        const long long wgs = (items + 3) / 4, res = s_res[is_bf16 ? 1 : 0];
+        dim3 sgrid((unsigned)(wgs < res ? wgs : res));
+        if (is_bf16)
+            hipLaunchKernelGGL((k_attn_short_fwd<__bf16>), sgrid, dim3(256), 0, stream, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v,
+                               (__bf16*)out, lse, H, Nq, Nk, (int)items, sl2, q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs);
+        else
+            hipLaunchKernelGGL((k_attn_short_fwd<_Float16>), sgrid, dim3(256), 0, stream, (const _Float16*)q, (const _Float16*)k,
+                               (const _Float16*)v, (_Float16*)out, lse, H, Nq, Nk, (int)items, sl2, q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs);
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return fail(-2, "launch k_attn_short_fwd", es);
+        return 0;
+    }
     // 4 waves x 2 query blocks (256 queries / workgroup) for long sequences, 4 x 1 for medium, one wave for short ones
     // (measured and not kept: 3 query blocks per wave at one wave per SIMD -- 446 registers, no spills -- ran 643 TFLOP/s at L0
     //  against 777 for 2 blocks x 2 waves per SIMD: the second resident wave hides more than the extra operand reuse saves)

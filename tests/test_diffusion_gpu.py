@@ -201,6 +201,31 @@ def test_frame_major_strided_attention_matches_transposed_math(T, P, H):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk,fm", [(5000, 5, 25, 25, True), (37, 3, 32, 32, True), (9, 2, 1, 1, False), (130, 4, 25, 17, False),
+                                          (3, 1, 7, 32, True), (70000, 1, 2, 3, False)])
+def test_short_row_attention_kernel_matches_fp32_and_the_general_kernel(dtype, B, H, Nq, Nk, fm, monkeypatch):
+    """Rows of <= 32 queries and keys (the temporal attention) run on the wave-per-item kernel (`k_attn_short_fwd`): output and the
+    log-sum-exp the backward kernels consume against the fp32 form, and against the general flash kernel on the same inputs
+    (GVD_ATTN_NO_SHORT=1) -- same operand rounding, so the two agree to a 16-bit ulp of the output.  More items than resident waves
+    (grid-stride walk), a single item per wave, ragged tails, clamped rows past Nq / Nk."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(B + 7 * Nq + Nk)
+    C = H * 64
+    shq, shk = ((Nq, B, C), (Nk, B, C)) if fm else ((B, Nq, C), (B, Nk, C))
+    q = (torch.randn(shq, device=DEV, generator=g) * 1.5).to(dtype)
+    k, v = (torch.randn(shk, device=DEV, generator=g).to(dtype) for _ in range(2))
+    monkeypatch.delenv("GVD_ATTN_NO_SHORT", raising=False)
+    o, lse = ops._hip_attention_fwd(q, k, v, H, fm, want_lse=True)
+    monkeypatch.setenv("GVD_ATTN_NO_SHORT", "1")
+    o_gen, lse_gen = ops._hip_attention_fwd(q, k, v, H, fm, want_lse=True)
+    ref = ops.attention_math(q.float(), k.float(), v.float(), H, frame_major=fm)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert o.shape == q.shape and float((o.float() - ref).abs().max()) < tol
+    assert float((o.float() - o_gen.float()).abs().max()) <= (2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6) * float(ref.abs().max())
+    assert float((lse - lse_gen).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (33, 1280), (5, 2048), (1, 8)])
 def test_layer_norm_row_kernel_matches_fp32_layer_norm(dtype, M, C):
     """Tolerance: one rounding of the 16-bit output type (2^-11 rel for f16, 2^-8 for bf16) on |y| <~ 6."""
