@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(256) k_attn_short_fwd(const T* __restrict__ q,
                 const T2 pr = { va[ps][i], vb[ps][i] };
                 *reinterpret_cast<T2*>(&sVt[wave][(vo + 4 * ps) * 8 + i][2 * kp]) = pr;
             }
+        __builtin_amdgcn_wave_barrier();   // (compiler only: V^T is read back by other lanes below)
         // ---- S^T = K Q^T (keys in the rows: a lane owns ONE query's 16 + 16 scores) ----
         f16v s = {};
 #pragma unroll
@@ -472,6 +473,7 @@ __global__ void __launch_bounds__(256) k_attn_short_fwd(const T* __restrict__ q,
             *reinterpret_cast<uint2*>(&sO[wave][r32][d0]) = w0;
             *reinterpret_cast<uint2*>(&sO[wave][r32][32 + d0]) = w1;
         }
+        __builtin_amdgcn_wave_barrier();   // (compiler only: the read-back below is of OTHER lanes' writes; the LDS itself is in order)
         T* ob = out + (size_t)b * o_bs + (size_t)h * 64 + 8 * (lane & 7);
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {

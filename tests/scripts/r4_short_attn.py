@@ -49,3 +49,30 @@ for T, P, C in ((25, 9216, 320), (25, 2304, 640), (25, 576, 1280), (25, 144, 128
     t_old = bench(lambda: run(qkv, heads, False))
     gb = 4 * T * P * C * 2 / 1e9
     print(f"T {T:2d} P {P:5d} C {C:4d}: err new {en:.1e} old {eo:.1e}  lse diff {el:.1e}   new {t_new:7.1f} us ({gb / t_new * 1e3:5.2f} TB/s)   old {t_old:7.1f} us ({gb / t_old * 1e3:5.2f} TB/s)", flush=True)
+
+print("-- backward (dq, dk, dv): one wave-per-item kernel against delta + dkv + dq", flush=True)
+for T, P, C in ((25, 2240, 320), (25, 560, 640), (25, 140, 1280), (25, 9216, 320)):
+    heads = C // 64
+    g = torch.Generator(device=DEV).manual_seed(P + T)
+    q, k, v = (torch.randn(T, P, C, device=DEV, generator=g).half().requires_grad_(True) for _ in range(3))
+    go = torch.randn(T, P, C, device=DEV, generator=g).half()
+
+    def grads(short):
+        if short:
+            os.environ.pop("GVD_ATTN_NO_SHORT", None)
+        else:
+            os.environ["GVD_ATTN_NO_SHORT"] = "1"
+        o = ops.attention(q, k, v, heads, frame_major=True)
+        return o, o.grad_fn
+
+    res = {}
+    for short in (True, False):
+        o, _ = grads(short)
+        gs = torch.autograd.grad(o, (q, k, v), go, retain_graph=True)
+        t = bench(lambda: torch.autograd.grad(o, (q, k, v), go, retain_graph=True))
+        res[short] = (gs, t)
+    qf, kf, vf = (t_.detach().float().requires_grad_(True) for t_ in (q, k, v))
+    gr = torch.autograd.grad(ops.attention_math(qf, kf, vf, heads, True), (qf, kf, vf), go.float())
+    errs = [max(float((a.float() - r).abs().max() / r.abs().max()) for a, r in zip(res[s][0], gr)) for s in (True, False)]
+    gb = 7 * T * P * C * 2 / 1e9
+    print(f"T {T:2d} P {P:5d} C {C:4d}: err new {errs[0]:.1e} old {errs[1]:.1e}   new {res[True][1]:7.1f} us ({gb / res[True][1] * 1e3:5.2f} TB/s on 7 tensor passes)   old {res[False][1]:7.1f} us", flush=True)

@@ -226,6 +226,34 @@ def test_short_row_attention_kernel_matches_fp32_and_the_general_kernel(dtype, B
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk,fm", [(3000, 5, 25, 25, True), (37, 3, 32, 32, True), (9, 2, 1, 1, False), (130, 4, 25, 17, False),
+                                          (3, 1, 7, 32, True), (20000, 1, 2, 3, False)])
+def test_short_row_attention_backward_kernel_matches_fp32_and_the_general_kernels(dtype, B, H, Nq, Nk, fm, monkeypatch):
+    """dQ, dK, dV of rows of <= 32 queries and keys come from ONE wave-per-item kernel (`k_attn_short_bwd`; delta = rowsum(P o dP)
+    instead of rowsum(dO o O)): against autograd through the fp32 form (the tolerance of the general backward test) and against the
+    three general kernels on the same inputs (they differ by delta's rounding: O is 16 bit there)."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(B + 11 * Nq + Nk)
+    C = H * 64
+    shq, shk = ((Nq, B, C), (Nk, B, C)) if fm else ((B, Nq, C), (B, Nk, C))
+    q = (torch.randn(shq, device=DEV, generator=g) * 1.3).to(dtype).requires_grad_(True)
+    k, v = (torch.randn(shk, device=DEV, generator=g).to(dtype).requires_grad_(True) for _ in range(2))
+    go = torch.randn(shq, device=DEV, generator=g).to(dtype)
+    monkeypatch.delenv("GVD_ATTN_NO_SHORT", raising=False)
+    gs = torch.autograd.grad(ops.attention(q, k, v, H, frame_major=fm), (q, k, v), go)
+    monkeypatch.setenv("GVD_ATTN_NO_SHORT", "1")
+    gg = torch.autograd.grad(ops.attention(q, k, v, H, frame_major=fm), (q, k, v), go)
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    gr = torch.autograd.grad(ops.attention_math(qf, kf, vf, H, frame_major=fm), (qf, kf, vf), go.float())
+    tol = 6e-3 if dtype == torch.float16 else 3e-2
+    for name, a, b_, r in zip(("dq", "dk", "dv"), gs, gg, gr):
+        den = max(float(r.abs().max()), 1.0)
+        assert a.shape == r.shape and a.dtype == dtype
+        assert float((a.float() - r).abs().max()) / den < tol, (name, float((a.float() - r).abs().max()) / den)
+        assert float((a.float() - b_.float()).abs().max()) / den < tol / 2, name
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (33, 1280), (5, 2048), (1, 8)])
 def test_layer_norm_row_kernel_matches_fp32_layer_norm(dtype, M, C):
     """Tolerance: one rounding of the 16-bit output type (2^-11 rel for f16, 2^-8 for bf16) on |y| <~ 6."""
