@@ -937,6 +937,31 @@ __global__ void __launch_bounds__(256) k_layer_norm(const T* __restrict__ x, T* 
     }
 }
 
+// Phi(g) = 0.5 (1 + erf(g / sqrt 2)) and E = exp(-g^2 / 2) without libdevice's erff (~40 VALU): the complementary error function in
+// the Chebyshev form  erfc(z) = t exp(-z^2 + c(t)),  t = 1 / (1 + z / 2)  (Numerical Recipes' erfcc: FRACTIONAL error < 1.2e-7 for all
+// z >= 0 -- the negative tail of the gate, where gelu is 1e-4 .. 1e-7, keeps its relative accuracy, which the 1.5e-7 ABSOLUTE bound of
+// the shorter Abramowitz-Stegun form in gemm_mfma.hip's fused epilogue does not give; these row kernels sit at the HBM rate either
+// way).  Phi = 1 - erfc/2 for g >= 0, erfc/2 for g < 0: no cancellation.  The two row kernels were VALU-bound with erff + expf
+// (197 us for the 717 MB of a level-0 gate gradient: 3.6 TB/s); they now move their bytes at 5.5-5.8 TB/s.
+__device__ __forceinline__ void gelu_cdf_exp(float g, float& cdf, float& e)
+{
+    const float z = fabsf(g) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.f));
+    float c = fmaf(t, 0.17087277f, -0.82215223f);
+    c = fmaf(t, c, 1.48851587f);
+    c = fmaf(t, c, -1.13520398f);
+    c = fmaf(t, c, 0.27886807f);
+    c = fmaf(t, c, -0.18628806f);
+    c = fmaf(t, c, 0.09678418f);
+    c = fmaf(t, c, 0.37409196f);
+    c = fmaf(t, c, 1.00002368f);
+    c = fmaf(t, c, -1.26551223f);
+    const float mz2 = (-0.5f * 1.4426950408889634f) * (g * g);   // -z^2 log2(e)
+    e = __builtin_amdgcn_exp2f(mz2);
+    const float half_erfc = (0.5f * t) * __builtin_amdgcn_exp2f(fmaf(c, 1.4426950408889634f, mz2));
+    cdf = g >= 0.f ? 1.f - half_erfc : half_erfc;
+}
+
 // GEGLU gate (attention.py:415-423): y[m, c] = h[m, c] * gelu(h[m, C + c]) for h = proj(x) of width 2C; exact (erf) GELU.
 template <typename T>
 __global__ void __launch_bounds__(256) k_geglu(const T* __restrict__ h, T* __restrict__ y, long long M, int C)
@@ -954,7 +979,9 @@ __global__ void __launch_bounds__(256) k_geglu(const T* __restrict__ h, T* __res
         for (int k = 0; k < 8; k++) {
             const float gf = to_f(g[k]);
             // torch evaluates gelu in fp32 and rounds to the 16-bit type before the product (two separate ops)
-            const T ge = (T)(0.5f * gf * (1.f + erff(gf * 0.70710678118654752f)));
+            float cdf, e;
+            gelu_cdf_exp(gf, cdf, e);
+            const T ge = (T)(gf * cdf);
             r[k] = (T)(to_f(a[k]) * to_f(ge));
         }
         *reinterpret_cast<vec8*>(y + m * C + o * 8) = r;
@@ -962,22 +989,29 @@ __global__ void __launch_bounds__(256) k_geglu(const T* __restrict__ h, T* __res
 }
 
 // LayerNorm backward w.r.t. the input (weights frozen: guided sampler).  x_hat = (x - mu) rstd, g = dy gamma,
-// dx = rstd (g - mean(g) - x_hat mean(g x_hat)).  One wave per row, statistics recomputed from the row in registers.
-template <typename T>
+// dx = rstd (g - mean(g) - x_hat mean(g x_hat)) [+ add].  G lanes share a row (G = 8 for C <= 512, 16 for C <= 1024, 32 beyond:
+// every lane owns up to 8 16-byte chunks, chunk o = sub + G i), a wave covers 64 / G rows, the statistics are recomputed from the
+// row in registers.  (One wave per row, the first form, left 24 of 64 lanes idle at C = 320 and paid three 6-step wave reductions
+// per 640-byte row: 98 us for the 56 000 rows of a level-0 activation at 320x448, 1.45 TB/s; `k_row_stats` had the same disease.)
+template <typename T, int G>
 __global__ void __launch_bounds__(256) k_layer_norm_bwd(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ gamma,
                                                         const T* __restrict__ add, T* __restrict__ dx, long long M, int C, float eps)
 {
     typedef typename Tr<T>::vec8 vec8;
-    const int lane = threadIdx.x & 63, oct = C >> 3;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    constexpr int RPW = 64 / G, NV = 8;
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1), oct = C >> 3;
+    const long long row_ = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
+    const bool live = row_ < M;
+    const long long row = live ? row_ : M - 1;                // (dead rows recompute the last one and store nothing)
     const T* xr = x + row * C;
     const T* gr = dy + row * C;
-    vec8 v[4], g[4];
+    vec8 v[NV], g[NV];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int o = lane + 64 * j;
+    for (int j = 0; j < NV; j++) {
+        const int o = sub + G * j;
+        v[j] = vec8{};
+        g[j] = vec8{};
         if (o < oct) {
             v[j] = *reinterpret_cast<const vec8*>(xr + o * 8);
             g[j] = *reinterpret_cast<const vec8*>(gr + o * 8);
@@ -986,49 +1020,49 @@ __global__ void __launch_bounds__(256) k_layer_norm_bwd(const T* __restrict__ x,
         }
     }
 #pragma unroll
-    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);
+    for (int d = G / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (lane + 64 * j < oct) {
+    for (int j = 0; j < NV; j++)
+        if (sub + G * j < oct) {
 #pragma unroll
             for (int k = 0; k < 8; k++) { const float d = to_f(v[j][k]) - mean; q = fmaf(d, d, q); }
         }
 #pragma unroll
-    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off, 64);
+    for (int d = G / 2; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
     const float rstd = rsqrtf(q / (float)C + eps);
     float sg = 0.f, sgx = 0.f;
-    float gg[4][8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int o = lane + 64 * j;
+    for (int j = 0; j < NV; j++) {
+        const int o = sub + G * j;
         if (o < oct) {
             const vec8 gm = *reinterpret_cast<const vec8*>(gamma + o * 8);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const float gk = to_f(g[j][k]) * to_f(gm[k]);
-                gg[j][k] = gk;
                 sg += gk;
                 sgx = fmaf(gk, (to_f(v[j][k]) - mean) * rstd, sgx);
             }
         }
     }
 #pragma unroll
-    for (int off = 32; off; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgx += __shfl_xor(sgx, off, 64); }
+    for (int d = G / 2; d >= 1; d >>= 1) { sg += __shfl_xor(sg, d, 64); sgx += __shfl_xor(sgx, d, 64); }
     const float mg = sg / (float)C, mgx = sgx / (float)C;
     T* dr = dx + row * C;
     // `add`: the gradient that reaches the same tensor along the residual branch (x feeds LayerNorm -> ... and `+ x`): summed here in
     // fp32, one rounding, instead of a separate accumulation kernel over the two 16-bit gradients (3 more passes over [M, C])
     const T* ar = add ? add + row * C : nullptr;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int o = lane + 64 * j;
-        if (o < oct) {
+    for (int j = 0; j < NV; j++) {
+        const int o = sub + G * j;
+        if (o < oct && live) {
             vec8 r, av = vec8{};
             if (ar) av = *reinterpret_cast<const vec8*>(ar + o * 8);
+            const vec8 gm = *reinterpret_cast<const vec8*>(gamma + o * 8);   // (again: 64 registers of products would not stay resident)
 #pragma unroll
-            for (int k = 0; k < 8; k++) r[k] = (T)(rstd * (gg[j][k] - mg - (to_f(v[j][k]) - mean) * rstd * mgx) + to_f(av[k]));
+            for (int k = 0; k < 8; k++)
+                r[k] = (T)(rstd * (to_f(g[j][k]) * to_f(gm[k]) - mg - (to_f(v[j][k]) - mean) * rstd * mgx) + to_f(av[k]));
             *reinterpret_cast<vec8*>(dr + o * 8) = r;
         }
     }
@@ -1052,8 +1086,9 @@ __global__ void __launch_bounds__(256) k_geglu_bwd(const T* __restrict__ h, cons
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const float gf = to_f(g[k]), df = to_f(d[k]);
-            const float cdf = 0.5f * (1.f + erff(gf * 0.70710678118654752f));
-            const float pdf = 0.3989422804014327f * __expf(-0.5f * gf * gf);
+            float cdf, e;
+            gelu_cdf_exp(gf, cdf, e);
+            const float pdf = 0.3989422804014327f * e;
             ra[k] = (T)(df * gf * cdf);
             rg[k] = (T)(df * to_f(a[k]) * fmaf(gf, pdf, cdf));
         }
@@ -1351,9 +1386,13 @@ int gvd_layer_norm_bwd_add(const void* x, const void* dy, const void* gamma, con
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !dy || !gamma || !dx || M <= 0 || C <= 0 || (C % 8) || C > 2048) return fail(-1, "gvd_layer_norm_bwd: bad arguments (C % 8 == 0, C <= 2048)");
     if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)add) & 15) return fail(-1, "gvd_layer_norm_bwd: pointers must be 16-byte aligned");
-    const dim3 grid((unsigned)((M + 3) / 4));
-    if (is_bf16) hipLaunchKernelGGL(k_layer_norm_bwd<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (const __bf16*)gamma, (const __bf16*)add, (__bf16*)dx, M, C, eps);
-    else hipLaunchKernelGGL(k_layer_norm_bwd<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)dy, (const _Float16*)gamma, (const _Float16*)add, (_Float16*)dx, M, C, eps);
+    const int G = C <= 512 ? 8 : (C <= 1024 ? 16 : 32);
+    const long long rows_per_block = 4 * (64 / G);
+    const dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block));
+#define GVD_LNB(T, GG) hipLaunchKernelGGL((k_layer_norm_bwd<T, GG>), grid, dim3(256), 0, stream, (const T*)x, (const T*)dy, (const T*)gamma, (const T*)add, (T*)dx, M, C, eps)
+    if (is_bf16) { if (G == 8) GVD_LNB(__bf16, 8); else if (G == 16) GVD_LNB(__bf16, 16); else GVD_LNB(__bf16, 32); }
+    else { if (G == 8) GVD_LNB(_Float16, 8); else if (G == 16) GVD_LNB(_Float16, 16); else GVD_LNB(_Float16, 32); }
+#undef GVD_LNB
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_layer_norm_bwd", e);
     return 0;

@@ -275,18 +275,24 @@ def test_layer_norm_row_kernel_matches_fp32_layer_norm(dtype, M, C):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,C", [(999, 1280), (64, 2560), (3, 8)])
 def test_geglu_kernel_matches_torch_two_op_form_bitwise(dtype, M, C):
-    """The kernel reproduces torch's two roundings (gelu -> 16 bit, product -> 16 bit); erf implementations may
-    differ in the last fp32 ulp, so allow one 16-bit ulp on a handful of elements and exactness elsewhere."""
+    """The kernel reproduces torch's two roundings (gelu -> 16 bit, product -> 16 bit).  Its Phi comes from a fractional-error erfc
+    (diffusion_kernels.hip: gelu_cdf_exp), torch's from 0.5 (1 + erf) in fp32, which cancels in the negative tail; so the judge is the
+    float64 evaluation with the same two roundings: the kernel differs from it on no more elements than torch's own fp32 form does
+    (+ slack), never by more than two 16-bit spacings, and agrees with torch's form bit for bit on > 99 % of the elements."""
     from lvdm_amd import ops
     g = torch.Generator(device=DEV).manual_seed(M * C)
     h = (torch.randn(M, 2 * C, device=DEV, generator=g) * 1.5).to(dtype)
     y = ops.geglu(h)
     ref = ops.geglu_math(h)
     assert y.shape == (M, C) and y.dtype == dtype
-    diff = (y.float() - ref.float()).abs()
-    ulp = (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) * ref.float().abs().clamp_min(1e-3)
-    assert bool((diff <= ulp).all())
-    assert float((diff > 0).float().mean()) < 1e-2
+    a64, g64 = h[:, :C].double(), h[:, C:].double()
+    ge = (0.5 * g64 * (1.0 + torch.erf(g64 * 0.7071067811865476))).to(dtype)
+    y64 = (a64 * ge.double()).to(dtype)
+    miss_k, miss_t = float((y != y64).float().mean()), float((ref != y64).float().mean())
+    assert miss_k <= 1.5 * miss_t + 1e-3, (miss_k, miss_t)
+    spacing2 = (2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6) * y64.float().abs().clamp_min(1e-3)
+    assert bool(((y.float() - y64.float()).abs() <= spacing2).all())
+    assert float((y != ref).float().mean()) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
