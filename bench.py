@@ -766,7 +766,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     # around every launch of the two MFMA kernel families -- the implicit-GEMM convolutions and flash attention.
     from lvdm_amd import conv as mconv
     ev_attn, ev_conv = [], []
-    orig_attn, orig_conv = ops._hip_attention_fwd, mconv._launch
+    orig_attn, orig_conv, orig_split, orig_sheet = ops._hip_attention_fwd, mconv._launch, mconv._split_conv, mconv._sheet_conv
+    inside = [False]   # a frame-sheet convolution brackets its three launches as ONE convolution of the per-frame problem
 
     def timed_attn(q, k, v, heads, frame_major=False, want_lse=False, **kw):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -778,11 +779,35 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         return o
 
     def timed_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw):
+        if inside[0]:
+            return orig_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         o = orig_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw)
         b.record()
         ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * (3 if mode == mconv.TEMPORAL else 9), ("conv", mode, N, H, W, Cin, Cout, int(kw.get("upsample", 0) or 0))))
+        return o
+
+    def timed_split(xx, wpk, Cout, mode, N, H, W, Cin, ksplit, **kw):      # split-K slices + their sum: one convolution
+        if inside[0]:
+            return orig_split(xx, wpk, Cout, mode, N, H, W, Cin, ksplit, **kw)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        o = orig_split(xx, wpk, Cout, mode, N, H, W, Cin, ksplit, **kw)
+        b.record()
+        ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * (3 if mode == mconv.TEMPORAL else 9), ("conv", mode, N, H, W, Cin, Cout, 0)))
+        return o
+
+    def timed_sheet(xx, weight, backward, Cout, N, H, W, Cin, Q, **kw):     # sheet in + convolution (+ slices) + sheet out
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        inside[0] = True
+        try:
+            o = orig_sheet(xx, weight, backward, Cout, N, H, W, Cin, Q, **kw)
+        finally:
+            inside[0] = False
+        b.record()
+        ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * 9, ("conv", mconv.SPATIAL, N, H, W, Cin, Cout, 0)))
         return o
 
     from lvdm_amd import gemm as mgemm
@@ -815,6 +840,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     graph_was = sampler.graph_apply
     sampler.graph_apply = False
     ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
+    mconv._split_conv, mconv._sheet_conv = timed_split, timed_sheet
     xi = x
     t1 = time.perf_counter()
     try:
@@ -824,6 +850,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         el_inst = max(time.perf_counter() - t1, 1e-9)
     finally:
         ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = orig_attn, orig_conv, orig_gemm
+        mconv._split_conv, mconv._sheet_conv = orig_split, orig_sheet
         sampler.graph_apply = graph_was
     assert torch.isfinite(xi).all()
     if os.environ.get("GVD_BENCH_TORCH_PROFILE"):   # dev: where do the step's copy / fill / add / cat launches come from?  (op, first package frame) table

@@ -73,6 +73,8 @@ struct ConvArgs {
     int pad_lo;               // stride-2 mode: zero rows / columns in front of the image (1: U-Net Downsample, 0: VAE Downsample)
     int tiles_x, tiles_y;
     int nchunks;
+    int cps;              // split-K: input-channel chunks per blockIdx.z slice (== nchunks: no split); slice z writes its partial sums to
+    long long split_stride;   // out + z * split_stride (elements); no bias / add / residual / statistics on such launches
     int cpg, G, R;
     int PB;               // temporal: pixels per tile
     int NS;               // temporal: samples in this launch (x / out / res / bx are [NS][N frames][W pixels][C]; coef, statistics and
@@ -170,6 +172,8 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     const int wm = wave / WN, wn = wave % WN;
     const int co_tile = blockIdx.y;
     const int Cin = a.Cin, Cout = a.Cout;
+    const int chunk0 = blockIdx.z * a.cps;                                                     // split-K slice: chunks [chunk0, chunk0 + nloc)
+    const int nloc = a.nchunks - chunk0 < a.cps ? a.nchunks - chunk0 : a.cps;
 
     // ---- tile origin ----
     constexpr bool SPATIAL = MODE != 2;
@@ -250,14 +254,14 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 #pragma unroll
     for (int i = 0; i < PPT; i++) loff[i] = loff[i] < 0 ? 2 * PBYTES : loff[i];      // (relative to pbuf: pbuf + 2 PBYTES == dummy)
     auto load_cf = [&](int chunk) {
-        const int c0 = chunk * BK + k8 * 8;
+        const int c0 = (chunk0 + chunk) * BK + k8 * 8;
         const float4* cp = reinterpret_cast<const float4*>(coef + (c0 < Cin ? c0 : 0));
 #pragma unroll
         for (int j = 0; j < 4; j++) cfr[j] = cp[j];
     };
     auto load_p = [&](int chunk, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
-        const int c0 = chunk * BK + k8 * 8;
+        const int c0 = (chunk0 + chunk) * BK + k8 * 8;
         const int c0s = c0 < Cin ? c0 : 0;
         if (HALF == 0) chan_ok = c0 < Cin;       // (both halves of a patch are written before the next patch's first half is fetched)
 #pragma unroll
@@ -289,8 +293,8 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     typedef std::integral_constant<int, 1> H1;
 
     // ---- weight staging (linear copy of the pre-swizzled slab), one step ahead ----
-    const T* __restrict__ wt = (const T*)a.w + (size_t)co_tile * a.nchunks * NTAPS * (BN * BK);
-    const int total = a.nchunks * NTAPS;
+    const T* __restrict__ wt = (const T*)a.w + ((size_t)co_tile * a.nchunks + chunk0) * NTAPS * (BN * BK);
+    const int total = nloc * NTAPS;
     vec8 wreg[WPT];
     auto load_w = [&](int it) {
         const T* src = wt + (size_t)(it < total ? it : total - 1) * (BN * BK);
@@ -339,8 +343,8 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
         if (!WHOLE) load_p(0, H1{});
         store_p(0, H1{});
         GVD_CSTAMP(1);
-        const int last = a.nchunks - 1;
-        for (int chunk = 0; chunk < a.nchunks; chunk++) {
+        const int last = nloc - 1;
+        for (int chunk = 0; chunk < nloc; chunk++) {
             const int nxt = chunk < last ? chunk + 1 : last;      // (the last chunk re-fetches itself: never read)
             const int pcur = chunk & 1;
 #pragma unroll
@@ -390,7 +394,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     GVD_CSTAMP(2);
 
     // ---- epilogue ----
-    T* __restrict__ out = (T*)a.out;
+    T* __restrict__ out = (T*)a.out + (size_t)blockIdx.z * (size_t)a.split_stride;
     const T* __restrict__ res = (const T*)a.res;
     const T* __restrict__ bx = (const T*)a.bx;
     float ssum[8], ssq[8];
@@ -881,6 +885,108 @@ void choose(int mode, int N, int H, int W, int Cout, int* cfg, int* tw32)
     if (mode == 0) *tw32 = width32(CFG_PIX[c]);
 }
 
+// ---- frame sheets for maps smaller than a tile ---------------------------------------------------------------------------------
+// A 5 x 7, 10 x 14 or 9 x 16 latent fills 27-56 % of the smallest spatial tile (16 x 8 pixels), and tiles do not span frames: the
+// level-3 convolutions of the U-Net ran at 180-430 TFLOP/s.  The frames of such a launch are laid out as ONE sheet -- Q maps side by
+// side, R down, one ZERO row / column between neighbours (the zero padding both share) -- the ordinary 3 x 3 kernel runs on the
+// sheet as a single image (72-88 % of the tile slots real), and the maps are cut out again.  k_sheet_in also applies the
+// GroupNorm + SiLU affine that the convolution's prologue would have (per FRAME coefficients: the sheet is one image); k_sheet_out
+// adds the per-frame embedding term and the residual (fp32 sum, one rounding).  Both move a few MB.
+template <typename T>
+__global__ void __launch_bounds__(256) k_sheet_in(const T* __restrict__ x, T* __restrict__ v, const float2* __restrict__ coef, int silu,
+                                                  int N, int H, int W, int C, int Q, int Hv, int Wv)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    const int oct = C >> 3;
+    const long long total = (long long)Hv * Wv * oct;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / oct;
+        const int o = (int)(i - pix * oct), vr = (int)(pix / Wv), vc = (int)(pix - (long long)vr * Wv);
+        const int r = vr / (H + 1), y = vr - r * (H + 1), q = vc / (W + 1), xx = vc - q * (W + 1), n = r * Q + q;
+        vec8 val = vec8{};
+        if (y < H && xx < W && n < N) {
+            val = *reinterpret_cast<const vec8*>(x + (((size_t)n * H + y) * W + xx) * C + o * 8);
+            if (coef) {
+                const float4* cf = reinterpret_cast<const float4*>(coef + (size_t)n * C + o * 8);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float4 ab = cf[k];
+                    float f0 = fmaf((float)val[2 * k], ab.x, ab.y), f1 = fmaf((float)val[2 * k + 1], ab.z, ab.w);
+                    if (silu) { f0 = silu32(f0); f1 = silu32(f1); }
+                    val[2 * k] = (T)f0;
+                    val[2 * k + 1] = (T)f1;
+                }
+            }
+        }
+        *reinterpret_cast<vec8*>(v + (size_t)i * 8) = val;
+    }
+}
+
+// out[n][r][c] = sum over the split-K slices of the convolution's partial sums + bias[c] + add_nc[n][c] + res[n][r][c] (fp32 sum, one
+// rounding), read either from a plain [n][r][c] result (SHEET = false) or from the cells of a frame sheet; with `stats`, also the sum and
+// sum of squares of the ROUNDED outputs per (n, group) for the next GroupNorm (what a convolution epilogue leaves; fp64 atomics onto
+// [n][G][2], zeroed by the caller).  Lane map of the NSC norm kernels: a thread owns a channel octet and streams down a strip of rows.
+template <typename T, bool SHEET>
+__global__ void __launch_bounds__(256) k_slices_out(const T* __restrict__ part, T* __restrict__ out, const float* __restrict__ bias,
+                                                    const T* __restrict__ add_nc, const T* __restrict__ res, double* __restrict__ stats,
+                                                    int C, int G, long long S, int rows_per_block, int slices, long long slice_stride,
+                                                    int H, int W, int Q, int Wv)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    extern __shared__ double sh_g[];   // [G][2] when stats
+    const int n = blockIdx.y, oct = C >> 3, cpg = G > 0 ? C / G : C;
+    if (stats) {
+        for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.0;
+        __syncthreads();
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
+    const int Wd = oct < 256 ? oct : 256, rstep = 256 / Wd, lane_row = threadIdx.x / Wd;
+    const size_t cell0 = SHEET ? ((size_t)(n / Q) * (H + 1) * Wv + (size_t)(n % Q) * (W + 1)) : 0;
+    for (int o = threadIdx.x % Wd; o < oct && lane_row < rstep; o += Wd) {
+        float c0[8], s[8], q[8];
+        vec8 a = vec8{};
+        if (add_nc) a = *reinterpret_cast<const vec8*>(add_nc + (size_t)n * C + o * 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { c0[k] = (bias ? bias[o * 8 + k] : 0.f) + (float)a[k]; s[k] = 0.f; q[k] = 0.f; }
+        for (long long r = r0 + lane_row; r < r1; r += rstep) {
+            const size_t gi = ((size_t)n * S + r) * C + o * 8;
+            size_t si = gi;
+            if (SHEET) { const int y = (int)(r / W), xx = (int)(r - (long long)y * W); si = (cell0 + (size_t)y * Wv + xx) * C + o * 8; }
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) f[k] = c0[k];
+            for (int sl = 0; sl < slices; sl++) {
+                const vec8 p = *reinterpret_cast<const vec8*>(part + (size_t)sl * (size_t)slice_stride + si);
+#pragma unroll
+                for (int k = 0; k < 8; k++) f[k] += (float)p[k];
+            }
+            vec8 rr = vec8{}, val;
+            if (res) rr = *reinterpret_cast<const vec8*>(res + gi);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                val[k] = (T)(f[k] + (float)rr[k]);
+                const float g = (float)val[k];
+                s[k] += g;
+                q[k] = fmaf(g, g, q[k]);
+            }
+            *reinterpret_cast<vec8*>(out + gi) = val;
+        }
+        if (stats) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int g = (o * 8 + k) / cpg;
+                atomicAdd(&sh_g[2 * g], (double)s[k]);
+                atomicAdd(&sh_g[2 * g + 1], (double)q[k]);
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[(size_t)n * 2 * G + i], sh_g[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -899,9 +1005,12 @@ int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block
 static int conv_launch(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
                        const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
                        int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream_,
-                       const void* bwd_x, const float* bwd_coef, int bwd_coef_per_n, const float* bwd_gamma, int bwd_silu)
+                       const void* bwd_x, const float* bwd_coef, int bwd_coef_per_n, const float* bwd_gamma, int bwd_silu,
+                       int ksplit = 1, int* n_slices = nullptr)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (ksplit < 1 || (ksplit > 1 && (bias || add_nc || residual || stats || bwd_x || mode > 1 || upsample)))
+        return fail(-1, "gvd_conv_mfma_splitk: a split launch is a plain stride-1 convolution (optional prologue); the sums take the rest");
     if (bwd_x) {
         if (!stats || !bwd_gamma || (bwd_silu && !bwd_coef) || (Cout & 7) || mode > 1 || upsample || ((uintptr_t)bwd_x & 15) || ((uintptr_t)bwd_coef & 15))
             return fail(-1, "gvd_conv_mfma_norm_bwd: needs stats, gamma (and the forward affine with SiLU), Cout % 8 == 0, a stride-1 mode, aligned pointers");
@@ -937,12 +1046,17 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
     a.NS = NS;
     if (in_elems >= (1LL << 31) || out_elems >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
     a.nchunks = (Cin + BK - 1) / BK;
+    a.cps = (a.nchunks + ksplit - 1) / ksplit;
+    a.split_stride = out_elems;
+    const int slices = (a.nchunks + a.cps - 1) / a.cps;
+    if (n_slices) *n_slices = slices;
     a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
     a.coef_per_n = coef_per_n;
     a.bx = bwd_x; a.bcoef = reinterpret_cast<const float2*>(bwd_coef); a.bgamma = bwd_gamma; a.bsilu = bwd_silu ? 1 : 0;
     a.bcoef_per_n = bwd_coef_per_n;
     dim3 grid;
     grid.y = (Cout + BN - 1) / BN;
+    grid.z = (unsigned)slices;
     hipError_t e;
     if (mode != 1) {
         const int tw = (mode >= 2 || tw32) ? 32 : 16, th = PIX / tw;
@@ -972,6 +1086,14 @@ int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int co
                        H_in, W_in, Cin, Cout, upsample, silu, is_bf16, stream, nullptr, nullptr, 0, nullptr, 0);
 }
 
+int gvd_conv_mfma_splitk(const void* x, const void* w_packed, const float* coef, int coef_per_n, void* partials, int ksplit,
+                         int* n_slices, int mode, int N, int H, int W, int Cin, int Cout, int silu, int is_bf16, void* stream)
+{
+    if (!n_slices) return fail(-1, "gvd_conv_mfma_splitk: n_slices is required");
+    return conv_launch(x, w_packed, coef, coef_per_n, nullptr, nullptr, nullptr, partials, nullptr, 0, 0, mode, N, H, W, 0, 0, Cin, Cout, 0,
+                       silu, is_bf16, stream, nullptr, nullptr, 0, nullptr, 0, ksplit, n_slices);
+}
+
 int gvd_conv_mfma_norm_bwd(const void* g, const void* w_packed_bwd, void* d_act, double* bwd_stats, int stats_replicas, int groups,
                            int mode, int N, int H, int W, int Cin, int Cout, const void* norm_x, const float* norm_coef,
                            int norm_coef_per_n, const float* norm_gamma, int norm_silu, int is_bf16, void* stream)
@@ -986,6 +1108,60 @@ int gvd_conv_trace_read(unsigned long long* host, int n)
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ctrace), sizeof(unsigned long long) * (n < 2048 * 6 ? n : 2048 * 6)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+int gvd_conv_sheet_in(const void* x, void* sheet, const float* coef, int silu, int N, int H, int W, int C, int Q, int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !sheet || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || Q <= 0 || (((uintptr_t)x | (uintptr_t)sheet | (uintptr_t)coef) & 15))
+        return fail(-1, "gvd_conv_sheet_in: bad arguments (C % 8 == 0, 16-byte aligned tensors)");
+    const int R = (N + Q - 1) / Q, Hv = R * (H + 1) - 1, Wv = Q * (W + 1) - 1;
+    const long long total = (long long)Hv * Wv * (C >> 3);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (is_bf16) hipLaunchKernelGGL(k_sheet_in<__bf16>, dim3(blocks), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)sheet, reinterpret_cast<const float2*>(coef), silu, N, H, W, C, Q, Hv, Wv);
+    else hipLaunchKernelGGL(k_sheet_in<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)x, (_Float16*)sheet, reinterpret_cast<const float2*>(coef), silu, N, H, W, C, Q, Hv, Wv);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_sheet_in", e);
+    return 0;
+}
+
+static int slices_out(bool sheet, const void* part, int slices, long long slice_stride, void* out, const float* bias, const void* add_nc,
+                      const void* residual, double* stats, int groups, int n, long long S, int C, int H, int W, int Q, int Wv, int is_bf16,
+                      hipStream_t stream)
+{
+    // strips of rows per block: ~1024 blocks in flight, short strips for small maps (see gn_rows_per_block in diffusion_kernels.hip)
+    long long rows = ((long long)n * S + 1023) / 1024;
+    rows = rows < 4 ? 4 : (rows > 128 ? 128 : rows);
+    dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)n);
+    const size_t sh = stats ? (size_t)groups * 16 : 0;
+#define GVD_SO(T, SH) hipLaunchKernelGGL((k_slices_out<T, SH>), grid, dim3(256), sh, stream, (const T*)part, (T*)out, bias, (const T*)add_nc, (const T*)residual, stats, C, groups, S, (int)rows, slices, slice_stride, H, W, Q, Wv)
+    if (is_bf16) { if (sheet) GVD_SO(__bf16, true); else GVD_SO(__bf16, false); }
+    else { if (sheet) GVD_SO(_Float16, true); else GVD_SO(_Float16, false); }
+#undef GVD_SO
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_slices_out", e);
+    return 0;
+}
+
+int gvd_conv_sheet_out(const void* sheet, int slices, void* out, const float* bias, const void* add_nc, const void* residual, double* stats,
+                       int groups, int N, int H, int W, int C, int Q, int is_bf16, void* stream_)
+{
+    if (!sheet || !out || slices < 1 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || Q <= 0 || (stats && (groups <= 0 || C % groups)) ||
+        (((uintptr_t)sheet | (uintptr_t)out | (uintptr_t)add_nc | (uintptr_t)residual) & 15))
+        return fail(-1, "gvd_conv_sheet_out: bad arguments (C % 8 == 0, 16-byte aligned tensors, C % groups == 0)");
+    const int R = (N + Q - 1) / Q, Hv = R * (H + 1) - 1, Wv = Q * (W + 1) - 1;
+    return slices_out(true, sheet, slices, (long long)Hv * Wv * C, out, bias, add_nc, residual, stats, groups, N, (long long)H * W, C, H, W, Q, Wv,
+                      is_bf16, (hipStream_t)stream_);
+}
+
+int gvd_conv_sum_slices(const void* partials, int slices, void* out, const float* bias, const void* residual, double* stats, int groups,
+                        int n_stat, long long rows, int C, int is_bf16, void* stream_)
+{
+    if (!partials || !out || slices < 1 || n_stat <= 0 || rows <= 0 || rows % n_stat || C <= 0 || (C & 7) || (stats && (groups <= 0 || C % groups)) ||
+        (((uintptr_t)partials | (uintptr_t)out | (uintptr_t)residual) & 15))
+        return fail(-1, "gvd_conv_sum_slices: bad arguments (C % 8 == 0, rows % n_stat == 0, 16-byte aligned tensors, C % groups == 0)");
+    return slices_out(false, partials, slices, rows * C, out, bias, nullptr, residual, stats, groups, n_stat, rows / n_stat, C, 0, 0, 1, 0, is_bf16,
+                      (hipStream_t)stream_);
+}
 
 int gvd_group_norm_merge(double* stats, const double* partial, int replicas, int merge, int N, int G, void* stream_)
 {

@@ -206,6 +206,120 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
     return out, None
 
 
+SHEETS = os.environ.get("GVD_CONV_SHEETS", "1") == "1"   # 0: small maps run one tile (or two) per frame, as before round 4 (A/B runs, tests)
+SHEET_MAX_PIXELS = 256
+
+
+def _sheet_plan(N, H, W):
+    """Maps per sheet row (Q >= 1) if the N maps of H x W pixels should run as ONE frame sheet (csrc/conv_mfma.hip: k_sheet_in), else
+    0.  A map smaller than the 16 x 8 tile wastes the rest of it (5 x 7: 73 %, 10 x 14 and 9 x 16: 44 %); on the sheet the tiles span
+    maps.  Taken when the padded tile area shrinks by >= 17 %."""
+    if not SHEETS or N < 2 or H * W > SHEET_MAX_PIXELS:
+        return 0
+
+    def padded(h, w):   # tile slots of the better of the two 128-pixel tile shapes (16 x 8, 32 x 4)
+        return min(-(-h // (128 // tw)) * (128 // tw) * (-(-w // tw) * tw) for tw in (16, 32))
+
+    now = N * padded(H, W)
+    best_q, best = 0, now
+    for q in (1, 2, 4):
+        if q > N:
+            break
+        a = padded(-(-N // q) * (H + 1) - 1, q * (W + 1) - 1)
+        if a < best:
+            best_q, best = q, a
+    return best_q if best * 1.2 <= now else 0
+
+
+SPLITK = os.environ.get("GVD_CONV_SPLITK", "1") == "1"   # 0: no split-K launches (A/B runs, tests)
+
+
+def _groups(mode, N, H, W, Cin, Cout):
+    """Workgroups gvd_conv_mfma launches for this problem (csrc/conv_mfma.hip: choose / conv_launch)."""
+    BN, pix, tw = config(mode, N, H, W, Cin, Cout)
+    cols = -(-Cout // BN)
+    if mode == TEMPORAL:
+        return -(-W // max(1, min(pix // N, 32))) * H * cols
+    return N * -(-H // (pix // tw)) * -(-W // tw) * cols
+
+
+def _ksplit(mode, N, H, W, Cin, Cout):
+    """Split-K factor: launches of fewer workgroups than the chip has slots (2 x 256) whose reduction is long -- the deepest U-Net
+    level: 190-320 workgroups walking K = 9 x 1280 ... 9 x 2560, the temporal form at 35 / 144 pixels -- are cut along the input
+    channels into ~1000 workgroups (>= 8 chunks of 32 channels each); the fp32 sum of the slices is a pass over a few MB."""
+    nchunks = -(-Cin // 32)
+    if not SPLITK or nchunks < 16 or mode not in (SPATIAL, TEMPORAL):
+        return 1
+    g = _groups(mode, N, H, W, Cin, Cout)
+    if g >= 448:
+        return 1
+    k = min(8, nchunks // 8, int(1024 / g + 0.5))
+    return k if k >= 2 else 1
+
+
+def _launch_split(x, wpk, Cout, mode, N, H, W, Cin, ksplit, *, coef_ptr=None, silu=False):
+    """The convolution as `ksplit` input-channel slices (gvd_conv_mfma_splitk): 16-bit partial sums [slices, ...out...], slices."""
+    P = ctypes.c_void_p
+    shape = ((N, W, Cout) if H == 1 else (H, N, W, Cout)) if mode == TEMPORAL else (N, H, W, Cout)
+    part = torch.empty((ksplit,) + shape, dtype=x.dtype, device=x.device)
+    n_sl = ctypes.c_int(0)
+    with ops._on(x.device):
+        ops._check(ops.lib().gvd_conv_mfma_splitk(P(x.data_ptr()), P(wpk.data_ptr()), P(coef_ptr), 1, P(part.data_ptr()), int(ksplit),
+                                                  ctypes.byref(n_sl), mode, N, H, W, Cin, Cout, int(bool(silu)),
+                                                  1 if x.dtype == torch.bfloat16 else 0, P(ops._stream())))
+    return part, n_sl.value
+
+
+def _sum_slices(part, slices, bias, residual, n_stat=1, stats_groups=0):
+    """out = sum of the split-K slices + bias + residual (fp32, one rounding); with stats_groups also the PartialStats of out per
+    (sample of n_stat, group), accumulated in the same pass."""
+    P, LL = ctypes.c_void_p, ctypes.c_longlong
+    out = torch.empty(part.shape[1:], dtype=part.dtype, device=part.device)
+    C = out.shape[-1]
+    sums = _ZeroArena.take((1, n_stat, stats_groups, 2), part.device) if stats_groups else None
+    with ops._on(part.device):
+        ops._check(ops.lib().gvd_conv_sum_slices(P(part.data_ptr()), int(slices), P(out.data_ptr()), P(None if bias is None else bias.data_ptr()),
+                                                 P(None if residual is None else residual.data_ptr()), P(None if sums is None else sums.data_ptr()),
+                                                 int(stats_groups), int(n_stat), LL(out.numel() // C), C,
+                                                 1 if part.dtype == torch.bfloat16 else 0, P(ops._stream())))
+    return out, (PartialStats(sums, 1, n_stat, stats_groups, out.numel() // (n_stat * C)) if stats_groups else None)
+
+
+def _split_conv(x, wpk, Cout, mode, N, H, W, Cin, ksplit, *, coef_ptr=None, silu=False, bias=None, residual=None, n_stat=1, stats_groups=0):
+    """conv(act(x)) + bias + residual as split-K slices and their sum: (out, PartialStats | None)."""
+    part, slices = _launch_split(x, wpk, Cout, mode, N, H, W, Cin, ksplit, coef_ptr=coef_ptr, silu=silu)
+    return _sum_slices(part, slices, bias, residual, n_stat, stats_groups)
+
+
+def _sheet_conv(x, weight, backward, Cout, N, H, W, Cin, Q, *, pad=0, coef_ptr=None, silu=False, bias=None, add_nc=None, residual=None, stats_groups=0):
+    """conv(act(x)) + bias + add_nc + residual of N small maps through one frame sheet: 3 launches (sheet in with the norm's affine,
+    the plain convolution on a single image, sheet out with the per-frame adds)."""
+    P = ctypes.c_void_p
+    R = -(-N // Q)
+    Hv, Wv = R * (H + 1) - 1, Q * (W + 1) - 1
+    bf = 1 if x.dtype == torch.bfloat16 else 0
+    sheet = torch.empty((1, Hv, Wv, Cin), dtype=x.dtype, device=x.device)
+    with ops._on(x.device):
+        ops._check(ops.lib().gvd_conv_sheet_in(P(x.data_ptr()), P(sheet.data_ptr()), P(coef_ptr), int(bool(silu)), N, H, W, Cin, Q, bf,
+                                               P(ops._stream())))
+    BN, _, _ = config(SPATIAL, 1, Hv, Wv, Cin, Cout)
+    wpk = packed(weight, BN, backward, pad, x.dtype)
+    k = _ksplit(SPATIAL, 1, Hv, Wv, Cin, Cout)
+    if k > 1:   # one sheet is few workgroups with a long reduction: cut it along the input channels
+        out_v, slices = _launch_split(sheet, wpk, Cout, SPATIAL, 1, Hv, Wv, Cin, k)
+    else:
+        (out_v, _), slices = _launch(sheet, wpk, Cout, SPATIAL, 1, Hv, Wv, Cin), 1
+    out = torch.empty((N, H, W, Cout), dtype=x.dtype, device=x.device)
+    sums = _ZeroArena.take((1, N, stats_groups, 2), x.device) if stats_groups else None
+    with ops._on(x.device):
+        ops._check(ops.lib().gvd_conv_sheet_out(P(out_v.data_ptr()), slices, P(out.data_ptr()), P(None if bias is None else bias.data_ptr()),
+                                                P(None if add_nc is None else add_nc.data_ptr()),
+                                                P(None if residual is None else residual.data_ptr()),
+                                                P(None if sums is None else sums.data_ptr()), int(stats_groups), N, H, W, Cout, Q, bf,
+                                                P(ops._stream())))
+    return out, (PartialStats(sums, 1, N, stats_groups, H * W) if stats_groups else None)
+
+
 FUSE_NORM_BACKWARD_STATS = os.environ.get("GVD_FUSE_NORM_BWD", "1") == "1"   # 0: separate statistics pass (k_gn_bwd_stats_*), for A/B runs and tests
 
 
@@ -263,6 +377,15 @@ def _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, st
     n_norm = H if mode == TEMPORAL else N
     if ns is not None and (ns.C != Cin or ns.N != n_norm):
         raise RuntimeError(f"fused_conv: norm state is for {ns.N} x {ns.C} channels, input has {n_norm} x {Cin}")
+    Q = _sheet_plan(N, H, W) if (mode == SPATIAL and not upsample and Cout % 8 == 0) else 0
+    if Q:   # maps smaller than a tile: one frame sheet (the per-frame prologue / epilogue terms move into the sheet kernels)
+        return _sheet_conv(x.contiguous(), weight, False, Cout, N, H, W, Cin + pad, Q, pad=pad, coef_ptr=None if ns is None else ns.coef_ptr,
+                           silu=silu, bias=b32, add_nc=None if add_nc is None else add_nc.contiguous(),
+                           residual=None if residual is None else residual.contiguous(), stats_groups=stats_groups)
+    k = _ksplit(mode, N, H, W, Cin + pad, Cout) if (not upsample and add_nc is None and Cout % 8 == 0) else 1
+    if k > 1:   # few workgroups, long reduction: split-K slices, then the sum with the epilogue terms (and a statistics pass)
+        return _split_conv(x.contiguous(), wpk, Cout, mode, N, H, W, Cin + pad, k, coef_ptr=None if ns is None else ns.coef_ptr, silu=silu, bias=b32,
+                           residual=None if residual is None else residual.contiguous(), n_stat=n_norm, stats_groups=stats_groups)
     return _launch(x.contiguous(), wpk, Cout, mode, N, H, W, Cin + pad,
                    coef_ptr=None if ns is None else ns.coef_ptr, coef_per_n=1,
                    silu=silu, bias=b32, add_nc=None if add_nc is None else add_nc.contiguous(),
@@ -316,13 +439,20 @@ class _FusedConvFn(torch.autograd.Function):
                 if (2 * H, 2 * W) != (H_in, W_in):
                     d_act = d_act[:, :H_in, :W_in].contiguous()
             else:
+                Q = _sheet_plan(N, H, W) if (mode == SPATIAL and not upsample and Cin % 8 == 0) else 0
                 BN, _, _ = config(mode, N, H, W, Cout + pad, Cin)
-                wT = packed(weight, BN, True, pad, gout.dtype)
-                if ns is not None and not upsample and FUSE_NORM_BACKWARD_STATS:
+                wT = None if Q else packed(weight, BN, True, pad, gout.dtype)
+                ks = 1 if (Q or upsample or Cin % 8) else _ksplit(mode, N, H, W, Cout + pad, Cin)
+                if Q:       # small maps: the input-gradient convolution on one frame sheet; the norm's backward runs its own two passes
+                    d_act, _ = _sheet_conv(g, weight, True, Cin, N, H, W, Cout + pad, Q, pad=pad)
+                elif ks > 1:   # few workgroups, long reduction: split-K slices + their sum (the norm's backward: two passes)
+                    d_act, _ = _split_conv(g, wT, Cin, mode, N, H, W, Cout + pad, ks)
+                elif ns is not None and not upsample and FUSE_NORM_BACKWARD_STATS:
                     # the GroupNorm-backward statistics come out of the input-gradient convolution's epilogue
                     gx = _dgrad_with_norm_backward(g, wT, x, ns, silu, mode, N, H, W, Cout + pad, Cin, add=extra)
                     return (gx, g_res) + tail
-                d_act, _ = _launch(g, wT, Cin, mode, N, H, W, Cout + pad)
+                else:
+                    d_act, _ = _launch(g, wT, Cin, mode, N, H, W, Cout + pad)
             if upsample:   # nearest x2 backward: each input pixel fed a 2x2 block
                 d_act = d_act.reshape(N, H // 2, 2, W // 2, 2, Cin).sum(dim=(2, 4))
             if ns is None:
@@ -402,6 +532,6 @@ def fused_conv(x, conv, *, mode=SPATIAL, upsample=False, gn=None, norm=None, n_s
         if stats_groups:
             N = x.shape[0]
             S = out.shape[-3] * out.shape[-2] if mode == TEMPORAL else out.shape[1] * out.shape[2]
-            part = PartialStats(res[1], STATS_REPLICAS, res[1].shape[1], stats_groups, S)
+            part = PartialStats(res[1], res[1].shape[0], res[1].shape[1], stats_groups, S)
         return out, part
     return _run_forward(x, conv.weight, conv.bias, mode, upsample, ns, silu, add_nc, residual, stats_groups)

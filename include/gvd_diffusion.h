@@ -184,6 +184,33 @@ int gvd_conv_mfma_norm_bwd(const void* g, const void* w_packed_bwd, void* d_act,
                            int mode, int N, int H, int W, int Cin, int Cout, const void* norm_x, const float* norm_coef,
                            int norm_coef_per_n, const float* norm_gamma, int norm_silu, int is_bf16, void* stream);
 
+/* Frame sheets for maps smaller than a convolution tile (the 5 x 7 / 10 x 14 / 9 x 16 latents of the U-Net's deepest level,
+ * openaimodel3d.py:110-220 at 1/8 of the latent): the N maps [N][H][W][C] of one launch are laid out as ONE image
+ * [R (H + 1) - 1][Q (W + 1) - 1][C], R = ceil(N / Q), map n at cell (n / Q, n % Q), a zero row / column between neighbours (the
+ * zero padding both share), so that gvd_conv_mfma(mode 0, N = 1) on the sheet equals the per-map convolution at the cells.
+ * _in: fills the whole sheet (zeros included) and applies act(v) = silu?(a[n,c] v + b[n,c]) when coef != NULL (the fp32 (a, b) pairs
+ * of gvd_group_norm_coef -- the prologue the convolution would have run); _out: out[n] = sum over `slices` sheets (1: a plain
+ * gvd_conv_mfma result) of cell n + bias + add_nc[n] + residual[n] (fp32 [C] | NULL, 16-bit [N][C] | NULL, 16-bit [N][H][W][C] | NULL;
+ * fp32 sum, one rounding).  C % 8 == 0. */
+int gvd_conv_sheet_in(const void* x, void* sheet, const float* coef, int silu, int N, int H, int W, int C, int Q, int is_bf16,
+                      void* stream);
+int gvd_conv_sheet_out(const void* sheet, int slices, void* out, const float* bias, const void* add_nc, const void* residual,
+                       double* stats, int groups, int N, int H, int W, int C, int Q, int is_bf16, void* stream);
+
+/* Split-K form of gvd_conv_mfma for launches with fewer workgroups than the chip has slots and a long reduction (the deepest U-Net
+ * level: K = 9 x 1280 ... 9 x 2560 over 35-150 pixels per frame; the temporal (3,1,1) form at 35 / 144 pixels): the input channels
+ * are cut into `ksplit` runs of 32-channel chunks, slice z (blockIdx.z) convolves its run and writes its 16-bit partial sums to
+ * partials + z * (elements of the output); *n_slices receives the number of slices written (<= ksplit).  Stride-1 modes (0, 1), the
+ * GroupNorm(+SiLU) prologue as in gvd_conv_mfma, no bias / add / residual / statistics: those belong to the sum,
+ *   gvd_conv_sum_slices:  out[r][c] = sum_z partials[z][r][c] + bias[c] + residual[r][c]        (fp32 sum, one rounding)
+ *   (stats != NULL: also the sum / sum of squares of the rounded outputs per (sample, group) -- fp64 [n_stat][groups][2], zeroed by
+ *    the caller, rows = n_stat x rows per sample: what gvd_conv_mfma's epilogue leaves for the next GroupNorm; same for the sheet form)
+ * or, for a frame sheet, gvd_conv_sheet_out with slices = *n_slices (slice stride = the sheet's elements). */
+int gvd_conv_mfma_splitk(const void* x, const void* w_packed, const float* coef, int coef_per_n, void* partials, int ksplit,
+                         int* n_slices, int mode, int N, int H, int W, int Cin, int Cout, int silu, int is_bf16, void* stream);
+int gvd_conv_sum_slices(const void* partials, int slices, void* out, const float* bias, const void* residual, double* stats,
+                        int groups, int n_stat, long long rows, int C, int is_bf16, void* stream);
+
 /* stats[n][g][0..1] = sum over replicas r and m < merge of partial[r][n*merge + m][g][0..1]  (N outputs). */
 int gvd_group_norm_merge(double* stats, const double* partial, int replicas, int merge, int N, int G, void* stream);
 

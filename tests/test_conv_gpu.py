@@ -69,8 +69,9 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", SHAPES)
-def test_conv3x3_matches_fp32(N, H, W, Cin, Cout):
+def test_conv3x3_matches_fp32(N, H, W, Cin, Cout, monkeypatch):
     from lvdm_amd import conv as C
+    monkeypatch.setattr(C, "SHEETS", False)   # every (tile configuration, tile width) on the per-frame path; frame sheets have their own test
     g = torch.Generator(device=DEV).manual_seed(N * 1000 + H + W + Cin + Cout)
     x = torch.randn(N, H, W, Cin, device=DEV, generator=g).half()
     m = _conv_module(Cin, Cout, Cin + Cout)
@@ -227,11 +228,12 @@ def test_conv_input_gradients_match_autograd_of_the_fp32_form():
     ("spatial", (3, 18, 32), 320, 640, True, torch.float16), ("spatial", (2, 9, 16), 128, 128, False, torch.float16),
     ("spatial", (2, 20, 24), 160, 320, True, torch.bfloat16), ("temporal", (25, 50), 320, 320, True, torch.float16),
     ("temporal", (7, 33), 64, 128, False, torch.float16)])
-def test_norm_backward_statistics_from_the_dgrad_epilogue(mode, shape, C, Cout, silu, dtype):
+def test_norm_backward_statistics_from_the_dgrad_epilogue(mode, shape, C, Cout, silu, dtype, monkeypatch):
     """gvd_conv_mfma_norm_bwd: the GroupNorm-backward sums accumulated in the input-gradient convolution's epilogue give the
     same input gradient as the separate statistics pass (k_gn_bwd_stats_*) -- both sum the same rounded d_act in fp32 partials
     and fp64 totals, so they agree to the 16-bit rounding of dx -- and both match fp32 autograd of the same expression."""
     from lvdm_amd import conv as C_
+    monkeypatch.setattr(C_, "SHEETS", False)   # (small maps would otherwise take the frame-sheet path, whose norm backward is always two passes)
     g = torch.Generator(device=DEV).manual_seed(314)
     x = (torch.randn(*shape, C, device=DEV, generator=g) * 1.3 + 0.3).to(dtype).requires_grad_(True)
     m = _conv_module(C, Cout, 5, three_d=(mode == "temporal"))
@@ -258,6 +260,99 @@ def test_norm_backward_statistics_from_the_dgrad_epilogue(mode, shape, C, Cout, 
     yr = C_._reference(xf, m.weight.float(), m.bias.float(), cmode, False, gn, silu, None, None, n_stat)
     (gr,) = torch.autograd.grad(yr, [xf], gy.float())
     assert _rel(outs[True], gr) < (4e-2 if dtype == torch.bfloat16 else 6e-3), _rel(outs[True], gr)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,G,dtype", [(50, 5, 7, 64, 128, 32, torch.float16), (25, 9, 16, 160, 320, 32, torch.float16),
+                                                    (13, 10, 14, 40, 72, 8, torch.float16), (7, 4, 4, 32, 64, 4, torch.bfloat16),
+                                                    (2, 9, 16, 64, 64, 32, torch.float16)])
+def test_small_maps_run_as_one_frame_sheet(N, H, W, Cin, Cout, G, dtype, monkeypatch):
+    """Maps smaller than a convolution tile (the 5 x 7 / 10 x 14 / 9 x 16 latents of the U-Net's deepest level) run as ONE image -- the
+    frames side by side and below each other with a zero row / column between them (conv.py: _sheet_plan, k_sheet_in / k_sheet_out):
+    same operator (GroupNorm + SiLU in front, bias, per-frame add, residual, statistics for the next norm) and same input gradient as
+    the per-frame launch and as fp32 torch.  Tolerance: the sheet rounds the activated input and the convolution result to 16 bit
+    before the per-frame adds (one rounding more than the fused epilogue)."""
+    from lvdm_amd import conv as C
+    assert C._sheet_plan(N, H, W) > 0
+    g = torch.Generator(device=DEV).manual_seed(N * 100 + H * W + Cin)
+    x = (torch.randn(N, H, W, Cin, device=DEV, generator=g) * 1.7 + 0.4).to(dtype).requires_grad_(True)
+    res = torch.randn(N, H, W, Cout, device=DEV, generator=g).to(dtype).requires_grad_(True)
+    add = torch.randn(N, Cout, device=DEV, generator=g).to(dtype)
+    m = _conv_module(Cin, Cout, 11).to(dtype)
+    gn = nn.GroupNorm(G, Cin, eps=1e-5).to(DEV).to(dtype)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(Cin, device=DEV, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(Cin, device=DEV, generator=g) * 0.2)
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    gy = torch.randn(N, H, W, Cout, device=DEV, generator=g).to(dtype)
+    seen = []
+    orig = C._sheet_conv
+    monkeypatch.setattr(C, "_sheet_conv", lambda *a, **k: (seen.append(a[2]), orig(*a, **k))[1])
+    outs = {}
+    for sheets in (True, False):
+        monkeypatch.setattr(C, "SHEETS", sheets)
+        y, part = C.fused_conv(x, m, gn=gn, silu=True, add_nc=add, residual=res, stats_groups=G)
+        gx, gr = torch.autograd.grad(y, [x, res], gy)
+        with torch.no_grad():
+            y_ng, part_ng = C.fused_conv(x.detach(), m, gn=gn, silu=True, add_nc=add, residual=res.detach(), stats_groups=G)
+        assert torch.equal(y_ng, y.detach()) and torch.equal(gr, gy)
+        outs[sheets] = (y.detach(), gx, part.sums.sum(0), part_ng.sums.sum(0))
+    assert seen == [False, True, False], seen          # forward, input gradient, no-grad forward went through the sheet -- and only with SHEETS on
+    f16 = dtype == torch.float16
+    ref = _ref_spatial(x.detach(), m, gn, True, add, res.detach()) if f16 else None
+    tol_y, tol_g = (3e-3, 8e-3) if f16 else (2.5e-2, 5e-2)
+    assert _rel(outs[True][0], outs[False][0]) < tol_y, _rel(outs[True][0], outs[False][0])
+    assert _rel(outs[True][1], outs[False][1]) < tol_g, _rel(outs[True][1], outs[False][1])
+    if f16:
+        assert _rel(outs[True][0], ref) < 3e-3, _rel(outs[True][0], ref)
+    # the statistics are those of the tensor that was returned
+    yg = outs[True][0].double().reshape(N, H * W, G, Cout // G)
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], -1)
+    for got in outs[True][2:]:
+        assert torch.allclose(got, want, rtol=2e-5, atol=1e-3), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("mode,shape,Cin,Cout,dtype", [("spatial", (25, 5, 7), 640, 512, torch.float16), ("spatial", (3, 20, 24), 512, 128, torch.float16),
+                                                       ("temporal", (25, 40), 640, 512, torch.float16), ("temporal", (2, 16, 33), 512, 128, torch.float16),
+                                                       ("spatial", (4, 9, 16), 544, 64, torch.bfloat16)])
+def test_split_k_launches_match_the_single_pass(mode, shape, Cin, Cout, dtype, monkeypatch):
+    """Launches with fewer workgroups than CU slots and a long reduction are cut along the input channels (gvd_conv_mfma_splitk, the
+    slices summed in fp32 by gvd_conv_sum_slices / gvd_conv_sheet_out): same result as the single launch up to the 16-bit rounding of
+    the partial sums (<= 8 slices), with the GroupNorm + SiLU prologue, residual, statistics, and the input gradient."""
+    from lvdm_amd import conv as C
+    cmode = C.TEMPORAL if mode == "temporal" else C.SPATIAL
+    g = torch.Generator(device=DEV).manual_seed(Cin + Cout)
+    x = (torch.randn(*shape, Cin, device=DEV, generator=g) * 1.3 + 0.3).to(dtype).requires_grad_(True)
+    m = _conv_module(Cin, Cout, 21, three_d=(mode == "temporal")).to(dtype)
+    gn = nn.GroupNorm(32, Cin).to(DEV).to(dtype)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(Cin, device=DEV, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(Cin, device=DEV, generator=g) * 0.2)
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    res = torch.randn(*shape, Cout, device=DEV, generator=g).to(dtype)
+    gy = torch.randn(*shape, Cout, device=DEV, generator=g).to(dtype)
+    n_split = []
+    orig = C._launch_split
+    monkeypatch.setattr(C, "_launch_split", lambda *a, **k: (lambda r: (n_split.append(r[1]), r)[1])(orig(*a, **k)))
+    outs = {}
+    for split in (True, False):
+        monkeypatch.setattr(C, "SPLITK", split)
+        y, part = C.fused_conv(x, m, mode=cmode, gn=gn, silu=True, residual=res, stats_groups=32)
+        (gx,) = torch.autograd.grad(y, [x], gy)
+        outs[split] = (y.detach(), gx, part.sums.sum(0))
+    # the forward -- and the input gradient, whose reduction runs over Cout -- were split, and only with SPLITK on
+    assert len(n_split) == (2 if Cout >= 512 else 1) and min(n_split) >= 2, n_split
+    f16 = dtype == torch.float16
+    assert _rel(outs[True][0], outs[False][0]) < (2e-3 if f16 else 1.6e-2), _rel(outs[True][0], outs[False][0])
+    assert _rel(outs[True][1], outs[False][1]) < (6e-3 if f16 else 5e-2), _rel(outs[True][1], outs[False][1])
+    n_stat = (shape[0] if len(shape) == 3 and mode == "temporal" else 1) if mode == "temporal" else shape[0]
+    yg = outs[True][0].double().reshape(n_stat, -1, 32, Cout // 32)
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], -1)
+    assert torch.allclose(outs[True][2], want, rtol=2e-5, atol=1e-3)
+    xf = x.detach().float()
+    ref = C._reference(xf, m.weight.float(), m.bias.float(), cmode, False, gn.float(), True, None, res.float(), n_stat)
+    assert _rel(outs[True][0], ref) < (3e-3 if f16 else 2e-2), _rel(outs[True][0], ref)
 
 
 def test_conv_bf16_and_rejections():
