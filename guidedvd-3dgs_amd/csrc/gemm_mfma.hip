@@ -427,6 +427,69 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
     }
 }
 
+// ---- skinny problems: M <= 256 rows (the cross-attention context projections -- 77 text / 256 image tokens x 1024 -> 640 .. 2560 --
+// the per-frame embedding Linears, the time-embedding MLP: ~115 launches per DDIM step) ----
+// One persistent tile of the kernel above walks K in 32-channel steps behind a barrier each: 21-25 us for a 77 x 2560 x 1024 product
+// whose 5 MB of weights are 1.3 us of HBM time.  Here the N x K weight matrix is cut into (32 channels) x (a quarter of K) pieces, one
+// WAVE each: the wave loads its W piece and the matching X columns straight into MFMA operand registers (no LDS, no barrier in the
+// loop -- every load of the piece is in flight at once), multiplies, and the four K-quarters of a channel block meet in LDS.
+template <typename T, int TB>   // TB: 32-row blocks of X per workgroup (1, 2, 4)
+__global__ void __launch_bounds__(256) k_gemm_skinny(const GemmArgs a)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    __shared__ float red[4][TB][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, r32 = lane & 31;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * (TB * 32);   // (more than 128 rows: two workgroups of 4 row blocks each)
+    const int ksl = ((a.K + 63) / 64) * 16;                    // K-slice of a wave: a multiple of 16
+    const int k0 = wave * ksl, k1 = k0 + ksl < a.K ? k0 + ksl : a.K;
+    const int ch = n0 + r32 < a.N ? n0 + r32 : a.N - 1;
+    const T* wr = (const T*)a.w + (size_t)ch * a.ldw + 8 * hi;
+    const T* xr[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; tb++) {
+        const int m = m0 + tb * 32 + r32;
+        xr[tb] = (const T*)a.x + (size_t)(m < a.M ? m : a.M - 1) * a.ldx + 8 * hi;
+    }
+    f16v acc[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; tb++) acc[tb] = f16v{};
+    constexpr int UN = TB <= 2 ? 16 : 8;                       // K-steps whose loads are in flight together (registers: UN x (1 + TB) fragments)
+#pragma unroll UN
+    for (int k = k0; k < k1; k += 16) {
+        const bool ok = k + 8 * hi < a.K;                      // (K % 8 == 0: a lane's 8 channels are inside or outside together)
+        const int kk = ok ? k : 0;
+        vec8 af = *reinterpret_cast<const vec8*>(wr + kk);
+        if (!ok) af = vec8{};
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) {
+            const vec8 bf = *reinterpret_cast<const vec8*>(xr[tb] + kk);
+            acc[tb] = Tr<T>::mfma(af, bf, acc[tb]);            // (af = 0 past K: whatever bf holds there is multiplied by zero)
+        }
+    }
+#pragma unroll
+    for (int tb = 0; tb < TB; tb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave][tb][r][lane] = acc[tb][r];
+    __syncthreads();
+    // thread -> (token block, channel quad g, lane): channels n0 + 8 g + 4 hi + {0..3} of token 32 tb + r32
+    const int g = wave;
+#pragma unroll
+    for (int tb = 0; tb < TB; tb++) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int r = 4 * g + e;
+            v[e] = (red[0][tb][r][lane] + red[1][tb][r][lane]) + (red[2][tb][r][lane] + red[3][tb][r][lane]);
+        }
+        const int c0 = n0 + 8 * g + 4 * hi, m = m0 + tb * 32 + r32;
+        if (m < a.M && c0 < a.N) {                             // (N % 8 == 0 and c0 % 4 == 0: the quad is inside or outside)
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = v[e] * a.alpha + (a.bias ? a.bias[c0 + e] : 0.f);
+            *reinterpret_cast<uint2*>((T*)a.y + (size_t)m * a.ldy + c0) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // (mean, rstd) of every row of x [M, C] (16-bit), LayerNorm's biased variance, the row held in registers (mean first, then the
 // centred sum of squares).  G lanes share a row (G = 8 for C <= 512 ... 64 for C <= 4096; every lane owns up to 8 16-byte chunks,
 // chunk o = sub + G i), so a wave covers 64 / G rows: at C = 320 one wave per row left 24 of 64 lanes idle and paid two 6-step
@@ -631,6 +694,20 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
     a.M = M; a.N = N; a.K = K; a.batch = batch; a.alpha = alpha; a.bias = bias;
     a.row_stats = reinterpret_cast<const float2*>(row_stats); a.col_sum = col_sum;
     a.res = residual; a.ldr = ldr; a.sr = stride_r; a.geglu = geglu ? 1 : 0;
+    static const bool no_skinny = [] { const char* e = getenv("GVD_GEMM_NO_SKINNY"); return e && e[0] != '0'; }();   // (A/B switch)
+    if (M <= 256 && batch == 1 && !row_stats && !residual && !geglu && !no_skinny) {
+        // skinny: a wave per (32 channels, quarter of K); y = alpha x w^T + bias
+        const int tb = (M + 31) / 32;
+        const dim3 grid((unsigned)((N + 31) / 32), tb > 4 ? 2u : 1u);
+#define GVD_SK(T, TB_) hipLaunchKernelGGL((k_gemm_skinny<T, TB_>), grid, dim3(256), 0, stream, a)
+#define GVD_SK_T(T) do { if (tb <= 1) GVD_SK(T, 1); else if (tb <= 2) GVD_SK(T, 2); else GVD_SK(T, 4); } while (0)
+        if (is_bf16) GVD_SK_T(__bf16); else GVD_SK_T(_Float16);
+#undef GVD_SK_T
+#undef GVD_SK
+        const hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return fail(-2, "launch k_gemm_skinny", es);
+        return 0;
+    }
     const int bn = tile_n(M, N, batch);
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + bn - 1) / bn; a.mgroups = (a.tiles_m + 7) / 8;
     {   // channel tiles whose W rows (bn x K x 2 bytes each) share an XCD's L2 with the token panels in flight

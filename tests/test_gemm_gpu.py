@@ -32,6 +32,28 @@ def test_plain_product_with_bias(M, N, K, dtype):
     assert _rel(y, ref) < (1.5e-3 if dtype == torch.float16 else 1.2e-2), _rel(y, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 1280, 1280), (25, 320, 1280), (77, 640, 1024), (129, 72, 40), (256, 2560, 1024), (200, 1000, 1032), (33, 8, 8),
+                                   (64, 328, 5120)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_skinny_problems_run_on_the_wave_per_piece_kernel(M, N, K, dtype, monkeypatch):
+    """M <= 256 rows without a LayerNorm fold / residual / gate (context projections, embedding Linears) take `k_gemm_skinny`: against
+    fp32 torch and against the persistent kernel on the same operands (GVD_GEMM_NO_SKINNY is read once per process, so the second
+    half of the comparison is the batched entry, which never takes the skinny form): ragged N (not a multiple of 32), K (not of 16 or
+    64), strided row views, alpha and bias."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
+    xw = _mk(g, M, K + 16, dtype=dtype)
+    x = xw[:, 8:8 + K]                                               # a column view: row stride K + 16
+    w = _mk(g, N, K, dtype=dtype, scale=K ** -0.5)
+    b = torch.randn(N, device=DEV, generator=g)
+    y = gemm.gemm_nt(x, w, bias=b, alpha=0.7)
+    ref = 0.7 * (x.float() @ w.float().t()) + b
+    tol = 1.5e-3 if dtype == torch.float16 else 1.2e-2
+    assert y.shape == (M, N) and y.dtype == dtype and _rel(y, ref) < tol, _rel(y, ref)
+    y2 = gemm.gemm_nt(torch.stack([x, x]), w, bias=b, alpha=0.7)     # batch 2: the persistent kernel
+    assert _rel(y2[0], ref) < tol and _rel(y, y2[0].float()) < tol
+
+
 def test_strided_views_batches_and_scale():
     """Operands read in place: column slices of a packed [M, 3C] tensor, a broadcast (batch-stride 0) W, a batched W, alpha."""
     from lvdm_amd import gemm
