@@ -949,13 +949,13 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         if os.path.exists(pmc) and (args.ddim_height, args.ddim_width, T) == (576, 1024, 25):
             try:
                 pj = json.load(open(pmc))
-                key = [k_ for k_ in pj if k_.startswith("attn i1ELi1E")]
+                key = [k_ for k_ in pj if k_.startswith("attn short") or k_.startswith("attn i1ELi1E")]
                 if key:
                     traffic = pj[key[0]].get("traffic_bytes")
                     t_from = "profiles/r04_mfma_pmc.json: per LAUNCH of the level-0 shape (25 frames x 9216 pixels x 320 channels; 590 MB algorithmic), separate rocprofv3 --pmc passes; NOT observed in this run"
             except Exception:
                 traffic = None
-        r_hbm_attn = {"bound": "hbm", "kernel": "k_attn_fwd<1,1> (temporal self-attention, frames of a pixel read in place)", "achieved": round(ach, 1),
+        r_hbm_attn = {"bound": "hbm", "kernel": "k_attn_short_fwd (temporal self-attention: a wave per (pixel, head), the frames of a pixel read in place)", "achieved": round(ach, 1),
                       "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_from": t_from,
                       "alg_bytes_per_step": int(byt / n_inst), "launches_per_step": round(len(ta) / n_inst, 1), "ms_per_step": round(ms_ / n_inst, 3)}
     dominant = max((r for r in (r_conv, r_attn, r_gemm) if r), key=lambda r: r["ms_per_step"], default=None)   # the family with the most time per step

@@ -457,13 +457,14 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const GemmArgs a)
 #pragma unroll UN
     for (int k = k0; k < k1; k += 16) {
         const bool ok = k + 8 * hi < a.K;                      // (K % 8 == 0: a lane's 8 channels are inside or outside together)
-        const int kk = ok ? k : 0;
+        const int kk = ok ? k : -8 * hi;                       // (dummy read: the row's first 8 channels, always inside the matrix)
         vec8 af = *reinterpret_cast<const vec8*>(wr + kk);
         if (!ok) af = vec8{};
 #pragma unroll
         for (int tb = 0; tb < TB; tb++) {
-            const vec8 bf = *reinterpret_cast<const vec8*>(xr[tb] + kk);
-            acc[tb] = Tr<T>::mfma(af, bf, acc[tb]);            // (af = 0 past K: whatever bf holds there is multiplied by zero)
+            vec8 bf = *reinterpret_cast<const vec8*>(xr[tb] + kk);
+            if (!ok) bf = vec8{};                               // (BOTH operands: the dummy read may hold inf / NaN bits, and 0 x NaN = NaN --
+            acc[tb] = Tr<T>::mfma(af, bf, acc[tb]);            //  with K = 8 the upper half-wave reads past the row: found by the guided schedule test)
         }
     }
 #pragma unroll

@@ -28,10 +28,12 @@ for rows in [rows_of(a_dir), rows_of(b_dir)] + [rows_of(d) for d in traffic_dirs
     gemm_case = {d: GEMM_CASES[min(i // 3, len(GEMM_CASES) - 1)] for i, d in enumerate(gemm_ids)}
     for r in rows:
         n = r["Kernel_Name"]
-        if "k_conv_mfma" not in n and "k_attn_fwd" not in n and "k_attn_bwd" not in n and "k_gemm_nt" not in n:
+        if "k_conv_mfma" not in n and "k_attn_fwd" not in n and "k_attn_bwd" not in n and "k_gemm_nt" not in n and "k_attn_short" not in n:
             continue
         kind = "conv" if "k_conv_mfma" in n else ("gemm" if "k_gemm_nt" in n else ("attn_bwd_dkv" if "bwd_dkv" in n else ("attn_bwd_dq" if "bwd_dq" in n else "attn")))
         key = kind + " " + n.split("ConvArgs")[0].split("GemmArgs")[0][-40:] + f" grid={r['Grid_Size']}"
+        if "k_attn_short" in n:          # the wave-per-item kernels of the temporal attention (bench.py reads the forward's traffic by this prefix)
+            key = ("attn short bwd" if "short_bwd" in n else "attn short fwd") + f" grid={r['Grid_Size']}"
         if kind == "gemm":
             key = "gemm " + gemm_case[int(r["Dispatch_Id"])]
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"])

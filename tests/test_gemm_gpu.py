@@ -43,6 +43,8 @@ def test_skinny_problems_run_on_the_wave_per_piece_kernel(M, N, K, dtype, monkey
     from lvdm_amd import gemm
     g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
     xw = _mk(g, M, K + 16, dtype=dtype)
+    xw[:, :8] = float("nan")                                         # whatever surrounds the operand must not reach the product: the lanes
+    xw[:, 8 + K:] = float("inf")                                     # past K read (and discard) in-matrix dummies
     x = xw[:, 8:8 + K]                                               # a column view: row stride K + 16
     w = _mk(g, N, K, dtype=dtype, scale=K ** -0.5)
     b = torch.randn(N, device=DEV, generator=g)
