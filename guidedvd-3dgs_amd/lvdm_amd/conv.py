@@ -232,6 +232,7 @@ def _sheet_plan(N, H, W):
 
 
 SPLITK = os.environ.get("GVD_CONV_SPLITK", "1") == "1"   # 0: no split-K launches (A/B runs, tests)
+FORCE_KSPLIT = None
 
 
 def _groups(mode, N, H, W, Cin, Cout):
@@ -245,15 +246,19 @@ def _groups(mode, N, H, W, Cin, Cout):
 
 def _ksplit(mode, N, H, W, Cin, Cout):
     """Split-K factor: launches of fewer workgroups than the chip has slots (2 x 256) whose reduction is long -- the deepest U-Net
-    level: 190-320 workgroups walking K = 9 x 1280 ... 9 x 2560, the temporal form at 35 / 144 pixels -- are cut along the input
-    channels into ~1000 workgroups (>= 8 chunks of 32 channels each); the fp32 sum of the slices is a pass over a few MB."""
+    level: 140-320 workgroups walking K = 9 x 1280 ... 9 x 2560, the temporal form at 35 / 140 / 144 pixels -- are cut along the input
+    channels into ~900 workgroups of >= 8 chunks of 32 channels each.  The fp32 sum of the slices reads slices x output bytes: capped
+    at 40 MB (~10 us), which keeps the 7000-row temporal launch at two slices (tests/scripts/r4_ksplit_sweep.py: 131 us at 2, 155 at
+    5, 139 unsplit) and leaves launches of 340+ workgroups alone (a 400-workgroup VAE group measured 91 -> 109 us split)."""
     nchunks = -(-Cin // 32)
     if not SPLITK or nchunks < 16 or mode not in (SPATIAL, TEMPORAL):
         return 1
+    if FORCE_KSPLIT is not None:          # experiments (tests/scripts/r4_ksplit_sweep.py)
+        return max(1, min(int(FORCE_KSPLIT), nchunks // 2))
     g = _groups(mode, N, H, W, Cin, Cout)
-    if g >= 448:
+    if g > 340:
         return 1
-    k = min(8, nchunks // 8, int(1024 / g + 0.5))
+    k = min(8, nchunks // 8, int(900 / g + 0.5), max(1, (40 << 20) // (2 * N * H * W * Cout)))
     return k if k >= 2 else 1
 
 
