@@ -855,16 +855,17 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     assert torch.isfinite(xi).all()
     if os.environ.get("GVD_BENCH_TORCH_PROFILE"):   # dev: where do the step's copy / fill / add / cat launches come from?  (op, first package frame) table
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
             xi = one(warm + steps + n_inst, xi)
             torch.cuda.synchronize()
-        want = ("aten::copy_", "aten::add", "aten::add_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::sum", "aten::index_select", "aten::gather")
+        skip = ("aten::empty", "aten::view", "aten::reshape", "aten::as_strided", "aten::empty_like", "aten::empty_strided", "aten::to", "aten::_to_copy",
+                "aten::contiguous", "aten::clone", "aten::slice", "aten::select", "aten::permute", "aten::transpose", "aten::expand", "aten::unsqueeze", "aten::squeeze")
         agg = {}
         for ev in prof.events():
-            if ev.name not in want:
+            if not ev.name.startswith("aten::") or ev.name in skip:
                 continue
             frames = [f for f in (ev.stack or []) if ("lvdm_amd" in f or "bench.py" in f or "lvdm/" in f) and "torch/" not in f]
-            key = (ev.name, frames[0].strip() if frames else "(autograd engine / no python frame)")
+            key = (ev.name, (frames[0].strip() if frames else "") + " shapes " + str(getattr(ev, "input_shapes", ""))[:150])
             r = agg.setdefault(key, [0, 0.0])
             r[0] += 1
             r[1] += getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0)

@@ -404,7 +404,8 @@ class _FusedConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, mode, upsample, ns, silu, add_nc, stats_groups, cells=(None, None)):
         out, part = _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, stats_groups)
-        ctx.save_for_backward(x, weight)
+        ctx.set_materialize_grads(False)    # (the statistics output never carries a gradient: without this autograd fills a zero
+        ctx.save_for_backward(x, weight)    #  tensor of its shape for every backward call -- ~190 fill launches per guided step)
         # ops.GradCell hand-overs: grad_add is taken in backward and summed into d/dx by the GroupNorm-backward apply kernel;
         # the residual's gradient goes into res_to (if its taker armed it) instead of to autograd's accumulation
         grad_add, res_to = cells
@@ -421,6 +422,8 @@ class _FusedConvFn(torch.autograd.Function):
     def backward(ctx, gout, *unused):
         x, weight = ctx.saved_tensors
         mode, upsample, ns, silu, has_res = ctx.cfg
+        if gout is None:                    # nothing flows into `out` (only possible if the caller differentiates the statistics)
+            return (None,) * 11
         gout = gout.contiguous()
         gx = None
         grad_add, res_to = ctx.cells

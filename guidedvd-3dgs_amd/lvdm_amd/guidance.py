@@ -78,6 +78,23 @@ class LossGuidance:
             loss = loss + numel * self.lpips_fn(D.float(), G.float(), mask=mask) * 0.001
         return {"recon": loss}, numel
 
+    def frames_loss(self, diffused_images, batch_idx_start, batch_idx_end):
+        """The per-frame calls of __call__ over frames [start, end) as ONE set of tensor ops: diffused_images [3, F, H, W] (what one
+        decoder pass of the guided sampler holds) -> (sum over the frames of their `recon` losses, per-frame mask sums [F]).  The
+        reference's loop (ddim_guidance.py:296-317) runs ~20 elementwise / reduction launches per frame on one 3 x H x W image each
+        -- 25 x that per guided step, plus 25 full-size zero-filled gradient buffers from the slice backward: 4-5 ms of a 240 ms
+        step at 320x448.  Plain masked-L2 term only; None with the SSIM / perceptual add-ons (the sampler then loops per frame)."""
+        if self.ssim_guidance or self.lpips_guidance:
+            return None
+        D = ((diffused_images.permute(1, 0, 2, 3) + 1.) / 2.).clamp(0, 1)          # [F, 3, H, W]
+        if self.guidance_masks is None:
+            mask = torch.ones_like(D)
+        else:
+            mask = self.guidance_masks[batch_idx_start:batch_idx_end].expand_as(D)
+        G = self.guidance_images[batch_idx_start:batch_idx_end]
+        per_frame = (self.w_recon * torch.square(D - G) * mask).sum(dim=(1, 2, 3))
+        return per_frame.sum(), mask.sum(dim=(1, 2, 3))
+
     def update_save_dir(self, train_iter):
         """viewcrafter_wrapper.py:167-172: one sub-directory per training iteration that runs the diffusion."""
         if self.root_save_dir is not None:

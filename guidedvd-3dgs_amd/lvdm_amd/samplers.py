@@ -326,14 +326,22 @@ class DDIMSamplerGuidance(DDIMSampler):
                 f1 = min(f0 + group, f_hi)
                 z = pred_x0[:, :, f0:f1].clone().detach().requires_grad_(True)
                 D = m.differentiable_decode_first_stage(z)
-                total, numels = None, []
-                for j, f in enumerate(range(f0, f1)):
-                    loss_dict, numel = loss_guidance_fn(D[0][:, j:j + 1], index, f, f + 1)
-                    total = loss_dict["recon"] if total is None else total + loss_dict["recon"]
-                    numels.append(numel)
+                # this package's LossGuidance evaluates the frames of a decoder pass as one set of tensor ops (same sums: a frame's
+                # loss touches its own image only); any other callable keeps the reference's per-frame protocol
+                fast = getattr(loss_guidance_fn, "frames_loss", None)
+                fast = fast(D[0], f0, f1) if fast is not None else None
+                if fast is not None:
+                    total, numels = fast
+                else:
+                    total, numels = None, []
+                    for j, f in enumerate(range(f0, f1)):
+                        loss_dict, numel = loss_guidance_fn(D[0][:, j:j + 1], index, f, f + 1)
+                        total = loss_dict["recon"] if total is None else total + loss_dict["recon"]
+                        numels.append(numel)
+                    numels = torch.stack([torch.as_tensor(n_, device=z.device, dtype=z.dtype) for n_ in numels])
                 g = torch.autograd.grad(outputs=total, inputs=z)[0]
                 if not loss_guidance_fn.mean_loss:
-                    g = g / torch.stack([torch.as_tensor(n_, device=g.device, dtype=g.dtype) for n_ in numels]).view(1, 1, -1, 1, 1)
+                    g = g / numels.to(g.dtype).view(1, 1, -1, 1, 1)
                 grads.append(g)
                 if getattr(loss_guidance_fn, "save_dir", None) is not None:
                     decoded.append(D.detach())

@@ -355,3 +355,30 @@ def test_vgg_perceptual_loss_matches_reference_vggloss():
     # the guidance-weight schedule of scale_guidance_weight (viewcrafter_wrapper.py:88-94)
     lg2 = LossGuidance(ddim_steps=50, recur_steps=1, device="cpu", scale_guidance_weight=True)
     assert abs(lg2.guidance_weight_fn(0) - 0.01) < 1e-12 and abs(lg2.guidance_weight_fn(1250) - 0.1) < 1e-9 and lg2.guidance_weight_fn(9999) == 1.0
+
+
+def test_loss_guidance_frames_loss_equals_the_per_frame_calls():
+    """LossGuidance.frames_loss (one set of tensor ops for the frames of a decoder pass) against the reference protocol it replaces
+    in the guided sampler -- one __call__ per frame (viewcrafter_wrapper.py:128-147, ddim_guidance.py:296-317): summed loss, per-frame
+    mask sums and the gradient w.r.t. the decoded frames; with and without masks; None (per-frame fallback) with the SSIM add-on."""
+    from lvdm_amd.guidance import LossGuidance
+    g = torch.Generator().manual_seed(5)
+    F_, H, W = 7, 12, 10
+    for with_mask in (True, False):
+        lg = LossGuidance(ddim_steps=50, recur_steps=1)
+        lg.set_hw(H, W)
+        lg.set_guidance_images(torch.rand(F_, 3, 2 * H, 2 * W, generator=g))
+        if with_mask:
+            lg.set_guidance_masks((torch.rand(F_, 1, 2 * H, 2 * W, generator=g) > 0.4).float())
+        D = (torch.randn(3, F_, H, W, generator=g) * 0.8).requires_grad_(True)
+        total, numels = None, []
+        for j in range(2, 6):
+            ld, n = lg(D[:, j:j + 1], 10, j, j + 1)
+            total = ld["recon"] if total is None else total + ld["recon"]
+            numels.append(float(n))
+        (g_loop,) = torch.autograd.grad(total, D)
+        tot2, num2 = lg.frames_loss(D[:, 2:6], 2, 6)
+        (g_fast,) = torch.autograd.grad(tot2, D)
+        assert torch.allclose(tot2, total, rtol=1e-6) and num2.tolist() == numels
+        assert torch.allclose(g_fast, g_loop, rtol=1e-6, atol=1e-7)
+    assert LossGuidance(ddim_steps=50, recur_steps=1, ssim_guidance=True).frames_loss(D, 0, F_) is None
