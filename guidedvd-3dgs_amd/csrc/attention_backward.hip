@@ -506,7 +506,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* out, con
 {
     const float sl2 = scale * 1.4426950408889634f;
     const char* no_short = getenv("GVD_ATTN_NO_SHORT");   // (A/B switch: 1 = short rows on the three general kernels)
-    if (Nq <= 32 && Nk <= 32 && !(no_short && no_short[0] != '0')) {
+    if (Nq <= 32 && Nk <= 32 && dk && dv && !(no_short && no_short[0] != '0')) {
         // short rows (temporal attention): one wave per (batch entry, head) item, dQ / dK / dV in one pass; `out` and `delta` unused
         const long long items = (long long)B * H;
         if (items > 0x7fffffffLL) return fail(-1, "gvd_attention_bwd: too many (batch, head) items");
@@ -528,9 +528,10 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* out, con
     const long long total = (long long)B * H * Nq;
     hipLaunchKernelGGL(k_attn_delta<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const T*)out, (const T*)d_out,
                        delta, H, Nq, total, o_bs, o_rs);
-    hipLaunchKernelGGL(k_attn_bwd_dkv<T>, dim3((unsigned)(B * H), (unsigned)((Nk + 127) / 128)), dim3(256), 0, stream, (const T*)q,
-                       (const T*)k, (const T*)v, (const T*)d_out, lse, (const float*)delta, (T*)dk, (T*)dv, H, Nq, Nk, sl2, scale,
-                       q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs);
+    if (dk && dv)   // (both null: the keys / values carry no gradient -- the frame-invariant context of the cross-attention)
+        hipLaunchKernelGGL(k_attn_bwd_dkv<T>, dim3((unsigned)(B * H), (unsigned)((Nk + 127) / 128)), dim3(256), 0, stream, (const T*)q,
+                           (const T*)k, (const T*)v, (const T*)d_out, lse, (const float*)delta, (T*)dk, (T*)dv, H, Nq, Nk, sl2, scale,
+                           q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs);
     hipLaunchKernelGGL(k_attn_bwd_dq<T>, dim3((unsigned)(B * H), (unsigned)((Nq + 127) / 128)), dim3(256), 0, stream, (const T*)q,
                        (const T*)k, (const T*)v, (const T*)d_out, lse, (const float*)delta, (T*)dq, H, Nq, Nk, sl2, scale,
                        q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs);
@@ -547,11 +548,11 @@ extern "C" int gvd_attention_bwd_ex(const void* q, const void* k, const void* v,
                                     long long kv_rs, long long o_bs, long long o_rs, int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!q || !k || !v || !out || !d_out || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0)
-        return fail(-1, "gvd_attention_bwd: bad arguments");
+    if (!q || !k || !v || !out || !d_out || !lse || !delta || !dq || (!dk != !dv) || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0)
+        return fail(-1, "gvd_attention_bwd: bad arguments (dk and dv: both or neither)");
     if (D != 64) return fail(-1, "gvd_attention_bwd: head dim must be 64");
     if ((q_bs | q_rs | kv_bs | kv_rs | o_bs | o_rs) & 7) return fail(-1, "gvd_attention_bwd: strides must be multiples of 8 elements");
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)   // (null dk / dv pass)
         return fail(-1, "gvd_attention_bwd: pointers must be 16-byte aligned");
     if (is_bf16) return launch_bwd<__bf16>(q, k, v, out, d_out, lse, delta, dq, dk, dv, B, H, Nq, Nk, scale, q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs, stream);
     return launch_bwd<_Float16>(q, k, v, out, d_out, lse, delta, dq, dk, dv, B, H, Nq, Nk, scale, q_bs, q_rs, kv_bs, kv_rs, o_bs, o_rs, stream);

@@ -163,7 +163,10 @@ class _FlashAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         q, k, v, out, lse = ctx.saved_tensors
-        return _hip_attention_bwd(q, k, v, out, g, lse, ctx.heads, ctx.frame_major) + (None, None)
+        # keys / values without a gradient (the cross-attention's frame-invariant context): dQ only -- the dK / dV kernel walks ALL
+        # queries of a batch entry per 128 keys, which is what made one-context-per-sample batches expensive
+        need_kv = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        return _hip_attention_bwd(q, k, v, out, g, lse, ctx.heads, ctx.frame_major, need_kv=need_kv) + (None, None)
 
 
 class _PackedSelfAttention(torch.autograd.Function):
@@ -299,16 +302,17 @@ def _hip_attention_fwd(q, k, v, heads, frame_major=False, want_lse=False, accum=
     return (out, lse) if want_lse else out
 
 
-def _hip_attention_bwd(q, k, v, out, g, lse, heads, frame_major=False):
+def _hip_attention_bwd(q, k, v, out, g, lse, heads, frame_major=False, need_kv=True):
     g = g.contiguous()
     B, Nq, Nk, d, strides = _attn_geometry(q, k, heads, frame_major)
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dq = torch.empty_like(q)
+    dk, dv = (torch.empty_like(k), torch.empty_like(v)) if need_kv else (None, None)
     delta = torch.empty_like(lse)
     LL, P = ctypes.c_longlong, ctypes.c_void_p
     with _on(q.device):
         rc = lib().gvd_attention_bwd_strided(P(q.data_ptr()), P(k.data_ptr()), P(v.data_ptr()), P(out.data_ptr()),
                                              P(g.data_ptr()), P(lse.data_ptr()), P(delta.data_ptr()), P(dq.data_ptr()),
-                                             P(dk.data_ptr()), P(dv.data_ptr()), B, heads, Nq, Nk, d,
+                                             P(None if dk is None else dk.data_ptr()), P(None if dv is None else dv.data_ptr()), B, heads, Nq, Nk, d,
                                              ctypes.c_float(d ** -0.5), *(LL(s) for s in strides),
                                              1 if q.dtype == torch.bfloat16 else 0, P(_stream()))
     _check(rc)

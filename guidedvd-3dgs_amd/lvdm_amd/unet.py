@@ -22,6 +22,8 @@ Also: the 77 text + 256 image context tokens are projected ONCE per layer for al
 is frame-invariant (the reference projects 25 identical copies), and activation checkpointing is
 off by default (288 GB of HBM; `use_checkpoint=True` restores it).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -146,7 +148,10 @@ class CrossAttention(nn.Module):
             q = gemm.linear(x, self.to_q.weight, ln=norm, grad_add=cell)
             k, v, k_ip, v_ip = self._kv(context, shared_frames)
             q_shape = q.shape
-            if shared_frames > 1 and k.shape[0] > 1:
+            if shared_frames > 1 and k.shape[0] > 1 and os.environ.get("GVD_XATTN_EXPAND", "0") == "1":   # (A/B: K / V copied per frame, as before)
+                rep = lambda t_: None if t_ is None else t_.repeat_interleave(shared_frames, dim=0)
+                k, v, k_ip, v_ip = rep(k), rep(v), rep(k_ip), rep(v_ip)
+            elif shared_frames > 1 and k.shape[0] > 1:
                 # one context per SAMPLE, shared by its `shared_frames` consecutive rows of q: attention is independent per query
                 # row, so the frames of a sample are just more queries of ONE batch entry -- a view of q and of the output instead
                 # of K / V copied `shared_frames` times (repeat_interleave + copy: 1.4 ms per guided step at 320x448)

@@ -46,7 +46,8 @@ int gvd_attention_fwd_ex(const void* q, const void* k, const void* v, void* out,
  * Inputs: q, k, v, out (forward result), d_out, and lse = the [B, H, Nq] fp32 log2-domain log-sum-exp the forward
  * wrote (pass a buffer as `lse` above).  Outputs dq [same addressing as q], dk, dv [same addressing as k, v].
  * delta: [B, H, Nq] fp32 device scratch (rowsum(d_out * out)).  Flash style, deterministic (no atomics):
- * one pass over the K/V tiles accumulates dK, dV; a second pass over the Q tiles accumulates dQ. */
+ * one pass over the K/V tiles accumulates dK, dV; a second pass over the Q tiles accumulates dQ.  dk == dv == NULL: keys and
+ * values carry no gradient (the frame-invariant context of the cross-attention, attention.py:86-99): dQ only. */
 int gvd_attention_bwd_strided(const void* q, const void* k, const void* v, const void* out, const void* d_out,
                               const float* lse, float* delta, void* dq, void* dk, void* dv,
                               int B, int H, int Nq, int Nk, int D, float scale,

@@ -37,6 +37,32 @@ def test_mfma_attention_forward_matches_explicit_softmax(dtype, B, H, Nq, Nk):
         assert float((out2.float() - ref2).abs().max()) < tol
 
 
+def test_attention_backward_skips_dk_dv_when_keys_and_values_carry_no_gradient():
+    """The cross-attention's context is frame-invariant and frozen: dQ alone is computed (gvd_attention_bwd with dk = dv = NULL),
+    bit-identical to the dQ of the full backward; one context per sample with the frames folded into the query rows (what
+    CrossAttention does for the batch-2 CFG pair) equals the per-frame batch with K / V repeated."""
+    from lvdm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(17)
+    S, Fr, P, H = 2, 5, 300, 5
+    q = torch.randn(S * Fr, P, H * 64, device=DEV, generator=g).half().requires_grad_(True)
+    k, v = (torch.randn(S, 77, H * 64, device=DEV, generator=g).half() for _ in range(2))
+    go = torch.randn(S * Fr, P, H * 64, device=DEV, generator=g).half()
+    calls = []
+    orig = ops._hip_attention_bwd
+    ops._hip_attention_bwd = lambda *a, **kw: (calls.append(kw.get("need_kv", True)), orig(*a, **kw))[1]
+    try:
+        o_fold = ops.attention(q.reshape(S, Fr * P, H * 64), k, v, H).reshape(q.shape)
+        (dq_fold,) = torch.autograd.grad(o_fold, q, go)
+        kr, vr = (t.repeat_interleave(Fr, dim=0).requires_grad_(True) for t in (k, v))
+        o_rep = ops.attention(q, kr, vr, H)
+        dq_rep, dk_rep, dv_rep = torch.autograd.grad(o_rep, (q, kr, vr), go)
+    finally:
+        ops._hip_attention_bwd = orig
+    assert calls == [False, True]
+    assert torch.equal(o_fold, o_rep) and torch.equal(dq_fold, dq_rep)
+    assert torch.isfinite(dk_rep).all() and torch.isfinite(dv_rep).all()
+
+
 def test_attention_autograd_wrapper_gradients():
     from lvdm_amd import ops
     g = torch.Generator(device=DEV).manual_seed(3)
