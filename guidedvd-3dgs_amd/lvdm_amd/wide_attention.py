@@ -16,7 +16,11 @@ import torch.nn.functional as F
 from . import gemm, ops
 
 _P, _LL = ctypes.c_void_p, ctypes.c_longlong
-SCORE_BYTES = 96 << 20   # per score buffer (the backward holds two): both stay in the Infinity Cache
+# Per score buffer (the backward holds two).  Round 3 sized it to keep both in the 256 MB Infinity Cache (96 MB: 768-row chunks of
+# the 25 x 2240-token mid block); measured in round 4 (tests/scripts/r4_wide_attn_chunks.py, forward + backward): 25 x 2240 tokens
+# 5.2 ms at 96 MB, 3.44 ms unchunked (256 MB+); 5 x 9216 tokens 15.5 ms at 96 MB, 8.0 at 512 MB, 7.7 at 1 GB -- fewer, better
+# filled GEMM launches beat cache residency of the scores.
+SCORE_BYTES = 512 << 20
 
 
 def _chunk_rows(B, other):
