@@ -105,6 +105,11 @@ template <int PIX> struct Geo<3, PIX> {   // spatial stride 2, 32-pixel-wide out
     static constexpr int TW = 32, TH = PIX / 32, PW = 2 * TW + 1, PH = 2 * TH + 1, PITCH = PW * PIX_BYTES, NTAPS = 9;
     static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
 };
+template <int PIX> struct Geo<4, PIX> {   // nearest x2 upsampling + 3x3 as FOUR 2x2 convolutions of the low-resolution map (one per output
+    // phase): 32-pixel-wide tiles of INPUT pixels, the 3x3 halo patch of Geo<1>, 4 taps; blockIdx.z = phase (ay, ax)
+    static constexpr int TW = 32, TH = PIX / 32, PW = TW + 2, PH = TH + 2, PITCH = PW * PIX_BYTES, NTAPS = 4;
+    static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
+};
 template <int PIX> struct Geo<2, PIX> {   // temporal: rows = (t, p), one zero halo frame on both sides
     static constexpr int NTAPS = 3, TW = 1, TH = 1, PW = 1, PITCH = 0;   // (spatial members: unused placeholders)
     static constexpr int PATCH_BYTES = (PIX + 2 * PB_MAX) * PIX_BYTES, NPP_MAX = (PIX + 2 * PB_MAX) * 4;
@@ -172,8 +177,14 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     const int wm = wave / WN, wn = wave % WN;
     const int co_tile = blockIdx.y;
     const int Cin = a.Cin, Cout = a.Cout;
-    const int chunk0 = blockIdx.z * a.cps;                                                     // split-K slice: chunks [chunk0, chunk0 + nloc)
-    const int nloc = a.nchunks - chunk0 < a.cps ? a.nchunks - chunk0 : a.cps;
+    // MODE 4 (upsampling as four phase convolutions): y[2 i + a] = sum_t W_t U(x)[2 i + a + t] touches x[i + a + k - 1], k = 0, 1, per
+    // dimension -- a 2 x 2 convolution of the LOW-resolution map per output phase (a_y, a_x), with the taps that fall on the same input
+    // pixel summed on the host (conv.py: packed(..., "up2")): 16 tap evaluations per input pixel instead of 36, the GroupNorm + SiLU
+    // prologue once per input pixel instead of once per upsampled patch pixel.  blockIdx.z is the phase there, not a split-K slice.
+    constexpr bool UP2 = MODE == 4;
+    const int phase = UP2 ? blockIdx.z : 0, ay = phase >> 1, ax = phase & 1;
+    const int chunk0 = UP2 ? 0 : blockIdx.z * a.cps;                                           // split-K slice: chunks [chunk0, chunk0 + nloc)
+    const int nloc = UP2 ? a.nchunks : (a.nchunks - chunk0 < a.cps ? a.nchunks - chunk0 : a.cps);
 
     // ---- tile origin ----
     constexpr bool SPATIAL = MODE != 2;
@@ -293,7 +304,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     typedef std::integral_constant<int, 1> H1;
 
     // ---- weight staging (linear copy of the pre-swizzled slab), one step ahead ----
-    const T* __restrict__ wt = (const T*)a.w + ((size_t)co_tile * a.nchunks + chunk0) * NTAPS * (BN * BK);
+    const T* __restrict__ wt = (const T*)a.w + (((size_t)phase * gridDim.y + co_tile) * a.nchunks + chunk0) * NTAPS * (BN * BK);   // (phase = 0 outside MODE 4)
     const int total = nloc * NTAPS;
     vec8 wreg[WPT];
     auto load_w = [&](int it) {
@@ -320,7 +331,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     for (int ni = 0; ni < NI; ni++) {
         const int m = (wn * NI + ni) * 32 + r32;
         if (MODE == 0) b_off[ni] = (m >> 4) * G_::PITCH + (m & 15) * PIX_BYTES + hi * 16;
-        else if (MODE == 1) b_off[ni] = (m >> 5) * G_::PITCH + (m & 31) * PIX_BYTES + hi * 16;
+        else if (MODE == 1 || MODE == 4) b_off[ni] = (m >> 5) * G_::PITCH + (m & 31) * PIX_BYTES + hi * 16;
         else if (MODE == 3) b_off[ni] = 2 * (m >> 5) * G_::PITCH + 2 * (m & 31) * PIX_BYTES + hi * 16;
         else b_off[ni] = m * PIX_BYTES + hi * 16;
     }
@@ -364,7 +375,8 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* wb = wbuf + wcur * WBYTES;
                 int shift;
-                if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
+                if (UP2) shift = (ay + (tap >> 1)) * G_::PITCH + (ax + (tap & 1)) * PIX_BYTES;
+                else if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
                 else shift = tap * PB * PIX_BYTES;
                 const unsigned char* pb = pbuf + pcur * PBYTES + shift;
 #pragma unroll
@@ -394,7 +406,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     GVD_CSTAMP(2);
 
     // ---- epilogue ----
-    T* __restrict__ out = (T*)a.out + (size_t)blockIdx.z * (size_t)a.split_stride;
+    T* __restrict__ out = (T*)a.out + (UP2 ? (size_t)0 : (size_t)blockIdx.z * (size_t)a.split_stride);
     const T* __restrict__ res = (const T*)a.res;
     const T* __restrict__ bx = (const T*)a.bx;
     float ssum[8], ssq[8];
@@ -446,7 +458,8 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
             } else {
                 const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
                 valid = ty0 + ty < a.H && tx0 + tx < a.W;
-                off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
+                if (UP2) off = (((size_t)n * (2 * a.H) + 2 * (ty0 + ty) + ay) * (2 * a.W) + 2 * (tx0 + tx) + ax) * Cout;   // (a.H, a.W: the input map)
+                else off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
             }
         };
 #pragma unroll
@@ -578,7 +591,8 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
             } else {
                 const int ty = MODE == 0 ? (m >> 4) : (m >> 5), tx = MODE == 0 ? (m & 15) : (m & 31);
                 valid = ty0 + ty < a.H && tx0 + tx < a.W;
-                off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
+                if (UP2) off = (((size_t)n * (2 * a.H) + 2 * (ty0 + ty) + ay) * (2 * a.W) + 2 * (tx0 + tx) + ax) * Cout;   // (a.H, a.W: the input map)
+                else off = (((size_t)n * a.H + ty0 + ty) * a.W + tx0 + tx) * Cout;
             }
             valid = valid && pl < EP_PIX;
         };
@@ -993,9 +1007,10 @@ extern "C" {
 
 int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block_n, int* tile_pixels, int* tile_width)
 {
-    if (mode < 0 || mode > 3 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(-1, "gvd_conv_config: bad arguments");
+    if (mode < 0 || mode > 4 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(-1, "gvd_conv_config: bad arguments");
     int cfg, tw32;
-    choose(mode, N, H, W, Cout, &cfg, &tw32);
+    if (mode == 4) { choose(0, N, (H + 1) / 2, (W + 1) / 2, Cout, &cfg, &tw32); tw32 = 1; }   // phase upsampling: tiles of the INPUT map, 32 wide
+    else choose(mode, N, H, W, Cout, &cfg, &tw32);
     if (block_n) *block_n = CFG_BN[cfg];
     if (tile_pixels) *tile_pixels = CFG_PIX[cfg];
     if (tile_width) *tile_width = mode == 1 ? 0 : (tw32 ? 32 : 16);
@@ -1009,6 +1024,31 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
                        int ksplit = 1, int* n_slices = nullptr)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (mode == 4) {
+        // nearest x2 upsampling + 3x3 as four phase convolutions of the input map (kernel MODE 4): H, W are the OUTPUT dims
+        if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || Cin <= 0 || Cout <= 0 || (Cin & 7) || upsample || ksplit != 1 || bwd_x ||
+            (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)residual) & 15) || (stats && (groups <= 0 || Cout % groups || stats_replicas <= 0)))
+            return fail(-1, "gvd_conv_mfma (mode 4): even output dims, Cin % 8 == 0, aligned tensors, no split / norm-backward form");
+        const int Hl = H / 2, Wl = W / 2;
+        int cfg, tw32;
+        choose(0, N, Hl, Wl, Cout, &cfg, &tw32);
+        const int BN = CFG_BN[cfg], PIX = CFG_PIX[cfg];
+        ConvArgs a{};
+        a.x = x; a.w = w_packed; a.coef = reinterpret_cast<const float2*>(coef); a.bias = bias; a.add_nc = add_nc; a.res = residual;
+        a.out = out; a.stats = stats;
+        a.N = N; a.H = Hl; a.W = Wl; a.Hin = Hl; a.Win = Wl; a.Cin = Cin; a.Cout = Cout; a.ups = 0; a.silu = silu ? 1 : 0; a.NS = 1;
+        if ((long long)N * H * W * Cout >= (1LL << 31) || (long long)N * Hl * Wl * Cin >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
+        a.nchunks = (Cin + BK - 1) / BK; a.cps = a.nchunks; a.split_stride = 0;
+        a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
+        a.coef_per_n = coef_per_n;
+        const int th = PIX / 32;
+        a.tiles_x = (Wl + 31) / 32; a.tiles_y = (Hl + th - 1) / th;
+        dim3 grid((unsigned)(a.tiles_x * a.tiles_y * N), (unsigned)((Cout + BN - 1) / BN), 4u);
+        const hipError_t e4 = is_bf16 ? launch_cfg<__bf16, 4>(cfg, a, grid, stream) : launch_cfg<_Float16, 4>(cfg, a, grid, stream);
+        if (e4 != hipSuccess) return fail(-2, "launch k_conv_mfma (phase upsampling)", e4);
+        if (n_slices) *n_slices = 1;
+        return 0;
+    }
     if (ksplit < 1 || (ksplit > 1 && (bias || add_nc || residual || stats || bwd_x || mode > 1 || upsample)))
         return fail(-1, "gvd_conv_mfma_splitk: a split launch is a plain stride-1 convolution (optional prologue); the sums take the rest");
     if (bwd_x) {

@@ -21,6 +21,8 @@ from . import ops
 
 SPATIAL, TEMPORAL, STRIDE2, STRIDE2_PAD_HI = 0, 1, 2, 3   # C-ABI `mode` values (include/gvd_diffusion.h)
 NEAREST, ZERO_STUFF = 1, 2                               # C-ABI `upsample` values
+UP2 = 4                                                  # C-ABI mode: nearest x2 upsampling + 3x3 as four phase convolutions of the input map
+UP2_PHASES = os.environ.get("GVD_CONV_UP2_PHASES", "1") == "1"   # 0: the on-the-fly upsampled patch with 9 taps (A/B runs, tests)
 STATS_REPLICAS = 8
 
 
@@ -81,6 +83,22 @@ def packed(weight, BN, backward=False, cin_pad=0, dtype=None):
             pass
     hit = cache[1].get(key)
     if hit is None:
+        if backward == "up2":
+            # nearest x2 upsampling + 3x3 as four 2x2 convolutions of the input map (kernel mode 4): output pixel 2 i + a reads
+            # x[i + a + k - 1], k = 0, 1, per dimension; the taps of W that land on the same input pixel are summed (fp32, one rounding):
+            # kernel index sets per (phase a, tap k):  a = 0: {0}, {1, 2};  a = 1: {0, 1}, {2}
+            sets = (((0,), (1, 2)), ((0, 1), (2,)))
+            w4 = weight.detach().float()
+            phases = []
+            for ay in (0, 1):
+                for ax in (0, 1):
+                    taps = [sum(w4[:, :, jy, jx] for jy in sets[ay][ky] for jx in sets[ax][kx]) for ky in (0, 1) for kx in (0, 1)]
+                    w3 = torch.stack(taps, dim=2).to(dtype)                       # [Cout, Cin, 4]
+                    if cin_pad:
+                        w3 = F.pad(w3, (0, 0, 0, cin_pad))
+                    phases.append(pack_weight(w3.contiguous(), BN))
+            hit = cache[1][key] = torch.stack(phases).contiguous()               # [4 phases][co tiles][chunks][4 taps][BN][4][8]
+            return hit
         w3 = _taps(weight.detach()).to(dtype)
         if backward:
             w3 = w3.flip(2).transpose(0, 1)
@@ -376,6 +394,16 @@ def _run_forward(x, weight, bias, mode, upsample, ns, silu, add_nc, residual, st
         if ns is not None:
             raise RuntimeError("fused_conv: a GroupNorm prologue needs Cin % 8 == 0")
         x = F.pad(x, (0, pad))
+    up2 = bool(upsample) and mode == SPATIAL and UP2_PHASES and W // 2 >= 24 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+    if up2:   # nearest x2 + 3x3 as four 2x2 phase convolutions of the input map: 16 tap evaluations per input pixel instead of 36
+        BN, _, _ = config(UP2, N, H, W, Cin + pad, Cout)
+        b32 = None if bias is None else ops._f32_param(bias)
+        if ns is not None and (ns.C != Cin or ns.N != N):
+            raise RuntimeError(f"fused_conv: norm state is for {ns.N} x {ns.C} channels, input has {N} x {Cin}")
+        return _launch(x.contiguous(), packed(weight, BN, "up2", pad, x.dtype), Cout, UP2, N, H, W, Cin + pad,
+                       coef_ptr=None if ns is None else ns.coef_ptr, coef_per_n=1, silu=silu, bias=b32,
+                       add_nc=None if add_nc is None else add_nc.contiguous(),
+                       residual=None if residual is None else residual.contiguous(), stats_groups=stats_groups)
     BN, _, _ = config(mode, N, H, W, Cin + pad, Cout)
     wpk = packed(weight, BN, False, pad, x.dtype)
     b32 = None if bias is None else ops._f32_param(bias)

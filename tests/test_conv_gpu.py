@@ -355,6 +355,51 @@ def test_split_k_launches_match_the_single_pass(mode, shape, Cin, Cout, dtype, m
     assert _rel(outs[True][0], ref) < (3e-3 if f16 else 2e-2), _rel(outs[True][0], ref)
 
 
+@pytest.mark.parametrize("N,h,w,Cin,Cout,dtype", [(2, 18, 32, 320, 320, torch.float16), (1, 40, 56, 256, 128, torch.float16), (3, 9, 28, 64, 640, torch.float16),
+                                                  (1, 33, 47, 40, 72, torch.float16), (2, 20, 32, 128, 128, torch.bfloat16)])
+def test_nearest_upsample_as_four_phase_convolutions(N, h, w, Cin, Cout, dtype, monkeypatch):
+    """conv3x3(nearest_x2(x)) as four 2x2 convolutions of the input map, one per output phase, with the taps that land on the same
+    input pixel summed on the host (kernel mode 4; conv.packed(..., "up2")): against the on-the-fly upsampled 9-tap form and fp32
+    torch, with the GroupNorm + SiLU prologue (applied once per INPUT pixel here), per-frame add, residual at the output resolution,
+    next-norm statistics; ragged tiles (input maps 9 x 28, 33 x 47); the input gradient (which stays the 9-tap form)."""
+    from lvdm_amd import conv as C
+    g = torch.Generator(device=DEV).manual_seed(h * w + Cin)
+    x = (torch.randn(N, h, w, Cin, device=DEV, generator=g) * 1.5 + 0.3).to(dtype).requires_grad_(True)
+    res = torch.randn(N, 2 * h, 2 * w, Cout, device=DEV, generator=g).to(dtype)
+    add = torch.randn(N, Cout, device=DEV, generator=g).to(dtype)
+    m = _conv_module(Cin, Cout, 31).to(dtype)
+    G = 8
+    gn = nn.GroupNorm(G, Cin, eps=1e-5).to(DEV).to(dtype)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(Cin, device=DEV, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(Cin, device=DEV, generator=g) * 0.2)
+    for p in gn.parameters():
+        p.requires_grad_(False)
+    gy = torch.randn(N, 2 * h, 2 * w, Cout, device=DEV, generator=g).to(dtype)
+    modes = []
+    orig = C._launch
+    monkeypatch.setattr(C, "_launch", lambda x_, w_, co, mode, *a, **k: (modes.append(mode), orig(x_, w_, co, mode, *a, **k))[1])
+    outs = {}
+    for phases in (True, False):
+        monkeypatch.setattr(C, "UP2_PHASES", phases)
+        y, part = C.fused_conv(x, m, upsample=True, gn=gn, silu=True, add_nc=add, residual=res, stats_groups=G)
+        (gx,) = torch.autograd.grad(y, [x], gy)
+        y2, _ = C.fused_conv(x.detach(), m, upsample=True)                      # plain: no prologue, no epilogue terms
+        outs[phases] = (y.detach(), gx, part.sums.sum(0), y2)
+    assert modes[0] == C.UP2 and modes.count(C.UP2) == 2, modes              # the two forwards of the first round, nothing else
+    f16 = dtype == torch.float16
+    tol = 2.5e-3 if f16 else 2e-2
+    assert _rel(outs[True][0], outs[False][0]) < tol, _rel(outs[True][0], outs[False][0])
+    assert _rel(outs[True][3], outs[False][3]) < tol
+    assert _rel(outs[True][1], outs[False][1]) < (6e-3 if f16 else 5e-2)
+    if f16:
+        assert _rel(outs[True][0], _ref_spatial(x.detach(), m, gn, True, add, res, upsample=True)) < 3e-3
+        assert _rel(outs[True][3], _ref_spatial(x.detach(), m, upsample=True)) < 2.5e-3
+    yg = outs[True][0].double().reshape(N, 4 * h * w, G, Cout // G)
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], -1)
+    assert torch.allclose(outs[True][2], want, rtol=2e-5, atol=2e-3), float((outs[True][2] - want).abs().max())
+
+
 def test_conv_bf16_and_rejections():
     from lvdm_amd import conv as C
     m = _conv_module(64, 64, 1)
