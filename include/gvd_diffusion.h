@@ -166,11 +166,11 @@ int gvd_layer_norm_bwd_add(const void* x, const void* dy, const void* gamma, con
  * stats: NULL, or fp64 accumulators [stats_replicas][Nstat][groups][2] (zeroed by the caller) that receive the sum and
  *        sum of squares of the ROUNDED outputs per (sample, group) -- Nstat = N in mode 0, the samples H in mode 1 -- i.e. the first pass
  *        of the next GroupNorm, spread over `stats_replicas` copies to keep the atomics apart (block b adds to copy b % R).
- * Cin % 8 == 0.  16-bit element type: fp16 or bf16 (is_bf16), fp32 accumulation either way.  * mode 4 (round 4): nearest x2 upsampling + 3x3 evaluated as FOUR 2x2 convolutions of the input map, one per output phase: H, W are
+ * Cin % 8 == 0.  16-bit element type: fp16 or bf16 (is_bf16), fp32 accumulation either way.
+ * mode 4 (round 4): nearest x2 upsampling + 3x3 evaluated as FOUR 2x2 convolutions of the input map, one per output phase: H, W are
  * the (even) OUTPUT dims, x is [N][H/2][W/2][Cin], w_packed holds the four phase weight sets [4][co tiles][chunks][4 taps][BN][4][8]
  * (taps of the 3x3 kernel that read the same input pixel summed: kernel index sets {0}, {1,2} for phase 0 and {0,1}, {2} for phase 1
- * per dimension; tap k of phase a reads input pixel i + a + k - 1); prologue / epilogue terms as in mode 0, `upsample` = 0.
-*/
+ * per dimension; tap k of phase a reads input pixel i + a + k - 1); prologue / epilogue terms as in mode 0, `upsample` = 0. */
 int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
                   const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
                   int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream);
