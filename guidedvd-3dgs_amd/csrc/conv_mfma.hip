@@ -110,6 +110,11 @@ template <int PIX> struct Geo<4, PIX> {   // nearest x2 upsampling + 3x3 as FOUR
     static constexpr int TW = 32, TH = PIX / 32, PW = TW + 2, PH = TH + 2, PITCH = PW * PIX_BYTES, NTAPS = 4;
     static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
 };
+template <int PIX> struct Geo<5, PIX> {   // input gradient of mode 4: the four PHASE IMAGES g[2 j + b] of the output-resolution gradient are the
+    // "input channels" of one 2x2 convolution per phase on the low-resolution grid (chunks run over phase x channel chunk)
+    static constexpr int TW = 32, TH = PIX / 32, PW = TW + 2, PH = TH + 2, PITCH = PW * PIX_BYTES, NTAPS = 4;
+    static constexpr int PATCH_BYTES = PH * PITCH, NPP_MAX = PH * PW * 4;
+};
 template <int PIX> struct Geo<2, PIX> {   // temporal: rows = (t, p), one zero halo frame on both sides
     static constexpr int NTAPS = 3, TW = 1, TH = 1, PW = 1, PITCH = 0;   // (spatial members: unused placeholders)
     static constexpr int PATCH_BYTES = (PIX + 2 * PB_MAX) * PIX_BYTES, NPP_MAX = (PIX + 2 * PB_MAX) * 4;
@@ -181,10 +186,16 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     // dimension -- a 2 x 2 convolution of the LOW-resolution map per output phase (a_y, a_x), with the taps that fall on the same input
     // pixel summed on the host (conv.py: packed(..., "up2")): 16 tap evaluations per input pixel instead of 36, the GroupNorm + SiLU
     // prologue once per input pixel instead of once per upsampled patch pixel.  blockIdx.z is the phase there, not a split-K slice.
-    constexpr bool UP2 = MODE == 4;
+    // MODE 5 (its input gradient): gx[i] = sum_a gU[2 i + a] = sum_u K_u g[2 i + u], u = -1 .. 2 per dimension, written over the phase
+    // images g_b[j] = g[2 j + b] of the output-resolution gradient: u = 2 m + b, so phase b contributes taps m in {0, 1} (b = 0) or
+    // {-1, 0} (b = 1) on the LOW-resolution grid -- the same 2 x 2 structure, with (phase, channel chunk) as the reduction dimension
+    // (a.nchunks = 4 x chunks per phase; K_u summed on the host: conv.py packed(..., "up2_bwd")).  No 2 x 2 sum pass afterwards.
+    constexpr bool UP2 = MODE == 4, DN2 = MODE == 5;
     const int phase = UP2 ? blockIdx.z : 0, ay = phase >> 1, ax = phase & 1;
-    const int chunk0 = UP2 ? 0 : blockIdx.z * a.cps;                                           // split-K slice: chunks [chunk0, chunk0 + nloc)
-    const int nloc = UP2 ? a.nchunks : (a.nchunks - chunk0 < a.cps ? a.nchunks - chunk0 : a.cps);
+    const int chunk0 = (UP2 || DN2) ? 0 : blockIdx.z * a.cps;                                  // split-K slice: chunks [chunk0, chunk0 + nloc)
+    const int nloc = (UP2 || DN2) ? a.nchunks : (a.nchunks - chunk0 < a.cps ? a.nchunks - chunk0 : a.cps);
+    const int cpp = DN2 ? a.nchunks >> 2 : 1;                                                  // MODE 5: channel chunks per phase image
+    auto phase_of = [&](int vchunk) { return (vchunk >= cpp) + (vchunk >= 2 * cpp) + (vchunk >= 3 * cpp); };   // (uniform)
 
     // ---- tile origin ----
     constexpr bool SPATIAL = MODE != 2;
@@ -226,6 +237,11 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 const int gy = 2 * ty0 + py - a.pad_lo, gx = 2 * tx0 + px - a.pad_lo;
                 loff[i] = py * G_::PITCH + px * PIX_BYTES + k8 * 16;
                 if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) goff[i] = ((n * Hin + gy) * Win + gx) * Cin;
+            } else if (DN2) {       // pixel (gy, gx) of the low-resolution grid <-> pixel (2 gy, 2 gx) of the gradient image (phase offset added per chunk)
+                const int py = pixel / G_::PW, px = pixel - py * G_::PW;
+                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                loff[i] = py * G_::PITCH + px * PIX_BYTES + k8 * 16;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) goff[i] = ((n * (2 * a.H) + 2 * gy) * (2 * a.W) + 2 * gx) * Cin;
             } else if (SPATIAL) {
                 const int py = pixel / G_::PW, px = pixel - py * G_::PW;
                 const int gy = ty0 + py - 1, gx = tx0 + px - 1;
@@ -265,15 +281,16 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
 #pragma unroll
     for (int i = 0; i < PPT; i++) loff[i] = loff[i] < 0 ? 2 * PBYTES : loff[i];      // (relative to pbuf: pbuf + 2 PBYTES == dummy)
     auto load_cf = [&](int chunk) {
-        const int c0 = (chunk0 + chunk) * BK + k8 * 8;
+        const int c0 = (DN2 ? chunk - phase_of(chunk) * cpp : chunk0 + chunk) * BK + k8 * 8;
         const float4* cp = reinterpret_cast<const float4*>(coef + (c0 < Cin ? c0 : 0));
 #pragma unroll
         for (int j = 0; j < 4; j++) cfr[j] = cp[j];
     };
     auto load_p = [&](int chunk, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
-        const int c0 = (chunk0 + chunk) * BK + k8 * 8;
-        const int c0s = c0 < Cin ? c0 : 0;
+        const int pb_ = DN2 ? phase_of(chunk) : 0;                                   // MODE 5: which phase image this chunk reads
+        const int c0 = (DN2 ? chunk - pb_ * cpp : chunk0 + chunk) * BK + k8 * 8;
+        const int c0s = (c0 < Cin ? c0 : 0) + (DN2 ? ((pb_ >> 1) * (2 * a.W) + (pb_ & 1)) * Cin : 0);
         if (HALF == 0) chan_ok = c0 < Cin;       // (both halves of a patch are written before the next patch's first half is fetched)
 #pragma unroll
         for (int i = HALF * PH0; i < (HALF ? PPT : PH0); i++)
@@ -331,7 +348,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     for (int ni = 0; ni < NI; ni++) {
         const int m = (wn * NI + ni) * 32 + r32;
         if (MODE == 0) b_off[ni] = (m >> 4) * G_::PITCH + (m & 15) * PIX_BYTES + hi * 16;
-        else if (MODE == 1 || MODE == 4) b_off[ni] = (m >> 5) * G_::PITCH + (m & 31) * PIX_BYTES + hi * 16;
+        else if (MODE == 1 || MODE == 4 || MODE == 5) b_off[ni] = (m >> 5) * G_::PITCH + (m & 31) * PIX_BYTES + hi * 16;
         else if (MODE == 3) b_off[ni] = 2 * (m >> 5) * G_::PITCH + 2 * (m & 31) * PIX_BYTES + hi * 16;
         else b_off[ni] = m * PIX_BYTES + hi * 16;
     }
@@ -376,6 +393,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 const unsigned char* wb = wbuf + wcur * WBYTES;
                 int shift;
                 if (UP2) shift = (ay + (tap >> 1)) * G_::PITCH + (ax + (tap & 1)) * PIX_BYTES;
+                else if (DN2) { const int pc = phase_of(chunk); shift = ((tap >> 1) + 1 - (pc >> 1)) * G_::PITCH + ((tap & 1) + 1 - (pc & 1)) * PIX_BYTES; }
                 else if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
                 else shift = tap * PB * PIX_BYTES;
                 const unsigned char* pb = pbuf + pcur * PBYTES + shift;
@@ -1007,9 +1025,9 @@ extern "C" {
 
 int gvd_conv_config(int mode, int N, int H, int W, int Cin, int Cout, int* block_n, int* tile_pixels, int* tile_width)
 {
-    if (mode < 0 || mode > 4 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(-1, "gvd_conv_config: bad arguments");
+    if (mode < 0 || mode > 5 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(-1, "gvd_conv_config: bad arguments");
     int cfg, tw32;
-    if (mode == 4) { choose(0, N, (H + 1) / 2, (W + 1) / 2, Cout, &cfg, &tw32); tw32 = 1; }   // phase upsampling: tiles of the INPUT map, 32 wide
+    if (mode >= 4) { choose(0, N, (H + 1) / 2, (W + 1) / 2, Cout, &cfg, &tw32); tw32 = 1; }   // phase upsampling: tiles of the INPUT map, 32 wide
     else choose(mode, N, H, W, Cout, &cfg, &tw32);
     if (block_n) *block_n = CFG_BN[cfg];
     if (tile_pixels) *tile_pixels = CFG_PIX[cfg];
@@ -1024,11 +1042,12 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
                        int ksplit = 1, int* n_slices = nullptr)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (mode == 4) {
-        // nearest x2 upsampling + 3x3 as four phase convolutions of the input map (kernel MODE 4): H, W are the OUTPUT dims
+    if (mode == 4 || mode == 5) {
+        // 4: nearest x2 upsampling + 3x3 as four phase convolutions of the input map (kernel MODE 4): H, W are the OUTPUT dims
+        // 5: its input gradient (kernel MODE 5): x = the gradient [N][H][W][Cin] at the upsampled resolution, out [N][H/2][W/2][Cout]
         if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || Cin <= 0 || Cout <= 0 || (Cin & 7) || upsample || ksplit != 1 || bwd_x ||
             (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)residual) & 15) || (stats && (groups <= 0 || Cout % groups || stats_replicas <= 0)))
-            return fail(-1, "gvd_conv_mfma (mode 4): even output dims, Cin % 8 == 0, aligned tensors, no split / norm-backward form");
+            return fail(-1, "gvd_conv_mfma (mode 4 / 5): even upsampled dims, Cin % 8 == 0, aligned tensors, no split / norm-backward form");
         const int Hl = H / 2, Wl = W / 2;
         int cfg, tw32;
         choose(0, N, Hl, Wl, Cout, &cfg, &tw32);
@@ -1037,14 +1056,16 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
         a.x = x; a.w = w_packed; a.coef = reinterpret_cast<const float2*>(coef); a.bias = bias; a.add_nc = add_nc; a.res = residual;
         a.out = out; a.stats = stats;
         a.N = N; a.H = Hl; a.W = Wl; a.Hin = Hl; a.Win = Wl; a.Cin = Cin; a.Cout = Cout; a.ups = 0; a.silu = silu ? 1 : 0; a.NS = 1;
-        if ((long long)N * H * W * Cout >= (1LL << 31) || (long long)N * Hl * Wl * Cin >= (1LL << 31)) return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
-        a.nchunks = (Cin + BK - 1) / BK; a.cps = a.nchunks; a.split_stride = 0;
+        if ((long long)N * H * W * (mode == 4 ? Cout : Cin) >= (1LL << 31) || (long long)N * Hl * Wl * (mode == 4 ? Cin : Cout) >= (1LL << 31))
+            return fail(-1, "gvd_conv_mfma: tensor too large for 32-bit offsets");
+        a.nchunks = (Cin + BK - 1) / BK * (mode == 5 ? 4 : 1); a.cps = a.nchunks; a.split_stride = 0;
         a.G = groups > 0 ? groups : 1; a.cpg = Cout / a.G; a.R = stats_replicas > 0 ? stats_replicas : 1;
         a.coef_per_n = coef_per_n;
         const int th = PIX / 32;
         a.tiles_x = (Wl + 31) / 32; a.tiles_y = (Hl + th - 1) / th;
-        dim3 grid((unsigned)(a.tiles_x * a.tiles_y * N), (unsigned)((Cout + BN - 1) / BN), 4u);
-        const hipError_t e4 = is_bf16 ? launch_cfg<__bf16, 4>(cfg, a, grid, stream) : launch_cfg<_Float16, 4>(cfg, a, grid, stream);
+        dim3 grid((unsigned)(a.tiles_x * a.tiles_y * N), (unsigned)((Cout + BN - 1) / BN), mode == 4 ? 4u : 1u);
+        const hipError_t e4 = mode == 4 ? (is_bf16 ? launch_cfg<__bf16, 4>(cfg, a, grid, stream) : launch_cfg<_Float16, 4>(cfg, a, grid, stream))
+                                        : (is_bf16 ? launch_cfg<__bf16, 5>(cfg, a, grid, stream) : launch_cfg<_Float16, 5>(cfg, a, grid, stream));
         if (e4 != hipSuccess) return fail(-2, "launch k_conv_mfma (phase upsampling)", e4);
         if (n_slices) *n_slices = 1;
         return 0;

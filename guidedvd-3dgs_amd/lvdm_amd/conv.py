@@ -21,7 +21,7 @@ from . import ops
 
 SPATIAL, TEMPORAL, STRIDE2, STRIDE2_PAD_HI = 0, 1, 2, 3   # C-ABI `mode` values (include/gvd_diffusion.h)
 NEAREST, ZERO_STUFF = 1, 2                               # C-ABI `upsample` values
-UP2 = 4                                                  # C-ABI mode: nearest x2 upsampling + 3x3 as four phase convolutions of the input map
+UP2, UP2_BWD = 4, 5                                      # C-ABI modes: nearest x2 upsampling + 3x3 as four phase convolutions of the input map; its input gradient
 UP2_PHASES = os.environ.get("GVD_CONV_UP2_PHASES", "1") == "1"   # 0: the on-the-fly upsampled patch with 9 taps (A/B runs, tests)
 STATS_REPLICAS = 8
 
@@ -98,6 +98,22 @@ def packed(weight, BN, backward=False, cin_pad=0, dtype=None):
                         w3 = F.pad(w3, (0, 0, 0, cin_pad))
                     phases.append(pack_weight(w3.contiguous(), BN))
             hit = cache[1][key] = torch.stack(phases).contiguous()               # [4 phases][co tiles][chunks][4 taps][BN][4][8]
+            return hit
+        if backward == "up2_bwd":
+            # input gradient of the phase form (kernel mode 5): gx[i] = sum_u K_u g[2 i + u], u = -1 .. 2 per dimension, K_u the sum of
+            # the transposed taps W_j^T over the index sets {2}, {1, 2}, {0, 1}, {0} (u = -1, 0, 1, 2); over the phase images
+            # g_b[j] = g[2 j + b] tap k of phase b is u = 2 k - b.  The four phases are consecutive runs of input-channel chunks.
+            usets = {-1: (2,), 0: (1, 2), 1: (0, 1), 2: (0,)}
+            w4 = weight.detach().float()
+            cg = w4.shape[0] + cin_pad
+            cg32 = -(-cg // 32) * 32
+            runs = []
+            for by in (0, 1):
+                for bx in (0, 1):
+                    taps = [sum(w4[:, :, jy, jx] for jy in usets[2 * ky - by] for jx in usets[2 * kx - bx]).t() for ky in (0, 1) for kx in (0, 1)]
+                    w3 = torch.stack(taps, dim=2).to(dtype)                       # [Cin_fwd, Cout_fwd, 4]
+                    runs.append(F.pad(w3, (0, 0, 0, cg32 - w3.shape[1])))
+            hit = cache[1][key] = pack_weight(torch.cat(runs, dim=1).contiguous(), BN)   # [co tiles][4 x chunks per phase][4 taps][BN][4][8]
             return hit
         w3 = _taps(weight.detach()).to(dtype)
         if backward:
@@ -195,7 +211,8 @@ def _launch(x, wpk, Cout, mode, N, H, W, Cin, *, coef_ptr=None, coef_per_n=1, si
     (gvd_conv_mfma_norm_bwd) instead of the forward ones."""
     P = ctypes.c_void_p
     # (temporal: N = frames, H = samples, W = pixels per frame -- the samples of a batch are extra pixel tiles of ONE launch)
-    out = torch.empty(((N, W, Cout) if H == 1 else (H, N, W, Cout)) if mode == TEMPORAL else (N, H, W, Cout), dtype=x.dtype, device=x.device)
+    out = torch.empty(((N, W, Cout) if H == 1 else (H, N, W, Cout)) if mode == TEMPORAL else ((N, H // 2, W // 2, Cout) if mode == UP2_BWD else (N, H, W, Cout)),
+                      dtype=x.dtype, device=x.device)
     sums = None
     if stats_groups:
         n_stat = H if mode == TEMPORAL else N
@@ -474,6 +491,12 @@ class _FusedConvFn(torch.autograd.Function):
                                    upsample=ZERO_STUFF)
                 if (2 * H, 2 * W) != (H_in, W_in):
                     d_act = d_act[:, :H_in, :W_in].contiguous()
+            elif (upsample and mode == SPATIAL and UP2_PHASES and W // 2 >= 24 and Cin % 8 == 0 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+                # nearest x2 + 3x3: the input gradient as ONE 2x2-per-phase convolution over the four phase images of the gradient
+                # (16 tap evaluations per input pixel instead of 36, no 2x2 sum pass behind it)
+                BN, _, _ = config(UP2_BWD, N, H, W, Cout + pad, Cin)
+                d_act, _ = _launch(g, packed(weight, BN, "up2_bwd", pad, gout.dtype), Cin, UP2_BWD, N, H, W, Cout + pad)
+                upsample = False                # (d_act is already at the input resolution)
             else:
                 Q = _sheet_plan(N, H, W) if (mode == SPATIAL and not upsample and Cin % 8 == 0) else 0
                 BN, _, _ = config(mode, N, H, W, Cout + pad, Cin)

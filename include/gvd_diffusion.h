@@ -170,7 +170,11 @@ int gvd_layer_norm_bwd_add(const void* x, const void* dy, const void* gamma, con
  * mode 4 (round 4): nearest x2 upsampling + 3x3 evaluated as FOUR 2x2 convolutions of the input map, one per output phase: H, W are
  * the (even) OUTPUT dims, x is [N][H/2][W/2][Cin], w_packed holds the four phase weight sets [4][co tiles][chunks][4 taps][BN][4][8]
  * (taps of the 3x3 kernel that read the same input pixel summed: kernel index sets {0}, {1,2} for phase 0 and {0,1}, {2} for phase 1
- * per dimension; tap k of phase a reads input pixel i + a + k - 1); prologue / epilogue terms as in mode 0, `upsample` = 0. */
+ * per dimension; tap k of phase a reads input pixel i + a + k - 1); prologue / epilogue terms as in mode 0, `upsample` = 0.
+ * mode 5: the input gradient of mode 4: x = the gradient [N][H][W][Cin] at the UPSAMPLED resolution (H, W even), out
+ * [N][H/2][W/2][Cout]; w_packed [co tiles][4 x chunks(Cin)][4 taps][BN][4][8]: the four phase images g[2 j + b] are consecutive runs
+ * of input-channel chunks (each padded to 32 channels), tap k of phase b is K_u with u = 2 k - b, K_u = the transposed 3x3 taps summed
+ * over the index sets {2}, {1,2}, {0,1}, {0} for u = -1, 0, 1, 2 (per dimension). */
 int gvd_conv_mfma(const void* x, const void* w_packed, const float* coef, int coef_per_n, const float* bias, const void* add_nc,
                   const void* residual, void* out, double* stats, int stats_replicas, int groups, int mode, int N, int H, int W,
                   int H_in, int W_in, int Cin, int Cout, int upsample, int silu, int is_bf16, void* stream);

@@ -361,7 +361,8 @@ def test_nearest_upsample_as_four_phase_convolutions(N, h, w, Cin, Cout, dtype, 
     """conv3x3(nearest_x2(x)) as four 2x2 convolutions of the input map, one per output phase, with the taps that land on the same
     input pixel summed on the host (kernel mode 4; conv.packed(..., "up2")): against the on-the-fly upsampled 9-tap form and fp32
     torch, with the GroupNorm + SiLU prologue (applied once per INPUT pixel here), per-frame add, residual at the output resolution,
-    next-norm statistics; ragged tiles (input maps 9 x 28, 33 x 47); the input gradient (which stays the 9-tap form)."""
+    next-norm statistics; ragged tiles (input maps 9 x 28, 33 x 47); and the input gradient as one 2x2-per-phase convolution over the
+    four phase images of the output-resolution gradient (kernel mode 5) against the 9-tap gradient + 2x2 sum."""
     from lvdm_amd import conv as C
     g = torch.Generator(device=DEV).manual_seed(h * w + Cin)
     x = (torch.randn(N, h, w, Cin, device=DEV, generator=g) * 1.5 + 0.3).to(dtype).requires_grad_(True)
@@ -386,7 +387,7 @@ def test_nearest_upsample_as_four_phase_convolutions(N, h, w, Cin, Cout, dtype, 
         (gx,) = torch.autograd.grad(y, [x], gy)
         y2, _ = C.fused_conv(x.detach(), m, upsample=True)                      # plain: no prologue, no epilogue terms
         outs[phases] = (y.detach(), gx, part.sums.sum(0), y2)
-    assert modes[0] == C.UP2 and modes.count(C.UP2) == 2, modes              # the two forwards of the first round, nothing else
+    assert modes[0] == C.UP2 and modes.count(C.UP2) == 2 and modes.count(C.UP2_BWD) == 1, modes   # the two forwards and the input gradient of the first round, nothing else
     f16 = dtype == torch.float16
     tol = 2.5e-3 if f16 else 2e-2
     assert _rel(outs[True][0], outs[False][0]) < tol, _rel(outs[True][0], outs[False][0])
