@@ -63,8 +63,8 @@ struct GemmArgs {
 constexpr int BM = 256, NI = 2, WN = 4;   // tokens per tile: 4 wave columns x 2 blocks of 32
 __device__ const uint4 g_zero16 = { 0u, 0u, 0u, 0u };   // source of K-tail slots
 #ifdef GVD_GEMM_TRACE
-__device__ unsigned long long g_trace[1024];   // experiments: s_memtime stamps of workgroup 0, wave 0
-#define GVD_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && trace_n + (i) < 1024) g_trace[trace_n + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_trace[1024];   // experiments: s_memtime stamps of workgroup 0, every wave (128 slots = 16 tiles each): tests/scripts/r4_gemm_trace.py
+#define GVD_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_n + (i) < 128) g_trace[(threadIdx.x >> 6) * 128 + trace_n + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define GVD_STAMP(i) do { } while (0)
 #endif
