@@ -842,6 +842,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
     mconv._split_conv, mconv._sheet_conv = timed_split, timed_sheet
     xi = x
+    smi = _SmiSampler(dev.index or 0) if (n_inst and rank == 0) else None   # (outside the headline region: a host thread polling rocm-smi)
     t1 = time.perf_counter()
     try:
         for i in range(n_inst):
@@ -849,6 +850,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         torch.cuda.synchronize()
         el_inst = max(time.perf_counter() - t1, 1e-9)
     finally:
+        clock = smi.stop() if smi else None
         ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = orig_attn, orig_conv, orig_gemm
         mconv._split_conv, mconv._sheet_conv = orig_split, orig_sheet
         sampler.graph_apply = graph_was
@@ -981,6 +983,9 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         "cpu_baseline": None,
     }
+    # what the board sustains under this workload: the MFMA families run at the socket's power cap, well under the 2.4 GHz the
+    # 2.5 PFLOP/s peak is quoted at (tests/scripts/r4_clock_power.py)
+    line["sustained_clock"] = clock
     line["launch_path"] = "hipGraph replay of the two U-Net evaluations per step (DDIMSampler.graph_apply)" if sampler.graph_apply else "eager launches"
     line["instrumented_pass"] = None if not n_inst else {"steps": n_inst, "ms_per_step": round(1e3 * el_inst / n_inst, 2),
                                                      "what": "the same steps launched eagerly with a HIP event pair around every convolution / GEMM / attention launch, "
@@ -988,6 +993,49 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     if cpu_leg_wanted and unet_tflop and world == 1:
         line["cpu_baseline"] = ddim_cpu_leg(unet, T, unet_tflop, guided)
     return line
+
+
+class _SmiSampler:
+    """Shader clock and socket power while a region runs: `rocm-smi --showclocks --showpower --json` every 0.4 s on a host thread.
+    Reported next to the rooflines (peak quoted at 2.4 GHz); never inside a headline timed region.  Any failure -> None."""
+
+    def __init__(self, index=0):
+        import threading
+        self.index, self.rows, self.halt = index, [], False
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self.halt:
+            try:
+                out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                cards = json.loads(out)
+                card = cards.get(f"card{self.index}") or cards[sorted(cards)[0]]
+                mhz = watt = None
+                for k, v in card.items():
+                    if k.lower().startswith("sclk clock speed"):
+                        m = re.search(r"(\d+)\s*mhz", str(v).lower())
+                        mhz = float(m.group(1)) if m else None
+                    if "power (w)" in k.lower():
+                        watt = float(v)
+                if mhz is not None and watt is not None:
+                    self.rows.append((mhz, watt))
+            except Exception:   # noqa: BLE001 -- a missing / different rocm-smi must not fail a bench run
+                pass
+            time.sleep(0.4)
+
+    def stop(self):
+        self.halt = True
+        self.th.join(timeout=6)
+        rows = self.rows[1:] if len(self.rows) > 2 else self.rows     # (the first sample may predate the first launch)
+        if not rows:
+            return None
+        mhz = sum(r[0] for r in rows) / len(rows)
+        return {"sclk_mhz_mean": round(mhz, 0), "sclk_mhz_min": min(r[0] for r in rows), "socket_power_w_mean": round(sum(r[1] for r in rows) / len(rows), 0),
+                "samples": len(rows), "dense_f16_peak_at_this_clock_tflops": round(2500.0 * mhz / 2400.0, 0),
+                "what": "rocm-smi polled during the instrumented pass; the roofline peaks above are the 2.4 GHz figures"}
 
 
 def ddim_cpu_leg(unet, T, unet_tflop, guided):
