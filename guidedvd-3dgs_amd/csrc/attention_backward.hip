@@ -113,7 +113,9 @@ k_attn_bwd_dkv(const T* __restrict__ q, const T* __restrict__ k, const T* __rest
     __shared__ __attribute__((aligned(16))) float sLse[64];
     __shared__ __attribute__((aligned(16))) float sDelta[64];
 
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    int bh, tile_y;
+    xcd_item_tile(bh, tile_y);
+    const int b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31;
     const size_t rs = (size_t)q_rs, krs = (size_t)kv_rs;
     const T* qb = q + (size_t)b * q_bs + (size_t)h * 64;
@@ -122,7 +124,7 @@ k_attn_bwd_dkv(const T* __restrict__ q, const T* __restrict__ k, const T* __rest
     const float* lse_b = lse + (size_t)bh * Nq;
     const float* delta_b = delta + (size_t)bh * Nq;
 
-    const int key = blockIdx.y * 128 + wave * 32 + col;
+    const int key = tile_y * 128 + wave * 32 + col;
     const bool valid_k = key < Nk;
     vec8 kf[4], vf[4];
 #pragma unroll
@@ -232,14 +234,16 @@ k_attn_bwd_dq(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
     __shared__ __attribute__((aligned(16))) T sV[64][LDS_ROW];
     __shared__ __attribute__((aligned(16))) T sKt[64][LDS_ROW];
 
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    int bh, tile_y;
+    xcd_item_tile(bh, tile_y);
+    const int b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31;
     const size_t rs = (size_t)q_rs, krs = (size_t)kv_rs;
     const size_t qoff = (size_t)b * q_bs + (size_t)h * 64;
     const T* kb = k + (size_t)b * kv_bs + (size_t)h * 64;
     const T* vb = v + (size_t)b * kv_bs + (size_t)h * 64;
 
-    const int query = blockIdx.y * 128 + wave * 32 + col;
+    const int query = tile_y * 128 + wave * 32 + col;
     const bool valid_q = query < Nq;
     vec8 qf[4], gf[4];
 #pragma unroll

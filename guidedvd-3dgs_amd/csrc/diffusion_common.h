@@ -99,4 +99,28 @@ __device__ __forceinline__ float max3f(float a, float b, float c)
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 
+// XCD-aware (item, tile) of a workgroup of an (items, tiles) grid whose tiles of one item share operands through L2 (the query
+// tiles of one (frame, head) read the same K / V).  Dispatch walks the grid x fastest and workgroup L runs on XCD L % 8 (the GEMM's
+// slot map relies on the same observation), so with the plain (blockIdx.x, blockIdx.y) = (item, tile) reading the ~64 workgroups
+// resident on an XCD belong to ~64 different items and every one of them pulls its item's K / V through that XCD's 4 MiB L2 alone
+// (level-0 self-attention: 3.6 GB fetched per launch against 0.6 GB of tensors, profiles/r04_mfma_pmc.json).  Here XCD k takes a
+// contiguous range of the (item-major) work list instead: the tiles of an item run next to each other on ONE XCD.
+#ifndef GVD_XCD_ITEMS
+#define GVD_XCD_ITEMS 1   // 0 = plain reading (A/B builds)
+#endif
+__device__ __forceinline__ void xcd_item_tile(int& item, int& tile)
+{
+#if GVD_XCD_ITEMS
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+    const unsigned L = blockIdx.y * gx + blockIdx.x, k = L & 7, i = L >> 3;
+    const unsigned a = total >> 3, r = total & 7;
+    const unsigned t = k * a + (k < r ? k : r) + i;        // XCD k holds work items [k a + min(k, r), ...): cnt_k = a + (k < r)
+    item = (int)(t / gy);
+    tile = (int)(t - (unsigned)item * gy);
+#else
+    item = blockIdx.x;
+    tile = blockIdx.y;
+#endif
+}
+
 }  // namespace gvdd

@@ -63,7 +63,9 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     __shared__ __attribute__((aligned(16))) T sKb[2][KV_TILE][LDS_ROW];   // double-buffered: one barrier per tile
     __shared__ __attribute__((aligned(16))) T sVtb[2][64][LDS_ROW];
 
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    int bh, qtile;
+    xcd_item_tile(bh, qtile);
+    const int b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
     // element (batch b, row n, head h, d) lives at b*bs + n*rs + h*64 + d: covers the plain [B, N, H*64] layout
@@ -82,7 +84,7 @@ k_attn_fwd(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     float m[QB], l[QB];
 #pragma unroll
     for (int qi = 0; qi < QB; qi++) {
-        query[qi] = blockIdx.y * (32 * WAVES * QB) + (wave * QB + qi) * 32 + col;
+        query[qi] = qtile * (32 * WAVES * QB) + (wave * QB + qi) * 32 + col;
         valid_q[qi] = query[qi] < Nq;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++)
