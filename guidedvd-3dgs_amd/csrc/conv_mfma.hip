@@ -73,6 +73,7 @@ struct ConvArgs {
     int pad_lo;               // stride-2 mode: zero rows / columns in front of the image (1: U-Net Downsample, 0: VAE Downsample)
     int tiles_x, tiles_y;
     int nchunks;
+    int xcd_map;          // 1: read the grid through xcd_conv_ids (the channel tiles / phases of a pixel tile next to each other on one XCD)
     int cps;              // split-K: input-channel chunks per blockIdx.z slice (== nchunks: no split); slice z writes its partial sums to
     long long split_stride;   // out + z * split_stride (elements); no bias / add / residual / statistics on such launches
     int cpg, G, R;
@@ -180,7 +181,10 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, r32 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const int co_tile = blockIdx.y;
+    // XCD-aware reading of the grid (diffusion_common.h) where the input map is the large stream: the channel tiles / phases of a
+    // pixel tile then share its patch through one L2 instead of fetching it gridDim.y (x 4 phases) times from beyond (xcd_rule())
+    int pxi = blockIdx.x, co_tile = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd_map) xcd_conv_ids(pxi, co_tile, bz);
     const int Cin = a.Cin, Cout = a.Cout;
     // MODE 4 (upsampling as four phase convolutions): y[2 i + a] = sum_t W_t U(x)[2 i + a + t] touches x[i + a + k - 1], k = 0, 1, per
     // dimension -- a 2 x 2 convolution of the LOW-resolution map per output phase (a_y, a_x), with the taps that fall on the same input
@@ -191,8 +195,8 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     // {-1, 0} (b = 1) on the LOW-resolution grid -- the same 2 x 2 structure, with (phase, channel chunk) as the reduction dimension
     // (a.nchunks = 4 x chunks per phase; K_u summed on the host: conv.py packed(..., "up2_bwd")).  No 2 x 2 sum pass afterwards.
     constexpr bool UP2 = MODE == 4, DN2 = MODE == 5;
-    const int phase = UP2 ? blockIdx.z : 0, ay = phase >> 1, ax = phase & 1;
-    const int chunk0 = (UP2 || DN2) ? 0 : blockIdx.z * a.cps;                                  // split-K slice: chunks [chunk0, chunk0 + nloc)
+    const int phase = UP2 ? bz : 0, ay = phase >> 1, ax = phase & 1;
+    const int chunk0 = (UP2 || DN2) ? 0 : bz * a.cps;                                  // split-K slice: chunks [chunk0, chunk0 + nloc)
     const int nloc = (UP2 || DN2) ? a.nchunks : (a.nchunks - chunk0 < a.cps ? a.nchunks - chunk0 : a.cps);
     const int cpp = DN2 ? a.nchunks >> 2 : 1;                                                  // MODE 5: channel chunks per phase image
     auto phase_of = [&](int vchunk) { return (vchunk >= cpp) + (vchunk >= 2 * cpp) + (vchunk >= 3 * cpp); };   // (uniform)
@@ -202,13 +206,13 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     int n = 0, ty0 = 0, tx0 = 0, p0 = 0;
     if (SPATIAL) {
         const int per_img = a.tiles_x * a.tiles_y;
-        n = blockIdx.x / per_img;
-        const int rem = blockIdx.x - n * per_img;
+        n = pxi / per_img;
+        const int rem = pxi - n * per_img;
         ty0 = (rem / a.tiles_x) * G_::TH;
         tx0 = (rem % a.tiles_x) * G_::TW;
     } else {
-        n = blockIdx.x / a.tiles_x;                       // sample: the (3,1,1) convolution treats pixels independently, so the samples of
-        p0 = (blockIdx.x - n * a.tiles_x) * a.PB;         // a batch are just more pixel tiles of ONE launch (per-sample norms via coef_per_n)
+        n = pxi / a.tiles_x;                              // sample: the (3,1,1) convolution treats pixels independently, so the samples of
+        p0 = (pxi - n * a.tiles_x) * a.PB;         // a batch are just more pixel tiles of ONE launch (per-sample norms via coef_per_n)
     }
     const int PB = a.PB;
     const size_t sample_in = SPATIAL ? 0 : (size_t)n * a.N * a.W * a.Cin, sample_out = SPATIAL ? 0 : (size_t)n * a.N * a.W * a.Cout;
@@ -424,7 +428,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     GVD_CSTAMP(2);
 
     // ---- epilogue ----
-    T* __restrict__ out = (T*)a.out + (UP2 ? (size_t)0 : (size_t)blockIdx.z * (size_t)a.split_stride);
+    T* __restrict__ out = (T*)a.out + (UP2 ? (size_t)0 : (size_t)bz * (size_t)a.split_stride);
     const T* __restrict__ res = (const T*)a.res;
     const T* __restrict__ bx = (const T*)a.bx;
     float ssum[8], ssq[8];
@@ -834,6 +838,17 @@ __global__ void __launch_bounds__(64) k_gn_merge_coef(const double* __restrict__
 // (Measured alternative, not kept: staging the weight slabs with LDS-DMA (global_load_lds) instead of through registers was
 //  within +-3 % on every U-Net / VAE shape -- two workgroups per CU already cover the ds_write pass.)
 
+// When the XCD-aware grid reading pays (measured, profiles/r04_conv_xcd_map.txt): several channel tiles (or the four upsampling phases)
+// per pixel tile, no split-K slices (those share nothing), and the input map at least four times the weights -- with the plain
+// reading the workgroups resident on an XCD share a weight slab, with this one an input patch; at 18 x 32 x 1280 channels (37 MB of
+// input, 29 MB of weights) the plain reading wins by 3 %, at 9 x 16 by 12 %; at 72 x 128 / 36 x 64 and in the VAE this one by 2-4 %.
+static int xcd_rule(long long in_bytes, long long w_bytes, unsigned sharers, unsigned slices)
+{
+    static const int forced = [] { const char* e = getenv("GVD_CONV_XCD_MAP"); return e ? atoi(e) : -1; }();   // (A/B switch: 0 / 1)
+    if (forced == 0 || forced == 1) return forced;
+    return slices == 1 && sharers > 1 && in_bytes >= 4 * w_bytes;
+}
+
 template <typename T, int MI, int NI, int WM, int WN, int MODE, int PRO>
 hipError_t launch_pro(const ConvArgs& a, dim3 grid, hipStream_t stream)
 {
@@ -1064,6 +1079,7 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
         const int th = PIX / 32;
         a.tiles_x = (Wl + 31) / 32; a.tiles_y = (Hl + th - 1) / th;
         dim3 grid((unsigned)(a.tiles_x * a.tiles_y * N), (unsigned)((Cout + BN - 1) / BN), mode == 4 ? 4u : 1u);
+        a.xcd_map = xcd_rule((long long)N * (mode == 4 ? Hl * Wl : H * W) * Cin * 2, 16LL * Cin * Cout * 2, grid.y * grid.z, 1);
         const hipError_t e4 = mode == 4 ? (is_bf16 ? launch_cfg<__bf16, 4>(cfg, a, grid, stream) : launch_cfg<_Float16, 4>(cfg, a, grid, stream))
                                         : (is_bf16 ? launch_cfg<__bf16, 5>(cfg, a, grid, stream) : launch_cfg<_Float16, 5>(cfg, a, grid, stream));
         if (e4 != hipSuccess) return fail(-2, "launch k_conv_mfma (phase upsampling)", e4);
@@ -1118,6 +1134,7 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
     dim3 grid;
     grid.y = (Cout + BN - 1) / BN;
     grid.z = (unsigned)slices;
+    a.xcd_map = xcd_rule(in_elems * 2, (mode == 1 ? 3LL : 9LL) * Cin * Cout * 2, grid.y, (unsigned)slices);
     hipError_t e;
     if (mode != 1) {
         const int tw = (mode >= 2 || tw32) ? 32 : 16, th = PIX / tw;

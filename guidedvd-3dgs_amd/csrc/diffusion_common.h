@@ -123,4 +123,22 @@ __device__ __forceinline__ void xcd_item_tile(int& item, int& tile)
 #endif
 }
 
+// The same for a (pixel tiles, channel tiles, phases | K slices) convolution grid: the channel tiles (and upsampling phases) of one
+// pixel tile read the same input patch, so they are made neighbours on one XCD (channel tile fastest, then z, then the pixel tile).
+__device__ __forceinline__ void xcd_conv_ids(int& px, int& co, int& z)
+{
+#if GVD_XCD_ITEMS
+    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+    const unsigned L = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x, k = L & 7, i = L >> 3;
+    const unsigned a = total >> 3, r = total & 7;
+    const unsigned t = k * a + (k < r ? k : r) + i;
+    const unsigned u = t / gy;
+    co = (int)(t - u * gy);
+    px = (int)(u / gz);
+    z = (int)(u - (unsigned)px * gz);
+#else
+    px = blockIdx.x; co = blockIdx.y; z = blockIdx.z;
+#endif
+}
+
 }  // namespace gvdd
