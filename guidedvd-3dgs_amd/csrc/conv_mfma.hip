@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
     // XCD-aware reading of the grid (diffusion_common.h) where the input map is the large stream: the channel tiles / phases of a
     // pixel tile then share its patch through one L2 instead of fetching it gridDim.y (x 4 phases) times from beyond (xcd_rule())
     int pxi = blockIdx.x, co_tile = blockIdx.y, bz = blockIdx.z;
-    if (a.xcd_map) xcd_conv_ids(pxi, co_tile, bz);
+    if (a.xcd_map) xcd_conv_ids(pxi, co_tile, bz, a.xcd_map == 2);
     const int Cin = a.Cin, Cout = a.Cout;
     // MODE 4 (upsampling as four phase convolutions): y[2 i + a] = sum_t W_t U(x)[2 i + a + t] touches x[i + a + k - 1], k = 0, 1, per
     // dimension -- a 2 x 2 convolution of the LOW-resolution map per output phase (a_y, a_x), with the taps that fall on the same input
@@ -838,15 +838,24 @@ __global__ void __launch_bounds__(64) k_gn_merge_coef(const double* __restrict__
 // (Measured alternative, not kept: staging the weight slabs with LDS-DMA (global_load_lds) instead of through registers was
 //  within +-3 % on every U-Net / VAE shape -- two workgroups per CU already cover the ds_write pass.)
 
-// When the XCD-aware grid reading pays (measured, profiles/r04_conv_xcd_map.txt): several channel tiles (or the four upsampling phases)
-// per pixel tile, no split-K slices (those share nothing), and the input map at least four times the weights -- with the plain
-// reading the workgroups resident on an XCD share a weight slab, with this one an input patch; at 18 x 32 x 1280 channels (37 MB of
-// input, 29 MB of weights) the plain reading wins by 3 %, at 9 x 16 by 12 %; at 72 x 128 / 36 x 64 and in the VAE this one by 2-4 %.
-static int xcd_rule(long long in_bytes, long long w_bytes, unsigned sharers, unsigned slices)
+// Which XCD-aware grid reading a launch takes (measured: profiles/r04_conv_xcd_map.txt).  With the plain reading the pixel tiles of one
+// (channel tile, slice) are dealt round-robin to the 8 XCDs: every XCD pulls every weight slab AND the gy channel tiles of a pixel tile
+// fetch its patch gy times.  Reading 1 (inputs first) makes the channel tiles / upsampling phases of a pixel tile neighbours on one XCD:
+// the patch is fetched once, every XCD streams all weights once per round of resident workgroups.  Reading 2 (weights first) makes the
+// pixel tiles of one (channel tile, K slice) neighbours: a slab lives in 8 / (gy gz) L2s (>= 1), the patches are fetched gy times.
+// Bytes from beyond L2, per launch:  reading 1: in + 8 w rounds;  reading 2: min(gy, 8) in + max(1, 8 / (gy gz)) w.  Split-K slices share
+// no input, so they only take reading 2.
+static int xcd_rule(long long in_bytes, long long w_bytes, unsigned gx, unsigned gy, unsigned gz, bool split)
 {
-    static const int forced = [] { const char* e = getenv("GVD_CONV_XCD_MAP"); return e ? atoi(e) : -1; }();   // (A/B switch: 0 / 1)
-    if (forced == 0 || forced == 1) return forced;
-    return slices == 1 && sharers > 1 && in_bytes >= 4 * w_bytes;
+    static const int forced = [] { const char* e = getenv("GVD_CONV_XCD_MAP"); return e ? atoi(e) : -1; }();   // (A/B switch: 0 plain, 1, 2)
+    if (forced >= 0 && forced <= 2) return (forced == 1 && split) ? 0 : forced;
+    if (gx * gy * gz < 16) return 0;
+    const double rounds = (double)((gx * gy * gz + 511) / 512);
+    const unsigned share = gy * gz;
+    const double c1 = split ? 1e30 : (double)in_bytes + 8.0 * (double)w_bytes * rounds;
+    const double c2 = (double)(gy < 8 ? gy : 8) * (double)in_bytes + (share >= 8 ? 1.0 : 8.0 / share) * (double)w_bytes;
+    if (gy * gz == 1) return 0;      // one workgroup per pixel tile and one slab: nothing to choose
+    return c1 <= c2 ? 1 : 2;
 }
 
 template <typename T, int MI, int NI, int WM, int WN, int MODE, int PRO>
@@ -1079,7 +1088,7 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
         const int th = PIX / 32;
         a.tiles_x = (Wl + 31) / 32; a.tiles_y = (Hl + th - 1) / th;
         dim3 grid((unsigned)(a.tiles_x * a.tiles_y * N), (unsigned)((Cout + BN - 1) / BN), mode == 4 ? 4u : 1u);
-        a.xcd_map = xcd_rule((long long)N * (mode == 4 ? Hl * Wl : H * W) * Cin * 2, 16LL * Cin * Cout * 2, grid.y * grid.z, 1);
+        a.xcd_map = xcd_rule((long long)N * (mode == 4 ? Hl * Wl : H * W) * Cin * 2, 16LL * Cin * Cout * 2, grid.x, grid.y, grid.z, false);
         const hipError_t e4 = mode == 4 ? (is_bf16 ? launch_cfg<__bf16, 4>(cfg, a, grid, stream) : launch_cfg<_Float16, 4>(cfg, a, grid, stream))
                                         : (is_bf16 ? launch_cfg<__bf16, 5>(cfg, a, grid, stream) : launch_cfg<_Float16, 5>(cfg, a, grid, stream));
         if (e4 != hipSuccess) return fail(-2, "launch k_conv_mfma (phase upsampling)", e4);
@@ -1134,12 +1143,12 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
     dim3 grid;
     grid.y = (Cout + BN - 1) / BN;
     grid.z = (unsigned)slices;
-    a.xcd_map = xcd_rule(in_elems * 2, (mode == 1 ? 3LL : 9LL) * Cin * Cout * 2, grid.y, (unsigned)slices);
     hipError_t e;
     if (mode != 1) {
         const int tw = (mode >= 2 || tw32) ? 32 : 16, th = PIX / tw;
         a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
         grid.x = (unsigned)(a.tiles_x * a.tiles_y * N);
+        a.xcd_map = xcd_rule(in_elems * 2, 9LL * Cin * Cout * 2, grid.x, grid.y, grid.z, slices > 1);
         if (mode >= 2) e = is_bf16 ? launch_stride2<__bf16>(cfg, a, grid, stream) : launch_stride2<_Float16>(cfg, a, grid, stream);
         else if (tw32) e = is_bf16 ? launch_cfg<__bf16, 1>(cfg, a, grid, stream) : launch_cfg<_Float16, 1>(cfg, a, grid, stream);
         else e = is_bf16 ? launch_cfg<__bf16, 0>(cfg, a, grid, stream) : launch_cfg<_Float16, 0>(cfg, a, grid, stream);
@@ -1150,6 +1159,7 @@ static int conv_launch(const void* x, const void* w_packed, const float* coef, i
         a.PB = pb;
         a.tiles_x = (W + pb - 1) / pb; a.tiles_y = 1;
         grid.x = (unsigned)(a.tiles_x * NS);
+        a.xcd_map = xcd_rule(in_elems * 2, 3LL * Cin * Cout * 2, grid.x, grid.y, grid.z, slices > 1);
         e = is_bf16 ? launch_cfg<__bf16, 2>(cfg, a, grid, stream) : launch_cfg<_Float16, 2>(cfg, a, grid, stream);
     }
     if (e != hipSuccess) return fail(-2, "launch k_conv_mfma", e);

@@ -125,17 +125,26 @@ __device__ __forceinline__ void xcd_item_tile(int& item, int& tile)
 
 // The same for a (pixel tiles, channel tiles, phases | K slices) convolution grid: the channel tiles (and upsampling phases) of one
 // pixel tile read the same input patch, so they are made neighbours on one XCD (channel tile fastest, then z, then the pixel tile).
-__device__ __forceinline__ void xcd_conv_ids(int& px, int& co, int& z)
+// `weights_first` is the mirror image for launches whose WEIGHTS are the large stream (small maps, 1280 channels, split-K slices):
+// the pixel tiles of one (channel tile, K slice) are neighbours on one XCD and share its weight slab; pixel tile fastest.
+__device__ __forceinline__ void xcd_conv_ids(int& px, int& co, int& z, bool weights_first)
 {
 #if GVD_XCD_ITEMS
     const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
     const unsigned L = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x, k = L & 7, i = L >> 3;
     const unsigned a = total >> 3, r = total & 7;
     const unsigned t = k * a + (k < r ? k : r) + i;
-    const unsigned u = t / gy;
-    co = (int)(t - u * gy);
-    px = (int)(u / gz);
-    z = (int)(u - (unsigned)px * gz);
+    if (weights_first) {
+        const unsigned u = t / gx;
+        px = (int)(t - u * gx);
+        z = (int)(u / gy);
+        co = (int)(u - (unsigned)z * gy);
+    } else {
+        const unsigned u = t / gy;
+        co = (int)(t - u * gy);
+        px = (int)(u / gz);
+        z = (int)(u - (unsigned)px * gz);
+    }
 #else
     px = blockIdx.x; co = blockIdx.y; z = blockIdx.z;
 #endif
