@@ -714,6 +714,9 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
     {   // channel tiles whose W rows (bn x K x 2 bytes each) share an XCD's L2 with the token panels in flight
         static const long long budget = [] { const char* e = getenv("GVD_GEMM_L2_BYTES"); return e ? atoll(e) : (3LL << 19); }();
         long long g = budget / ((long long)bn * K * 2);
+        // (a lone last tile as its own group re-reads every token panel for it: 7 + 1 of the level-0 feed-forward's 8 tiles.  Up to a
+        //  third over the budget, one group: 230 400 x 2560 x 320 0.614 -> 0.588 ms, profiles/r04_gemm_l2_budget.txt)
+        if ((long long)a.tiles_n * bn * K * 2 * 3 <= budget * 4) g = a.tiles_n;
         a.ngroup = (int)(g < 1 ? 1 : (g > a.tiles_n ? a.tiles_n : g));
     }
     if ((long long)a.mgroups * 8 * a.tiles_n * batch >= (1LL << 31)) return fail(-1, "gvd_gemm_nt: grid too large");
