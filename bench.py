@@ -986,6 +986,10 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     # what the board sustains under this workload: the MFMA families run at the socket's power cap, well under the 2.4 GHz the
     # 2.5 PFLOP/s peak is quoted at (tests/scripts/r4_clock_power.py)
     line["sustained_clock"] = clock
+    if clock and clock.get("dense_f16_peak_at_this_clock_tflops"):
+        for r in (r_conv, r_attn, r_gemm):      # (`frac` stays the fraction of the 2.4 GHz peak; this is the same figure against the clock the board held)
+            if r:
+                r["frac_at_sustained_clock"] = round(r["achieved"] / clock["dense_f16_peak_at_this_clock_tflops"], 4)
     line["launch_path"] = "hipGraph replay of the two U-Net evaluations per step (DDIMSampler.graph_apply)" if sampler.graph_apply else "eager launches"
     line["instrumented_pass"] = None if not n_inst else {"steps": n_inst, "ms_per_step": round(1e3 * el_inst / n_inst, 2),
                                                      "what": "the same steps launched eagerly with a HIP event pair around every convolution / GEMM / attention launch, "
