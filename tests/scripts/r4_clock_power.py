@@ -64,12 +64,16 @@ for (M, N, K) in [(230400, 2560, 320), (57600, 5120, 640), (14400, 10240, 1280)]
     bh = b.half()
     run(f"gemm {M}x{N}x{K} ours", lambda: gemm.gemm_nt(x, w, bias=b), 2.0 * M * N * K)
     run(f"gemm {M}x{N}x{K} hipBLASLt", lambda: F.linear(x, w, bh), 2.0 * M * N * K)
-x = torch.randn(25, 160, 224, 256, device=dev, generator=g).half()    # channels-last rows
-w = (torch.randn(256, 256, 3, 3, device=dev, generator=g) * 0.02).half()
-try:
-    pk = conv.packed(w, None) if hasattr(conv, "packed") else None
-except Exception:  # noqa: BLE001
-    pk = None
+# level-0 self-attention (25 frames x 5 heads, 9216 tokens) and two convolutions (U-Net 72 x 128 640 -> 640, VAE 576 x 1024 128 -> 128)
+q, k, v = (torch.randn(25, 9216, 320, device=dev, generator=g).half() for _ in range(3))
+run("attention fwd 25x5 heads N=9216 d=64", lambda: ops._hip_attention_fwd(q, k, v, 5, False, want_lse=True), 4.0 * 25 * 5 * 9216 * 9216 * 64)
+del q, k, v
+for (N, H, W, Cin, Cout) in [(25, 72, 128, 640, 640), (1, 576, 1024, 128, 128)]:
+    xc = torch.randn(N, H, W, Cin, device=dev, generator=g).half()
+    m = torch.nn.Conv2d(Cin, Cout, 3, padding=1).to(dev).half().requires_grad_(False)
+    with torch.no_grad():
+        run(f"conv3x3 N={N} {H}x{W} {Cin}->{Cout}", lambda: conv.fused_conv(xc, m), 2.0 * N * H * W * Cin * Cout * 9)
+    del xc, m
 xm = torch.randn(8 * 1024 * 1024, device=dev, generator=g).half()
 run("copy 16 MB x2 (HBM stream)", lambda: xm.clone(), 0.0)
 stop[0] = True
