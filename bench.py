@@ -909,6 +909,24 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         with open(os.environ["GVD_BENCH_SHAPE_TABLE"], "w") as fh:
             json.dump({"legend": {"conv": ["conv", "mode (0 spatial, 1 temporal, 2 stride-2)", "N", "H", "W", "Cin", "Cout", "upsample"],
                                   "gemm": ["gemm", "batch", "M", "N", "K", "geglu", "layernorm_fold", "residual"]}, "rows": rows}, fh, indent=1)
+    # `traffic` of the three MFMA families: memory-side bytes PER LAUNCH of one representative shape of the family, from the committed
+    # counter passes (separate rocprofv3 --pmc runs of tests/scripts/diff_kernels_one.py; FETCH_SIZE x 2 + WRITE_SIZE) -- never observed
+    # in this run, and only quoted at the resolution those passes ran at
+    if (args.ddim_height, args.ddim_width) == (576, 1024) and not guided:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_mfma_pmc.json")) as fh:
+                pmc_all = json.load(fh)
+            for r, prefix, what in ((r_attn, "attn i4ELi2", "level-0 self-attention forward, 25 frames x 5 heads x 9216 tokens (0.59 GB of q, k, v, out)"),
+                                    (r_gemm, "gemm L0 ff-in", "level-0 feed-forward in, 230400 x 2560 x 320 with LayerNorm fold + GEGLU (0.15 GB in, 0.59 GB out)"),
+                                    (r_conv, "conv fmaIDF16_Li5ELi2ELi1ELi4ELi1ELi0", "3x3 convolution 25 x 72 x 128, 640 -> 640 (0.29 GB in, 0.29 GB out, 7 MB of weights)")):
+                row = next((v for k, v in pmc_all.items() if k.startswith(prefix)), None)
+                if r and row and row.get("launches"):
+                    r["traffic"] = int(row["traffic_bytes"] / row["launches"])
+                    r["traffic_of"] = (what + "; profiles/r04_mfma_pmc.json, NOT observed in this run.  FETCH_SIZE doubled (the guide's gfx950 correction for "
+                                       "16-byte-per-lane reads), WRITE_SIZE raw -- uncalibrated per the guide, and on these kernels' 16-byte stores it reports about a "
+                                       "third of the known output bytes (attention out 147 MB -> 51 MB, GEMM out 590 -> 197, convolution out 295 -> 117)")
+        except (OSError, ValueError, KeyError):
+            pass
     # Bandwidth-bound Linear shapes (arithmetic intensity under the 2.5 PFLOP/s : 8 TB/s ridge of 312 flop/byte) get an HBM roofline
     # object of their own -- the MFMA fraction of such a launch says nothing: algorithmic bytes (X, W, Y and the residual, 16 bit) over
     # the in-run event time of the shape with the most time per step; `traffic` = the committed counter pass of that shape if it has one
