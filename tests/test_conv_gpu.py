@@ -422,3 +422,54 @@ def test_conv_bf16_and_rejections():
     yt, _ = C.fused_conv(xt, m3, mode=C.TEMPORAL)
     reft = F.conv3d(xt.float().permute(2, 0, 1)[None, ..., None], m3.weight.float(), m3.bias.float(), padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0)
     assert _rel(yt, reft) < 1.5e-2
+
+
+_XCD_PROBE = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "guidedvd-3dgs_amd"))
+import torch, torch.nn as nn
+from lvdm_amd import conv as C
+dev = "cuda:0"
+torch.manual_seed(0)                       # (the modules' default initialisation of biases / the Conv3d)
+g = torch.Generator(device=dev).manual_seed(3)
+out = []
+# several channel tiles per pixel tile (inputs first / weights first differ), a ragged map, a temporal launch with two samples, an
+# upsampling launch (four phases), a small map that is split along K, and the input gradient of the first
+for (N, H, W, Cin, Cout, kw) in [(3, 40, 56, 320, 640, {}), (2, 21, 37, 128, 384, {}), (2, 32, 48, 256, 256, {"upsample": True}), (5, 10, 14, 1280, 1280, {})]:
+    m = nn.Conv2d(Cin, Cout, 3, padding=1).to(dev).half().requires_grad_(False)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(m.weight.shape, device=dev, generator=g) * 0.02)
+    x = torch.randn(N, (H // 2) if kw else H, (W // 2) if kw else W, Cin, device=dev, generator=g).half().requires_grad_(not kw)
+    y, _ = C.fused_conv(x, m, **kw)
+    out.append(y.detach())
+    if not kw and Cin == 320:
+        (gx,) = torch.autograd.grad(y, [x], torch.ones_like(y))
+        out.append(gx)
+m3 = nn.Conv3d(640, 640, (3, 1, 1), padding=(1, 0, 0)).to(dev).half().requires_grad_(False)
+xt = torch.randn(2, 25, 70, 640, device=dev, generator=g).half()
+out.append(C.fused_conv(xt, m3, mode=C.TEMPORAL)[0])
+h = hashlib.sha256()
+for t in out:
+    h.update(t.float().cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_xcd_aware_grid_readings_are_permutations_of_the_same_work():
+    """csrc/diffusion_common.h xcd_conv_ids: the plain grid reading, inputs-first and weights-first (GVD_CONV_XCD_MAP = 0 / 1 / 2, read
+    once per process) and the per-launch rule must produce bit-identical outputs -- they only change WHICH workgroup does which tile."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for tag, val in (("plain", "0"), ("inputs", "1"), ("weights", "2"), ("rule", None)):
+        env = dict(os.environ)
+        env.pop("GVD_CONV_XCD_MAP", None)
+        if val is not None:
+            env["GVD_CONV_XCD_MAP"] = val
+        r = subprocess.run([sys.executable, "-c", _XCD_PROBE, root], env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")]
+        assert r.returncode == 0 and lines, (tag, r.stdout[-500:], r.stderr[-2000:])
+        digests[tag] = lines[-1]
+    assert len(set(digests.values())) == 1, digests
