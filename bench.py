@@ -268,6 +268,21 @@ def raster_run(args, dev, rank, world):
             torch.cuda.synchronize()
             t_sus = time.perf_counter() - t0s
         sustained = {"value": round(n_sus / t_sus, 2), "unit": "iters/s", "steps": n_sus, "window_s": round(t_sus, 3)}
+    # which clock the board holds under this loop (the VALU-issue roofline below is quoted at the nominal 2.4 GHz): a third, short
+    # window with a host thread polling rocm-smi -- it disturbs the host, so nothing from this window is reported as a rate
+    raster_clock = None
+    if world == 1 and rank == 0:
+        smi = _SmiSampler(dev.index or 0)
+        t0c, k_ = time.perf_counter(), 0
+        while time.perf_counter() - t0c < 1.3:
+            for i in range(100):
+                step(args.warmup + args.steps + k_ + i)
+            k_ += 100
+            torch.cuda.synchronize()
+        raster_clock = smi.stop()
+        if raster_clock:
+            raster_clock.pop("dense_f16_peak_at_this_clock_tflops", None)
+            raster_clock["what"] = "rocm-smi polled over a separate ~1.3 s window of the same loop (no rate is taken from that window)"
     two_view = None
     if world > 1:   # every rank takes part (barriers); an odd last rank has no partner and simply trains alone
         reduce_grads = pair_group is not None
@@ -351,7 +366,7 @@ def raster_run(args, dev, rank, world):
                             issue[kname] = {"ideal_us": round(ideal, 1), "avg_us": round(kern[kname]["avg_us"], 2),
                                             "frac": round(ideal / kern[kname]["avg_us"], 3)}
                     roofline["valu_issue"] = {"bound": "valu", "unit": "us per launch at 1024 SIMDs x 2.4 GHz", "kernels": issue,
-                                              "useful_lane_fraction": vv.get("useful_lane_fraction"),
+                                              "useful_lane_fraction": vv.get("useful_lane_fraction"), "sustained_clock": raster_clock,
                                               "from": "profiles/r04_raster_valu.json (lane_stats.py wave steps, ISA instruction counts at HEAD; NOT observed in this run)"}
                 except Exception:
                     pass
