@@ -57,6 +57,11 @@ struct GemmArgs {
 #ifndef GVD_GEMM_KUNROLL5
 #define GVD_GEMM_KUNROLL5 4   // (2 measured 1-3 % slower once the kernels stopped spilling)
 #endif
+#ifndef GVD_GEMM_NT_STORE
+#define GVD_GEMM_NT_STORE 1   // the output rows leave as non-temporal stores (0: plain, for A/B builds): a 150-590 MB output of the level-0 shapes only
+                              // passes through the caches on its way out -- 230 400 x 960 x 320 0.259 -> 0.234 ms, x 2560 0.588 -> 0.551, DDIM step
+                              // 238.2 -> 234.7 ms (profiles/r04_nt_stores.txt); neutral on the small shapes
+#endif
 #ifndef GVD_GEMM_DBG
 #define GVD_GEMM_DBG 0   // experiments only (tests/scripts/build_gemm_variants.sh): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue, 8 = one K-tile only, 16 = no global stores
 #endif
@@ -414,7 +419,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 #if GVD_GEMM_DBG & 16
                     if (m < a.M && col < ncols && w.x == 0x12345678u) *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
 #else
+#if GVD_GEMM_NT_STORE
+                    if (m < a.M && col < ncols) {
+                        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(u4v{ w.x, w.y, w.z, w.w }, reinterpret_cast<u4v*>(yb + (size_t)m * a.ldy + col));
+                    }
+#else
                     if (m < a.M && col < ncols) *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
+#endif
 #endif
                 }
             }
