@@ -226,7 +226,7 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     sa.radii = radii; sa.cursor = (uint32_t*)(geom + L.cursor);
     sa.point_offsets = (uint32_t*)(geom + L.point_offsets); sa.bucket = (uint64_t*)(bin + L.bucket);
     // zeroed here for the backward (no memset launch there) -- unless the caller announced that none will follow
-    sa.partials = t_expect_backward ? (float*)(bin + L.partials) : nullptr;
+    sa.pflags = t_expect_backward ? (uint32_t*)(bin + L.pflags) : nullptr;
     {
         ProfScope ps("scatter", stream);
         launch_scatter(sa, L.bin_blocks, L.lds_hist != 0, stream);
@@ -443,7 +443,8 @@ int gvd_raster_backward_conf(
     }
     const Layout L = make_layout(P, width, height, cap);
     if (!radii) radii = (const int*)(geom + L.internal_radii);
-    float* partials = (float*)(bin + L.partials);   // zeroed by the forward's k_scatter; k_render_bwd overwrites what it reaches
+    float* partials = (float*)(bin + L.partials);   // sub-records; their flag words were cleared by the forward's k_scatter
+    uint32_t* pflags = (uint32_t*)(bin + L.pflags);
     RenderBwdArgs ra{};
     ra.W = width; ra.H = height; ra.gx = L.gx; ra.gy = L.gy; ra.capacity = cap;
     ra.ranges = (const uint32_t*)(img + L.ranges); ra.point_list = (const uint32_t*)(bin + L.point_list);
@@ -452,7 +453,7 @@ int gvd_raster_backward_conf(
     ra.scalars = (const uint32_t*)(geom + L.scalars);
     ra.radii = radii; ra.means2D = (const float*)(geom + L.means2D); ra.conic_opacity = (const float*)(geom + L.conic_opacity);
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = background; ra.alphas = alphas;
-    ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials;
+    ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials; ra.pflags = pflags;
     {
         ProfScope ps("render_bwd", stream);
         launch_render_bwd(ra, L.T, stream);
@@ -467,7 +468,7 @@ int gvd_raster_backward_conf(
     ga.viewmatrix = viewmatrix; ga.projmatrix = projmatrix; ga.campos = campos; ga.radii = radii;
     ga.clamped = (const uint32_t*)(geom + L.clamped); ga.point_offsets = (const uint32_t*)(geom + L.point_offsets);
     ga.scalars = (const uint32_t*)(geom + L.scalars);
-    ga.partials = partials;
+    ga.partials = partials; ga.pflags = pflags;
     ga.confidence = confidence;
     ga.has_sh = (shs != nullptr && M > 0 && colors_precomp == nullptr) ? 1 : 0;
     ga.has_scales = (scales != nullptr && rotations != nullptr && cov3D_precomp == nullptr) ? 1 : 0;

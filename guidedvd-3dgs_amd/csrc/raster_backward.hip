@@ -1,13 +1,13 @@
 // raster_backward.hip -- backward pass of the MI355X-native Gaussian rasterizer (gfx950, wave64).
 //
-//   k_render_bwd   one workgroup per 16x16 tile, back-to-front replay (backward.cu:415-601).
+//   k_render_bwd   one WAVE per (16x16 tile, 8x8 quadrant), back-to-front replay (backward.cu:415-601).
 //                  The reference issues 10 global float atomics per (pixel, Gaussian) hit; on
 //                  MI355X same-address device-scope atomics serialise at ~11 ns each, so instead
-//                  every wave reduces its 64 pixels with DPP (no LDS traffic), the 4 waves'
-//                  results meet in LDS, and ONE 48-byte partial record per (Gaussian, tile)
-//                  instance is written to HBM at the instance's slot in Gaussian order
-//                  (slot = point_offsets[id-1] + row-major index of the tile inside the rect).
-//   k_gather_bwd   per Gaussian: sums its contiguous run of partial records in a fixed order
+//                  every wave reduces its 64 pixels in registers and writes ONE 48-byte partial
+//                  sub-record per (Gaussian, tile, quadrant) it walked, at the instance's slot in
+//                  Gaussian order (slot = point_offsets[id-1] + row-major index of the tile inside
+//                  the rect; sub-slot = quadrant), flagged in a byte of pflags[instance].
+//   k_gather_bwd   per Gaussian: sums its contiguous run of flagged sub-records in a fixed order
 //                  (=> deterministic gradients, no atomics), then the reference's
 //                  computeCov2DCUDA (backward.cu:144-274), preprocessCUDA-bwd (:346-412),
 //                  SH bwd (:20-139) and cov3D bwd (:278-341) in one pass.
@@ -24,45 +24,91 @@ namespace gvd {
 
 constexpr int kNV = 10;  // reduced values per (Gaussian, tile)
 
-// DA: the caller supplied a gradient for the depth and / or the alpha image.  The usual training step differentiates the
-// colour image only (both pointers NULL); every depth / alpha term is then exactly zero and DA == false leaves those
-// recurrences and products out (about 9 of the ~80 instructions per entry; the depth gradient is written as +0).
-template <bool DA>
-__global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
-{
-    // per staged entry one 32-byte record {x, y, list position (bits), -, conic a b c, opacity}: one address (slot << 5) and two
-    // 16-byte reads per entry in the walk instead of three arrays with three strides
-    __shared__ float4 s_rec[2 * 256];
-    __shared__ float4 s_cd[256];
-    constexpr int NVS = DA ? kNV : kNV - 1;   // value 9 (the depth term) is exactly 0 without a depth gradient: not stored.
-    __shared__ float s_part[4][256][NVS];     // 36 KiB instead of 40: the workgroup's LDS drops under a third of the CU's 160 KiB (3 resident workgroups)
-    __shared__ uint32_t s_wcount[4];
-    __shared__ uint4 s_wcount4[4];
-    __shared__ __attribute__((aligned(4))) uint16_t s_list[4][260];  // per quadrant (= wave): slots of the entries that can reach it
-    __shared__ uint32_t s_max;
-    __shared__ uint32_t s_qmax[4];
+// experiments (tests/scripts/r5_bwd_trace.py): per-workgroup stamps of k_render_bwd -- s_memrealtime at entry / exit, XCC + HW ids,
+// the tile's walk length, and each wave's s_memtime cycles inside the walk.  Compiled only with -DGVD_RBWD_TRACE.
+#ifdef GVD_RBWD_TRACE
+__device__ unsigned long long g_rtrace[8192 * 8];
+#define GVD_RT(i, v) do { if (blockIdx.x < 8192) g_rtrace[blockIdx.x * 8 + (i)] = (v); } while (0)
+#else
+#define GVD_RT(i, v) do { } while (0)
+#endif
 
-    const int tile = (int)a.tile_order[blockIdx.x];
+// ------------------------------------------------------------------------------------------------
+// k_render_bwd: ONE WAVE PER (TILE, 8x8 QUADRANT), no workgroup barriers (round 5).
+//
+// The round-4 form ran a 256-thread workgroup per tile: cooperative staging of 256 list entries, four quadrant waves walking their
+// compacted lists, and the four waves' sums meeting in LDS -- three barriers per batch.  A per-workgroup trace of that kernel
+// (tests/scripts/r5_bwd_trace.py, profiles/r05_bwd_trace_*.txt) showed where its time went: wave 0 spends 63 % of the workgroup's
+// life in the walk, 9 % in staging and 23 % parked at the batch-end barrier waiting for the slowest quadrant (the quadrant lists of
+// a batch differ by ~25 %, and the wait repeats every batch), and the launch lasts as long as its longest tile (1100 entries,
+// ~0.17 us each under a three-way shared SIMD).  Here a wave owns its quadrant from the first list entry to the last:
+//   * it stages 64 entries per trip itself (lane = entry: id -> records, ONE rectangle test against its own quadrant, ballot
+//     compaction into its private LDS strip; the next trip's gathers are in flight during the walk), and only the list prefix in
+//     front of ITS last contributor (max n_contrib of its 64 pixels), not the tile's;
+//   * its per-entry sums go to a private sub-record: partials[(4 * instance + quadrant)] (48 bytes), flagged in pflags[instance]
+//     byte `quadrant`; k_gather_bwd adds the flagged sub-records in the fixed order instance-major, quadrant-minor, so the
+//     gradients stay bitwise deterministic without any cross-wave meeting point.  The forward's k_scatter zeroes the 4-byte flag
+//     words instead of the 48-byte records.
+// 4 T independent units instead of T workgroups: the dispatcher balances quadrants, nothing waits for a neighbour, and the LDS
+// footprint (6 KiB per wave, + 8 KiB for the turn-around strip) no longer limits occupancy.
+//
+// kRows == 0: per-pixel gradient terms + the DPP wave reduction of round 2 (wave_reduce20 / wave_reduce10).
+// kRows > 0 : the transposed turn-around.  The walk keeps only what is serial per pixel and leaves, per (entry, pixel),
+//     q = G * dL_dalpha   (backward.cu:577-598: every conic / mean / opacity term is q times a polynomial in (dx, dy))
+//     w = alpha * T       (backward.cu:520-537: dL_dcolor[c] = w * dL_dpixel[c])
+//   in a row of the wave's LDS strip; every kRows entries the wave turns around -- lane = (entry e, pixel group g) -- and each lane
+//   accumulates the moments sum q, q dx, q dy, q dx^2, q dx dy, q dy^2 and sum w dL_dpix[c] over its group's pixels in its own
+//   registers (13 VALU per pixel for kRows entries at once instead of 17 term + 25 reduction instructions per entry).
+// DA: the caller supplied a gradient for the depth and / or the alpha image (else those recurrences are compiled out).
+// ------------------------------------------------------------------------------------------------
+template <bool DA, int kRows>
+__global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
+{
+    static_assert(kRows == 0 || kRows == 8 || kRows == 16, "rows per turn-around");
+    constexpr int NVS = DA ? kNV : kNV - 1;   // value 9 (the depth term) is exactly 0 without a depth gradient
+    constexpr int kOutStride = NVS | 1;       // odd: conflict-free per-slot rows
+    constexpr int kStride = 65;               // float2 per strip row: 64 pixels + the row's slot id; 130 words = 2 (mod 32)
+    __shared__ float4 s_rec[2 * 64];          // per staged entry {x, y, list position (bits), -, conic a b c, opacity}
+    __shared__ float4 s_cd[64];
+    __shared__ float s_out[64][kOutStride];
+    __shared__ float2 s_qw[kRows ? kRows : 1][kStride];
+    __shared__ float4 s_dl[kRows ? 64 : 1];   // the wave's pixels' (dL_dpix rgb, dL_ddepth)
+
+    // unit -> (tile, quadrant): 32 consecutive units are 8 consecutive positions of tile_order x 4 quadrants, so that unit u and
+    // position p agree modulo 8 -- the XCD a workgroup lands on and the image region k_tilescan dealt to that position (its L2).
+    const uint32_t unit = blockIdx.x;
+    const uint32_t pos = (unit >> 5) * 8u + (unit & 7u);
+    const int quad = (int)((unit >> 3) & 3u);
+    if (pos >= (uint32_t)(a.gx * a.gy)) return;
+    const int tile = (int)a.tile_order[pos];
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int px = tx * 16 + (w & 1) * 8 + (lane & 7);      // wave w owns the 8x8 quadrant (w & 1, w >> 1): the per-wave
-    const int py = ty * 16 + (w >> 1) * 8 + (lane >> 3);    // skip of entries that reach none of its pixels fires more often
+    const int lane = threadIdx.x;
+    const int qx = tx * 16 + (quad & 1) * 8, qy = ty * 16 + (quad >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pixfx = (float)px, pixfy = (float)py;
-    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
+    const float qx0 = (float)qx, qy0 = (float)qy;
     const size_t pid = (size_t)py * a.W + px;
     const size_t HW = (size_t)a.H * a.W;
 
+#ifdef GVD_RBWD_TRACE
+    unsigned long long walk_cycles = 0, stage_cycles = 0, tail_cycles = 0;
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        GVD_RT(0, __builtin_amdgcn_s_memrealtime());
+        GVD_RT(2, ((unsigned long long)xcc << 32) | hwid);
+        GVD_RT(1, 0ull); GVD_RT(3, 0ull); GVD_RT(4, 0ull); GVD_RT(5, 0ull); GVD_RT(6, 0ull); GVD_RT(7, 0ull);
+    }
+#endif
     // A capped forward that overflowed left truncated lists and point_offsets that index past the partial buffer:
     // do nothing (k_gather_bwd then writes zero gradients); the overflow itself is reported through d_status.
     if (a.scalars[2]) return;
     const uint32_t r0 = a.ranges[2 * tile];
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;
-
-    if (tid == 0) s_max = 0;
-    __syncthreads();
 
     const float T_final = inside ? (1.f - a.alphas[pid]) : 0.f;
     float T = T_final;
@@ -75,122 +121,107 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
         if (DA && a.dL_dpix_depth) dLd = a.dL_dpix_depth[pid];  // NULL == all-zero gradient
         if (DA && a.dL_dalphas) dLa = a.dL_dalphas[pid];
     }
+    if (kRows) s_dl[lane] = make_float4(dLp0, dLp1, dLp2, dLd);
     float bg_dot = 0.f;  // backward.cu:575-577 accumulation order
     bg_dot += a.bg[0] * dLp0;
     bg_dot += a.bg[1] * dLp1;
     bg_dot += a.bg[2] * dLp2;
-
+    uint32_t n_walk;     // entries at or behind this list position contribute to no pixel of the quadrant
     {
         uint32_t m = last_contributor;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-        if (lane == 0) {
-            s_qmax[w] = m;   // entries at or behind this position contribute to no pixel of quadrant w
-            if (m) atomicMax(&s_max, m);
-        }
+        n_walk = min((uint32_t)__builtin_amdgcn_readfirstlane((int)m), r1 - r0);
     }
-    __syncthreads();
-    const uint32_t qmax0 = s_qmax[0], qmax1 = s_qmax[1], qmax2 = s_qmax[2], qmax3 = s_qmax[3];
-    const uint32_t tile_max = min(s_max, r1 - r0);
-    if (tile_max == 0) return;
-
+#ifdef GVD_RBWD_TRACE
+    if (lane == 0) { GVD_RT(3, (unsigned long long)n_walk | ((unsigned long long)(r1 - r0) << 32)); GVD_RT(4, __builtin_amdgcn_s_memtime() - tk0); }
+    if (n_walk == 0 && lane == 0) GVD_RT(1, __builtin_amdgcn_s_memrealtime());
+#endif
+    if (n_walk == 0) return;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_d = 0.f, acc_a = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
     const float nddelx_dx = -0.5f * a.W, nddely_dy = -0.5f * a.H;   // -(d delta / d mean2D): backward.cu:490-491
     const float nTf = -T_final;
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);  // wave-uniform (kernel argument)
+    const unsigned long long below = (1ull << lane) - 1ull;
 
-    for (uint32_t bdone = 0; bdone < tile_max; bdone += 256) {
-        // ---- stage (descending list order) + cull + compact ----
-        uint32_t smask = 0;
-        float2 xy;
-        float4 co, cd;
-        uint32_t id = 0, ord = 0;
-        if (bdone + tid < tile_max) {
-            ord = tile_max - 1 - bdone - tid;  // value of `contributor` after its decrement
-            id = a.point_list[r0 + ord];
-            xy = reinterpret_cast<const float2*>(a.means2D)[id];
-            co = reinterpret_cast<const float4*>(a.conic_opacity)[id];
-            cd = reinterpret_cast<const float4*>(a.rgbd)[id];
-            smask = quad_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
-            smask &= (ord < qmax0 ? 1u : 0u) | (ord < qmax1 ? 2u : 0u) | (ord < qmax2 ? 4u : 0u) | (ord < qmax3 ? 8u : 0u);
-        }
-        const bool keep = smask != 0;
-        {
-            float4* z = reinterpret_cast<float4*>(&s_part[0][0][0]);
-#pragma unroll
-            for (int i = 0; i < (4 * 256 * NVS / 4) / 256; i++) z[i * 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
+    // turn-around roles (kRows > 0): entry e of the strip, pixel group g (pixels g * kRows .. + kRows - 1 of the quadrant, lane order)
+    constexpr int kR = kRows ? kRows : 8;
+    const int te = lane & (kR - 1), tg = lane / kR;
+    const float gy0 = qy0 + (float)(tg * (kR / 8));   // first pixel row of this lane's group (kR / 8 rows per group)
+
+    // ---- the records of trip b + 64 are fetched while trip b is walked ----
+    uint32_t n_id = 0, n_ord = 0, n_poff = 0;
+    int n_rad = 0;
+    float2 n_xy = make_float2(0.f, 0.f);
+    float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = make_float4(0.f, 0.f, 0.f, 0.f);
+#define GVD_BWD_FETCH(BASE)                                                                       \
+    if ((BASE) + (uint32_t)lane < n_walk) {                                                       \
+        n_ord = n_walk - 1u - (BASE) - (uint32_t)lane;  /* value of `contributor` after its decrement */ \
+        n_id = a.point_list[r0 + n_ord];                                                          \
+        n_xy = reinterpret_cast<const float2*>(a.means2D)[n_id];                                  \
+        n_co = reinterpret_cast<const float4*>(a.conic_opacity)[n_id];                            \
+        n_cd = reinterpret_cast<const float4*>(a.rgbd)[n_id];                                     \
+        n_rad = a.radii[n_id];                                                                    \
+        n_poff = n_id ? a.point_offsets[n_id - 1] : 0u;                                           \
+    }
+    GVD_BWD_FETCH(0u)
+
+    for (uint32_t base = 0; base < n_walk; base += 64) {
+#ifdef GVD_RBWD_TRACE
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- stage (descending list order) + cull against this quadrant + compact ----
+        const bool valid = base + (uint32_t)lane < n_walk;
+        const uint32_t ord = n_ord, poff = n_poff;
+        const int rad = n_rad;
+        const float2 xy = n_xy;
+        const float4 co = n_co, cd = n_cd;
+        const bool keep = valid && rect_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, qx0, qy0, 7.0f, 7.0f);
+        GVD_BWD_FETCH(base + 64u)
         const unsigned long long m = __ballot(keep);
-        const unsigned long long m0 = __ballot(smask & 1u), m1 = __ballot(smask & 2u), m2 = __ballot(smask & 4u),
-                                 m3 = __ballot(smask & 8u);
-        if (lane == 0) {
-            s_wcount[w] = (uint32_t)__popcll(m);
-            s_wcount4[w] = make_uint4((uint32_t)__popcll(m0), (uint32_t)__popcll(m1), (uint32_t)__popcll(m2), (uint32_t)__popcll(m3));
-        }
-        __syncthreads();
-        uint32_t wbase = 0;
-        uint4 base = make_uint4(0, 0, 0, 0), tot = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t c = s_wcount[i];
-            const uint4 c4 = s_wcount4[i];
-            if (i < w) { wbase += c; base.x += c4.x; base.y += c4.y; base.z += c4.z; base.w += c4.w; }
-            tot.x += c4.x; tot.y += c4.y; tot.z += c4.z; tot.w += c4.w;
-        }
-        const uint32_t slot = wbase + (uint32_t)__popcll(m & below);
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t slot = (uint32_t)__popcll(m & below);
         if (keep) {
             s_rec[2 * slot] = make_float4(xy.x, xy.y, __uint_as_float(ord), 0.f);
             s_rec[2 * slot + 1] = co;
             s_cd[slot] = cd;
-            if (smask & 1u) s_list[0][base.x + (uint32_t)__popcll(m0 & below)] = (uint16_t)slot;
-            if (smask & 2u) s_list[1][base.y + (uint32_t)__popcll(m1 & below)] = (uint16_t)slot;
-            if (smask & 4u) s_list[2][base.z + (uint32_t)__popcll(m2 & below)] = (uint16_t)slot;
-            if (smask & 8u) s_list[3][base.w + (uint32_t)__popcll(m3 & below)] = (uint16_t)slot;
         }
-        // entries of the batch that can reach this wave's quadrant, walked in list order
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w == 0 ? tot.x : w == 1 ? tot.y : w == 2 ? tot.z : tot.w));
-        const uint32_t* my_list = reinterpret_cast<const uint32_t*>(s_list[w]);  // two 16-bit slots per word
-        __syncthreads();
+        unsigned long long done = 0ull;   // wave-uniform: slots whose entry had an active pixel (their s_out rows are written)
+#ifdef GVD_RBWD_TRACE
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+        stage_cycles += tw0 - ts0;
+#endif
 
-        // ---- per-pixel gradient terms, wave-reduced per Gaussian ----
-        // Two entries per trip: geometry (power, exp, alpha, 1/(1-alpha)) of both is independent of the
-        // per-pixel recurrences (T, accum_rec*, last_*), whose loop-carried part is one multiply/fma
-        // each; the bodies are predicated (no divergent branches) so the scheduler can overlap entry
-        // j+1's geometry with entry j's gradient terms and reduction.
 // 1 / (1 - alpha) for T / (1 - alpha) (backward.cu:510) and for the background term -T_final / (1 - alpha) * (bg . dL_dpix)
-// (backward.cu:575-577): v_rcp_f32 + one Newton step, 3 VALU, shared by both uses, instead of two 10-instruction IEEE
-// division sequences.  Measured against the oracle on the C2 scene the gradient errors are unchanged (dL_dscales
-// 5.9e-5 vs 6.0e-5 of the largest entry, bar 1e-4; tests/scripts/err_probe.py); the raw v_rcp_f32 (1 ulp) alone
-// doubled the dL_dscales error and was rejected.
+// (backward.cu:575-577): v_rcp_f32 + one Newton step, shared by both uses.  Measured against the oracle on the C2 scene the
+// gradient errors equal those of the IEEE division; the raw v_rcp_f32 (1 ulp) alone doubled the dL_dscales error and was rejected.
 #define GVD_BWD_RCP(D) ([&] { const float r0_ = __builtin_amdgcn_rcpf(D); return fmaf(fmaf(-(D), r0_, 1.0f), r0_, r0_); }())
-#define GVD_BWD_GEOM(J, DX, DY, G, ALPHA, ACT)                                                    \
-        const float4 gxy##J = s_rec[2 * sl##J];                                                   \
-        const float4 con##J = s_rec[2 * sl##J + 1];                                               \
+#define GVD_BWD_GEOM(J, SL)                                                                       \
+        const float4 gxy##J = s_rec[2 * (SL)];                                                    \
+        const float4 con##J = s_rec[2 * (SL) + 1];                                                \
         const uint32_t ord##J = __float_as_uint(gxy##J.z);                                        \
-        const float DX = gxy##J.x - pixfx, DY = gxy##J.y - pixfy;                                 \
-        const float pw##J = gauss_power(con##J.x, con##J.y, con##J.z, DX, DY);                    \
-        const float G = __expf(pw##J);                                                            \
-        const float ALPHA = fminf(0.99f, con##J.w * G);                                           \
-        const bool ACT = (ord##J < last_contributor) && !(pw##J > 0.0f) && !(ALPHA < 1.0f / 255.0f);  \
-        /* wave-level "any lane active": the AND of the three compares' lane masks (ballot of a plain compare IS its SGPR   \
-           mask; __any / ballot of the combined bool goes through v_cndmask 0/1 + v_cmp_ne) */                            \
-        const bool any##J = (__builtin_amdgcn_ballot_w64(ord##J < last_contributor) &                                     \
-                             __builtin_amdgcn_ballot_w64(!(pw##J > 0.0f)) & __builtin_amdgcn_ballot_w64(!(ALPHA < 1.0f / 255.0f))) != 0ull;
-// Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the value the next
-// active entry would have formed (pushing (last_alpha=0, .) is the identity: fmaf(1, acc, 0*c) == acc
-// bit-exactly) and all ten terms are exactly 0 -- no per-variable selects needed.
-#define GVD_BWD_TERMS(J, DX, DY, G, ALPHA, ACT, V)                                                \
-        float V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9;                         \
+        const float dx##J = gxy##J.x - pixfx, dy##J = gxy##J.y - pixfy;                           \
+        const float pw##J = gauss_power(con##J.x, con##J.y, con##J.z, dx##J, dy##J);              \
+        const float G##J = __expf(pw##J);                                                         \
+        const float alpha##J = fminf(0.99f, con##J.w * G##J);                                     \
+        const bool act##J = (ord##J < last_contributor) && !(pw##J > 0.0f) && !(alpha##J < 1.0f / 255.0f);  \
+        /* wave-level "any lane active": the AND of the three compares' lane masks */             \
+        const bool any##J = (__builtin_amdgcn_ballot_w64(ord##J < last_contributor) &             \
+                             __builtin_amdgcn_ballot_w64(!(pw##J > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha##J < 1.0f / 255.0f))) != 0ull;
+// The serial part.  Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the value the next
+// active entry would have formed (fmaf(1, acc, 0 * c) == acc bit-exactly) and every term is exactly 0.
+// Leaves dopa##J = dL_dalpha (x T, + background term) and wgt##J = alpha * T.
+#define GVD_BWD_SERIAL(J, SL)                                                                     \
+        const float4 c##J = s_cd[SL];                                                             \
+        const float am##J = act##J ? alpha##J : 0.f;                                              \
+        const float gm##J = act##J ? G##J : 0.f;                                                  \
+        float dopa##J, wgt##J;                                                                    \
         {                                                                                         \
-            const float4 c = s_cd[sl##J];                                                         \
-            const float am = ACT ? ALPHA : 0.f;                                                   \
-            const float gm = ACT ? G : 0.f;                                                       \
-            const float one_m_a = 1.f - am;                                                       \
+            const float one_m_a = 1.f - am##J;                                                    \
             const float rinv = GVD_BWD_RCP(one_m_a);                                              \
             T = T * rinv;                                                                         \
-            const float dchannel_dcolor = am * T;                                                 \
+            wgt##J = am##J * T;                                                                   \
             const float oml = 1.f - last_alpha;                                                   \
             acc0 = fmaf(oml, acc0, last_alpha * lc0);                                             \
             acc1 = fmaf(oml, acc1, last_alpha * lc1);                                             \
@@ -199,106 +230,178 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
                 acc_d = fmaf(oml, acc_d, last_alpha * last_depth);                                \
                 acc_a = fmaf(oml, acc_a, last_alpha);                                             \
             }                                                                                     \
-            float dL_dopa = (c.x - acc0) * dLp0;                                                  \
-            dL_dopa = fmaf(c.y - acc1, dLp1, dL_dopa);                                            \
-            dL_dopa = fmaf(c.z - acc2, dLp2, dL_dopa);                                            \
+            float d_ = (c##J.x - acc0) * dLp0;                                                    \
+            d_ = fmaf(c##J.y - acc1, dLp1, d_);                                                   \
+            d_ = fmaf(c##J.z - acc2, dLp2, d_);                                                   \
             if (DA) {                                                                             \
-                dL_dopa = fmaf(c.w - acc_d, dLd, dL_dopa);                                        \
-                dL_dopa = fmaf(1.f - acc_a, dLa, dL_dopa);                                        \
+                d_ = fmaf(c##J.w - acc_d, dLd, d_);                                               \
+                d_ = fmaf(1.f - acc_a, dLa, d_);                                                  \
             }                                                                                     \
-            dL_dopa *= T;                                                                         \
+            d_ *= T;                                                                              \
             if (BG) { /* (-T_final / (1 - alpha)) * (bg . dL_dpix): quotient refined by one residual step */ \
                 float qb = nTf * rinv;                                                            \
                 qb = fmaf(fmaf(-one_m_a, qb, nTf), rinv, qb);                                     \
-                dL_dopa = fmaf(qb, bg_dot, dL_dopa);                                              \
+                d_ = fmaf(qb, bg_dot, d_);                                                        \
             }                                                                                     \
-            lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
-            /* dL_dG * G and its products with the offset polynomials, formed from q = o * G * dL_dalpha once */   \
-            V##5 = gm * dL_dopa;                                                                  \
-            const float q = con##J.w * V##5;                                                      \
-            const float u = fmaf(con##J.y, DY, con##J.x * DX);                                    \
-            const float v = fmaf(con##J.y, DX, con##J.z * DY);                                    \
-            V##0 = (q * nddelx_dx) * u;                                                           \
-            V##1 = (q * nddely_dy) * v;                                                           \
-            const float h = -0.5f * q;                                                            \
-            const float hx = h * DX, hy = h * DY;                                                 \
-            V##2 = hx * DX;                                                                       \
-            V##3 = hx * DY;                                                                       \
-            V##4 = hy * DY;                                                                       \
-            V##6 = dchannel_dcolor * dLp0;                                                        \
-            V##7 = dchannel_dcolor * dLp1;                                                        \
-            V##8 = dchannel_dcolor * dLp2;                                                        \
-            V##9 = DA ? dchannel_dcolor * dLd : 0.f;                                              \
+            dopa##J = d_;                                                                         \
+            lc0 = c##J.x; lc1 = c##J.y; lc2 = c##J.z; last_depth = c##J.w; last_alpha = am##J;    \
         }
-#define GVD_BWD_STORE10(J, V)                                                                     \
+// kRows == 0: the ten per-pixel terms of entry J (V##0..9), formed from q = o * G * dL_dalpha once
+#define GVD_BWD_TERMS(J, V)                                                                       \
+        float V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9;                         \
+        {                                                                                         \
+            V##5 = gm##J * dopa##J;                                                               \
+            const float q_ = con##J.w * V##5;                                                     \
+            const float u_ = fmaf(con##J.y, dy##J, con##J.x * dx##J);                             \
+            const float v_ = fmaf(con##J.y, dx##J, con##J.z * dy##J);                             \
+            V##0 = (q_ * nddelx_dx) * u_;                                                         \
+            V##1 = (q_ * nddely_dy) * v_;                                                         \
+            const float h_ = -0.5f * q_;                                                          \
+            const float hx_ = h_ * dx##J, hy_ = h_ * dy##J;                                       \
+            V##2 = hx_ * dx##J;                                                                   \
+            V##3 = hx_ * dy##J;                                                                   \
+            V##4 = hy_ * dy##J;                                                                   \
+            V##6 = wgt##J * dLp0;                                                                 \
+            V##7 = wgt##J * dLp1;                                                                 \
+            V##8 = wgt##J * dLp2;                                                                 \
+            V##9 = DA ? wgt##J * dLd : 0.f;                                                       \
+        }
+#define GVD_BWD_STORE10(SL, V)                                                                    \
         wave_reduce10(V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9);                \
         if ((lane & 31) == 31) {                                                                  \
-            float* o = &s_part[w][sl##J][(lane >> 5) * 5];                                        \
+            float* o = &s_out[SL][(lane >> 5) * 5];                                               \
             o[0] = V##0; o[1] = V##1; o[2] = V##2; o[3] = V##3;                                   \
             if (DA || lane < 32) o[4] = V##4;                                                     \
         }
-        // The walk is instantiated twice, with and without the background term (6 VALU instructions per entry that are
-        // exactly zero for the black background of train_guidedvd.py:301): one wave-uniform branch per batch picks.
-        auto walk = [&](auto bg_tag) {
-#pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
-            constexpr bool BG = decltype(bg_tag)::value;
-            uint32_t j = 0;
-            uint32_t pair = my_list[0];   // slots of entries j, j+1 (prefetched one trip ahead; the list is padded)
-            for (; j + 2 <= n; j += 2) {
-                const uint32_t sl0 = pair & 0xffffu, sl1 = pair >> 16;
-                pair = my_list[(j >> 1) + 1];
-                GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
-                GVD_BWD_GEOM(1, dx1, dy1, G1, alpha1, act1)
-                if (any0 && any1) {
-                    GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
-                    GVD_BWD_TERMS(1, dx1, dy1, G1, alpha1, act1, q)
-                    wave_reduce20(p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, q0, q1, q2, q3, q4, q5, q6, q7, q8, q9);
-                    if ((lane & 15) == 15) {  // row 0: A[0..4], row 1: B[0..4], row 2: A[5..9], row 3: B[5..9]
-                        float* o = &s_part[w][(lane & 16) ? sl1 : sl0][(lane >> 5) * 5];
-                        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3;
-                        if (DA || lane < 32) o[4] = p4;
-                    }
-                } else if (any0) {
-                    GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
-                    GVD_BWD_STORE10(0, p)
-                } else if (any1) {
-                    GVD_BWD_TERMS(1, dx1, dy1, G1, alpha1, act1, q)
-                    GVD_BWD_STORE10(1, q)
+// kRows > 0: entry J's row of the strip
+#define GVD_BWD_ROW(J, SL)                                                                        \
+        {                                                                                         \
+            float2* row = &s_qw[rows][0];                                                         \
+            row[lane] = make_float2(gm##J * dopa##J, wgt##J);                                     \
+            if (lane == 0) row[64] = make_float2(__uint_as_float(SL), 0.f);                       \
+            rows++;                                                                               \
+        }
+        // ---- the turn-around: rows [0, nrows) of the strip -> s_out[slot][0..NVS) ----
+        auto flush = [&](const uint32_t nrows) {
+#pragma clang fp contract(fast)
+            if ((uint32_t)te < nrows) {
+                const float2* row = &s_qw[te][0];
+                const uint32_t sl = __float_as_uint(row[64].x);
+                const float4 g0 = s_rec[2 * sl];
+                const float gxr = g0.x - qx0, gyr = g0.y - gy0;
+                const float2* qp = row + tg * kR;
+                const float4* dp = &s_dl[tg * kR];
+                float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, S6 = 0.f, S7 = 0.f, S8 = 0.f, S9 = 0.f;
+#pragma unroll
+                for (int t = 0; t < kR; t++) {
+                    const float2 qw = qp[t];
+                    const float4 dl = dp[t];
+                    const float dx = gxr - (float)(t & 7), dy = gyr - (float)(t >> 3);
+                    const float qdx = qw.x * dx, qdy = qw.x * dy;
+                    S0 += qw.x; S1 += qdx; S2 += qdy;
+                    S3 = fmaf(qdx, dx, S3); S4 = fmaf(qdx, dy, S4); S5 = fmaf(qdy, dy, S5);
+                    S6 = fmaf(qw.y, dl.x, S6); S7 = fmaf(qw.y, dl.y, S7); S8 = fmaf(qw.y, dl.z, S8);
+                    if (DA) S9 = fmaf(qw.y, dl.w, S9);
                 }
-            }
-            if (j < n) {
-                const uint32_t sl0 = pair & 0xffffu;
-                GVD_BWD_GEOM(0, dx0, dy0, G0, alpha0, act0)
-                if (any0) {
-                    GVD_BWD_TERMS(0, dx0, dy0, G0, alpha0, act0, p)
-                    GVD_BWD_STORE10(0, p)
+#pragma unroll
+                for (int msk = kR; msk < 64; msk <<= 1) {
+                    S0 += __shfl_xor(S0, msk, 64); S1 += __shfl_xor(S1, msk, 64); S2 += __shfl_xor(S2, msk, 64);
+                    S3 += __shfl_xor(S3, msk, 64); S4 += __shfl_xor(S4, msk, 64); S5 += __shfl_xor(S5, msk, 64);
+                    S6 += __shfl_xor(S6, msk, 64); S7 += __shfl_xor(S7, msk, 64); S8 += __shfl_xor(S8, msk, 64);
+                    if (DA) S9 += __shfl_xor(S9, msk, 64);
+                }
+                if (tg == 0) {
+                    const float4 con = s_rec[2 * sl + 1];
+                    const float ox = con.w * nddelx_dx, oy = con.w * nddely_dy, oh = -0.5f * con.w;
+                    float* o = &s_out[sl][0];
+                    o[0] = ox * fmaf(con.y, S2, con.x * S1);   // sum (o q) (-0.5 W) (a dx + b dy)
+                    o[1] = oy * fmaf(con.y, S1, con.z * S2);
+                    o[2] = oh * S3;
+                    o[3] = oh * S4;
+                    o[4] = oh * S5;
+                    o[5] = S0;
+                    o[6] = S6; o[7] = S7; o[8] = S8;
+                    if (DA) o[9] = S9;
                 }
             }
         };
+        // The walk is instantiated twice, with and without the background term (6 VALU instructions per entry that are
+        // exactly zero for the black background of train_guidedvd.py:301): one wave-uniform branch per trip picks.
+        auto walk = [&](auto bg_tag) {
+#pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
+            constexpr bool BG = decltype(bg_tag)::value;
+            uint32_t rows = 0;   // wave-uniform: filled rows of the strip (kRows > 0)
+            uint32_t j = 0;
+            for (; j + 2 <= n; j += 2) {
+                GVD_BWD_GEOM(0, j)
+                GVD_BWD_GEOM(1, j + 1)
+                if (kRows) {
+                    if (any0) { GVD_BWD_SERIAL(0, j) GVD_BWD_ROW(0, j) done |= 1ull << j; }
+                    if (any1) { GVD_BWD_SERIAL(1, j + 1) GVD_BWD_ROW(1, j + 1) done |= 2ull << j; }
+                    if (rows >= (uint32_t)kR - 1u) { flush(rows); rows = 0; }
+                } else if (any0 && any1) {
+                    GVD_BWD_SERIAL(0, j) GVD_BWD_TERMS(0, p)
+                    GVD_BWD_SERIAL(1, j + 1) GVD_BWD_TERMS(1, q)
+                    wave_reduce20(p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, q0, q1, q2, q3, q4, q5, q6, q7, q8, q9);
+                    if ((lane & 15) == 15) {  // row 0: A[0..4], row 1: B[0..4], row 2: A[5..9], row 3: B[5..9]
+                        float* o = &s_out[j + ((lane >> 4) & 1)][(lane >> 5) * 5];
+                        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3;
+                        if (DA || lane < 32) o[4] = p4;
+                    }
+                    done |= 3ull << j;
+                } else if (any0) {
+                    GVD_BWD_SERIAL(0, j) GVD_BWD_TERMS(0, p)
+                    GVD_BWD_STORE10(j, p)
+                    done |= 1ull << j;
+                } else if (any1) {
+                    GVD_BWD_SERIAL(1, j + 1) GVD_BWD_TERMS(1, q)
+                    GVD_BWD_STORE10(j + 1, q)
+                    done |= 2ull << j;
+                }
+            }
+            if (j < n) {
+                GVD_BWD_GEOM(0, j)
+                if (any0) {
+                    GVD_BWD_SERIAL(0, j)
+                    if (kRows) { GVD_BWD_ROW(0, j) } else { GVD_BWD_TERMS(0, p) GVD_BWD_STORE10(j, p) }
+                    done |= 1ull << j;
+                }
+            }
+            if (kRows && rows) flush(rows);
+        };
         if (has_bg) walk(std::true_type{});
         else walk(std::false_type{});
+#undef GVD_BWD_ROW
 #undef GVD_BWD_STORE10
-#undef GVD_BWD_GEOM
 #undef GVD_BWD_TERMS
-        __syncthreads();
+#undef GVD_BWD_SERIAL
+#undef GVD_BWD_GEOM
+#undef GVD_BWD_RCP
+#ifdef GVD_RBWD_TRACE
+        const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+        walk_cycles += tw1 - tw0;
+#endif
 
-        // ---- one partial record per kept (Gaussian, tile) instance, at its Gaussian-order slot ----
-        if (keep) {
-            const int4 r = get_rect(xy.x, xy.y, a.radii[id], a.gx, a.gy);
+        // ---- one sub-record per walked (Gaussian, tile, quadrant), at the instance's Gaussian-order slot ----
+        if (keep && ((done >> slot) & 1ull)) {
+            const int4 r = get_rect(xy.x, xy.y, rad, a.gx, a.gy);
             const uint32_t k = (uint32_t)((ty - r.y) * (r.z - r.x) + (tx - r.x));
-            const uint32_t g = (id ? a.point_offsets[id - 1] : 0u) + k;
-            float o[kNV];
-#pragma unroll
-            for (int q = 0; q < NVS; q++)
-                o[q] = ((s_part[0][slot][q] + s_part[1][slot][q]) + s_part[2][slot][q]) + s_part[3][slot][q];
-            if (!DA) o[kNV - 1] = 0.f;
-            float4* dst = reinterpret_cast<float4*>(a.partials + (size_t)g * kPartialStride);
+            const uint32_t g = poff + k;
+            const float* o = &s_out[slot][0];
+            float4* dst = reinterpret_cast<float4*>(a.partials + ((size_t)g * 4 + quad) * kPartialStride);
             dst[0] = make_float4(o[0], o[1], o[2], o[3]);
             dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-            dst[2] = make_float4(o[8], o[9], 0.f, 0.f);
+            dst[2] = make_float4(o[8], DA ? o[NVS - 1] : 0.f, 0.f, 0.f);
+            reinterpret_cast<uint8_t*>(a.pflags)[(size_t)g * 4 + quad] = 1;
         }
-        __syncthreads();
+#ifdef GVD_RBWD_TRACE
+        tail_cycles += __builtin_amdgcn_s_memtime() - tw1;
+#endif
     }
+#undef GVD_BWD_FETCH
+#ifdef GVD_RBWD_TRACE
+    if (lane == 0) { GVD_RT(5, stage_cycles); GVD_RT(6, walk_cycles); GVD_RT(7, tail_cycles); GVD_RT(1, __builtin_amdgcn_s_memrealtime()); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -307,35 +410,39 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a)
 // Gaussian's row of the block's LDS tile and receives only the FACTORS (kShW + k: w_k, kShRGB + c: dRGB[c], kShConf,
 // kShCount: number of basis functions of the active degree); k_gather_bwd expands them when it streams the tile out.
 constexpr int kShW = 0, kShRGB = 16, kShConf = 19, kShCount = 20, kShRow = 21;
-template <bool STAGED>
-__device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int idx, float* dsh)
+// Sums of one Gaussian's flagged sub-records of quadrant column q (fixed instance order; two instances' loads in flight).
+__device__ __forceinline__ void gather_column(const GatherBwdArgs& a, const uint32_t beg, const uint32_t end, const int q, float* s)
 {
-    const bool visible = a.radii[idx] > 0 && a.scalars[2] == 0;  // overflowed forward: all-zero gradients
-    float s[kNV];
+    for (uint32_t g = beg; g < end; g += 2) {
+        const bool two = g + 1 < end;
+        const uint32_t f0 = a.pflags[g], f1 = two ? a.pflags[g + 1] : 0u;
+        const bool h0 = (f0 >> (8 * q)) & 0xffu, h1 = (f1 >> (8 * q)) & 0xffu;
+        float4 r[2][3];
 #pragma unroll
-    for (int q = 0; q < kNV; q++) s[q] = 0.f;
-    if (visible) {
-        const uint32_t beg = idx ? a.point_offsets[idx - 1] : 0u;
-        const uint32_t end = a.point_offsets[idx];
-        // four records' loads in flight per trip (the run is a chain of dependent round trips otherwise); the additions
-        // stay in record order, so the sums are bit-identical to the one-at-a-time loop
-        for (uint32_t g = beg; g < end; g += 4) {
-            float4 r[4][3];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4* rec = reinterpret_cast<const float4*>(a.partials + (size_t)min(g + j, end - 1) * kPartialStride);
+        for (int j = 0; j < 2; j++) {
+            if (j ? h1 : h0) {
+                const float4* rec = reinterpret_cast<const float4*>(a.partials + ((size_t)(g + j) * 4 + q) * kPartialStride);
                 r[j][0] = rec[0]; r[j][1] = rec[1]; r[j][2] = rec[2];
+            } else {
+                r[j][0] = r[j][1] = r[j][2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (g + j < end) {
-                    s[0] += r[j][0].x; s[1] += r[j][0].y; s[2] += r[j][0].z; s[3] += r[j][0].w;
-                    s[4] += r[j][1].x; s[5] += r[j][1].y; s[6] += r[j][1].z; s[7] += r[j][1].w;
-                    s[8] += r[j][2].x; s[9] += r[j][2].y;
-                }
+        for (int j = 0; j < 2; j++) {
+            if (j ? h1 : h0) {
+                s[0] += r[j][0].x; s[1] += r[j][0].y; s[2] += r[j][0].z; s[3] += r[j][0].w;
+                s[4] += r[j][1].x; s[5] += r[j][1].y; s[6] += r[j][1].z; s[7] += r[j][1].w;
+                s[8] += r[j][2].x; s[9] += r[j][2].y;
             }
         }
     }
+}
+
+// `s`: the Gaussian's ten per-pixel-sum totals (k_gather_bwd's first phase).
+template <bool STAGED>
+__device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int idx, const float* __restrict__ s, float* dsh)
+{
+    const bool visible = a.radii[idx] > 0 && a.scalars[2] == 0;  // overflowed forward: all-zero gradients
     // Optional per-Gaussian confidence (the fork's Python-side scaling, ref __init__.py:147-157, folded
     // in): every returned gradient except the screen-space one is multiplied by conf AFTER it has been
     // formed exactly as without confidence (x * 1.0f == x, so conf == NULL and conf == 1 agree bitwise).
@@ -592,28 +699,59 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
     }
 }
 
-// dL_dsh is 48 floats (192 B) per Gaussian: written per thread it is a 192-byte-stride scatter (64 cache
-// lines per store instruction).  Instead each thread drops the 21 factors of its row into an LDS tile (odd row stride:
-// conflict-free) and the block expands and streams the tile out as contiguous float4 (1 KiB per wave store).  Staging the
-// factors instead of the 48 products keeps the tile at 21 KiB, so the kernel's occupancy is set by its registers (6
-// workgroups per CU) and not by LDS (3 with a 48-float row): the kernel is a stream of dependent global reads and lives on
-// the number of waves in flight.
+// A workgroup handles kGatherG = 64 consecutive Gaussians in two phases.
+//   Phase 1, four lanes per Gaussian: lane q adds the Gaussian's flagged sub-records of quadrant column q over its contiguous run
+//   of instances (a quad reads one instance's 192 contiguous bytes together), then the four columns meet as (q0 + q1) + (q2 + q3)
+//   -- a fixed order, so the totals are bit-identical from run to run; they go to LDS.
+//   Phase 2, one lane per Gaussian (wave 0): computeCov2D / preprocess / SH / cov3D backward on the totals.
+// dL_dsh is 48 floats (192 B) per Gaussian: written per thread it is a 192-byte-stride scatter (64 cache lines per store
+// instruction).  Instead each Gaussian drops the 21 factors of its row into an LDS tile (odd row stride: conflict-free) and the
+// block expands and streams the tile out as contiguous float4 (1 KiB per wave store).
+constexpr int kGatherG = 64;
 __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
 {
-    extern __shared__ float s_sh[];  // [256][kShRow] when M == 16 (launch passes the size), else unused
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ float s_sh[];  // [kGatherG][kShRow] when M == 16 (launch passes the size), else unused
+    __shared__ float s_sum[kGatherG][kNV + 1];
+    const int tid = threadIdx.x;
+    {
+        const int q = tid & 3, gi = tid >> 2;
+        const int idx = blockIdx.x * kGatherG + gi;
+        float s[kNV];
+#pragma unroll
+        for (int v = 0; v < kNV; v++) s[v] = 0.f;
+        if (idx < a.P && a.radii[idx] > 0 && a.scalars[2] == 0) {
+            const uint32_t beg = idx ? a.point_offsets[idx - 1] : 0u;
+            const uint32_t end = a.point_offsets[idx];
+            gather_column(a, beg, end, q, s);
+        }
+#pragma unroll
+        for (int v = 0; v < kNV; v++) {
+            float t = s[v];
+            t += __shfl_xor(t, 1, 64);   // (q0 + q1) | (q2 + q3)
+            t += __shfl_xor(t, 2, 64);   // the same two numbers added in either order: one value in all four lanes
+            s[v] = t;
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int v = 0; v < kNV; v++) s_sum[gi][v] = s[v];
+        }
+    }
+    __syncthreads();
     const bool stage_sh = (a.M == 16);
-    if (idx < a.P) {
-        if (stage_sh) gather_body<true>(a, idx, s_sh + threadIdx.x * kShRow);
-        else gather_body<false>(a, idx, a.dL_dsh + (size_t)idx * a.M * 3);
+    if (tid < kGatherG) {
+        const int idx = blockIdx.x * kGatherG + tid;
+        if (idx < a.P) {
+            if (stage_sh) gather_body<true>(a, idx, &s_sum[tid][0], s_sh + tid * kShRow);
+            else gather_body<false>(a, idx, &s_sum[tid][0], a.dL_dsh + (size_t)idx * a.M * 3);
+        }
     }
     if (stage_sh) {
         __syncthreads();
-        const size_t block_base = (size_t)blockIdx.x * 256 * 48;
+        const size_t block_base = (size_t)blockIdx.x * kGatherG * 48;
         const size_t total = (size_t)a.P * 48;
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
-            const int i = (k * 256 + (int)threadIdx.x) * 4;  // float index inside the block's 256x48 tile
+        for (int k = 0; k < kGatherG * 48 / 4 / 256; k++) {
+            const int i = (k * 256 + tid) * 4;  // float index inside the block's kGatherG x 48 tile
             if (block_base + i < total) {
                 const int g = i / 48, c = i - g * 48;
                 const float* r = s_sh + g * kShRow;
@@ -640,17 +778,32 @@ __global__ void __launch_bounds__(256) k_scale_cov(int n, float* __restrict__ dL
 
 void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 {
-    // Extra (unused) dynamic LDS lowers the resident workgroups per CU: occupancy experiments only.
-    static const size_t pad = getenv("GVD_BWD_LDS_PAD") ? (size_t)atol(getenv("GVD_BWD_LDS_PAD")) : 0;
-    if (a.dL_dpix_depth || a.dL_dalphas) hipLaunchKernelGGL(k_render_bwd<true>, dim3(T), dim3(256), pad, s, a);
-    else hipLaunchKernelGGL(k_render_bwd<false>, dim3(T), dim3(256), pad, s, a);
+    // A/B switch (round 5): 1 = transposed turn-around, 16 rows (shipped: 113 us on the C2 view); 2 = 8 rows (134 us);
+    // 0 = per-pixel terms + DPP wave reduction (141 us)
+    static const int variant = getenv("GVD_BWD_VARIANT") ? atoi(getenv("GVD_BWD_VARIANT")) : 1;
+    const bool da = a.dL_dpix_depth || a.dL_dalphas;
+    const int units = ((T + 7) / 8) * 32;   // (tile, quadrant) units, one wave each
+#define GVD_LAUNCH(K) hipLaunchKernelGGL(K, dim3(units), dim3(64), 0, s, a)
+    switch (variant) {
+    case 0: if (da) GVD_LAUNCH((k_render_bwd<true, 0>)); else GVD_LAUNCH((k_render_bwd<false, 0>)); break;
+    case 2: if (da) GVD_LAUNCH((k_render_bwd<true, 8>)); else GVD_LAUNCH((k_render_bwd<false, 8>)); break;
+    default: if (da) GVD_LAUNCH((k_render_bwd<true, 16>)); else GVD_LAUNCH((k_render_bwd<false, 16>)); break;
+    }
+#undef GVD_LAUNCH
 }
 void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + 255) / 256), dim3(256), a.M == 16 ? (size_t)256 * kShRow * 4 : 0, s, a);
+    hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + kGatherG - 1) / kGatherG), dim3(256), a.M == 16 ? (size_t)kGatherG * kShRow * 4 : 0, s, a);
     // only needed when the caller consumes dL_dcov3D (precomputed-covariance path)
     if (a.confidence && !a.has_scales)
         hipLaunchKernelGGL(k_scale_cov, dim3((a.P * 6 + 255) / 256), dim3(256), 0, s, a.P * 6, a.dL_dcov3D, a.confidence);
 }
 
 }  // namespace gvd
+
+#ifdef GVD_RBWD_TRACE
+extern "C" int gvd_debug_rtrace_read(unsigned long long* dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gvd::g_rtrace), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -396,14 +396,13 @@ __global__ void __launch_bounds__(256) k_scatter(ScatterArgs a)
         }
         __syncthreads();
     }
-    // The block's instances are the contiguous slots [chunk_base, carry) of the backward's partial-record array
-    // (Gaussian order): zero them here, coalesced and under this kernel's atomic latency, instead of a 21 MB memset
-    // launch at the head of every backward.  k_render_bwd overwrites the records of the instances it reaches.
-    if (a.partials) {
+    // The block's instances are the contiguous slots [chunk_base, carry) of the backward's partial-record arrays (Gaussian
+    // order).  k_render_bwd's quadrant waves write the sub-records they reach and flag them; only the 4-byte flag words are
+    // cleared here (coalesced, under this kernel's atomic latency) -- no memset launch at the head of every backward, and since
+    // round 5 no 48-byte-per-instance zeroing either.
+    if (a.pflags) {
         const uint32_t beg = min(a.chunk_base[blockIdx.x], a.capacity), end = min(carry, a.capacity);
-        float4* z = reinterpret_cast<float4*>(a.partials);
-        for (size_t i = (size_t)beg * (kPartialStride / 4) + tid; i < (size_t)end * (kPartialStride / 4); i += 256)
-            z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t i = beg + tid; i < end; i += 256) a.pflags[i] = 0u;
     }
 }
 

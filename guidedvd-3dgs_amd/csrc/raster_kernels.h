@@ -33,7 +33,7 @@ struct ScatterArgs {
     const int* radii;
     uint32_t *cursor, *point_offsets;
     uint64_t* bucket;
-    float* partials;   // backward's partial records (kPartialStride floats per instance), zeroed per block; NULL: leave alone
+    uint32_t* pflags;  // backward's per-instance sub-record flags (4 bytes per instance), zeroed per block; NULL: leave alone
 };
 
 struct SortArgs {
@@ -65,7 +65,8 @@ struct RenderBwdArgs {
     const int* radii;
     const float *means2D, *conic_opacity, *rgbd, *bg, *alphas;
     const float *dL_dpix, *dL_dpix_depth, *dL_dalphas;
-    float* partials;  // [R][12]
+    float* partials;  // [R][4 quadrants][12]
+    uint32_t* pflags; // [R]: byte q set = sub-record (instance, q) written
 };
 
 struct GatherBwdArgs {
@@ -75,6 +76,7 @@ struct GatherBwdArgs {
     const int* radii;
     const uint32_t *clamped, *point_offsets, *scalars;
     const float* partials;
+    const uint32_t* pflags;
     const float* confidence;  // [P] or NULL
     int has_sh, has_scales;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_ddepth;

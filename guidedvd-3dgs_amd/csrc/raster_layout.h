@@ -10,7 +10,7 @@ namespace gvd {
 constexpr size_t kAlign = 128;
 constexpr int kMaxLdsHistTiles = 12288;  // 48 KiB of LDS tile counters per binning block
 constexpr int kMaxBinBlocks = 1024;
-constexpr int kPartialStride = 12;       // floats per (Gaussian,tile) backward partial record
+constexpr int kPartialStride = 12;       // floats per (Gaussian, tile, quadrant) backward partial sub-record (4 per instance)
 
 struct Layout {
     int P, W, H, gx, gy, T;
@@ -25,7 +25,7 @@ struct Layout {
     size_t ranges, n_contrib, tile_order;
     size_t img_bytes;
     // binning chunk (depends on capacity R)
-    size_t keys, point_list, bucket, partials;
+    size_t keys, point_list, bucket, pflags, partials;
     size_t bin_bytes;
 };
 
@@ -76,7 +76,8 @@ inline Layout make_layout(int P, int W, int H, uint32_t R)
     L.keys = carve(c, Rz * 8);
     L.point_list = carve(c, Rz * 4);
     L.bucket = carve(c, Rz * 8);
-    L.partials = carve(c, Rz * kPartialStride * 4);
+    L.pflags = carve(c, Rz * 4);                          // byte q: quadrant q of the instance wrote its sub-record
+    L.partials = carve(c, Rz * 4 * kPartialStride * 4);
     L.bin_bytes = c + kAlign;
     return L;
 }

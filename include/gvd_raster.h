@@ -94,14 +94,15 @@ int gvd_raster_forward(
  * gvd_raster_binning_capacity inverts gvd_raster_binning_bytes (0xffffffff if `bytes` is not a chunk size). */
 void gvd_raster_set_speculation(int on);
 
-/* Forward -> backward contract of the binning chunk (MI355X addition).  The backward's per-instance partial records live in
- * the binning chunk and are ZEROED BY THE FORWARD (its scatter kernel writes capacity x 48 bytes under its own latency, instead
- * of a memset launch at the head of every backward).  gvd_raster_backward(_conf) therefore requires the binning chunk exactly as
- * the forward left it -- bytes may be copied / offloaded / restored, but not modified -- and consumes it: a second backward on
- * the same chunk needs a fresh forward.  A caller that will NOT run a backward on the chunks of its next forwards (no-grad /
- * evaluation renders) may say so with gvd_raster_expect_backward(0): the zeroing stores are skipped (~21 MB per render at
- * 200k Gaussians) and a backward on such a chunk is undefined.  Per host thread, sticky until changed; default 1 (the
- * reference's contract: any forward may be followed by a backward). */
+/* Forward -> backward contract of the binning chunk (MI355X addition).  The backward's partial records live in the binning
+ * chunk: four 48-byte sub-records per (Gaussian, tile) instance -- one per 8x8 quadrant wave of k_render_bwd -- and one 4-byte
+ * flag word per instance that says which of them were written.  The FLAG WORDS ARE CLEARED BY THE FORWARD (its scatter kernel
+ * writes capacity x 4 bytes under its own latency, instead of a memset launch at the head of every backward).
+ * gvd_raster_backward(_conf) therefore requires the binning chunk as the forward left it -- bytes may be copied / offloaded /
+ * restored, but not modified.  A caller that will NOT run a backward on the chunks of its next forwards (no-grad / evaluation
+ * renders) may say so with gvd_raster_expect_backward(0): the clearing stores are skipped and a backward on such a chunk is
+ * undefined.  Per host thread, sticky until changed; default 1 (the reference's contract: any forward may be followed by a
+ * backward). */
 void gvd_raster_expect_backward(int yes);
 uint32_t gvd_raster_binning_capacity(size_t binning_chunk_bytes);
 
