@@ -315,7 +315,7 @@ def raster_run(args, dev, rank, world):
     torch.cuda.synchronize()
     L.gvd_profile_enable(0)
     kern = {}
-    for name in ("preprocess", "colscan", "tilescan", "scatter", "sort_tiles", "render_fwd", "render_bwd", "gather_bwd"):
+    for name in ("preprocess", "colscan", "tilescan", "scatter", "sort_tiles", "render_fwd", "render_bwd", "combine_bwd", "gather_bwd"):
         ms, n = ctypes.c_double(0), ctypes.c_int(0)
         L.gvd_profile_read(name.encode(), ctypes.byref(ms), ctypes.byref(n))
         if n.value:

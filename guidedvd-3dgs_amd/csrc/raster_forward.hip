@@ -533,43 +533,45 @@ __global__ void __launch_bounds__(CLASS == 0 ? 256 : 1024) k_sort_tiles(SortArgs
 
 // ------------------------------------------------------------------------------------------------
 // k_render_fwd: one workgroup (4 waves) per 16x16 tile; wave w owns the 8x8 pixel quadrant (w & 1, w >> 1).
-// The workgroup first sorts the tile's list (merge_sort_u64; lists over kFusedSortMax arrive sorted).
-// Per batch of 256 list entries: each thread fetches one entry (id -> xy, conic/opacity, rgb+depth),
-// runs the conservative test against each of the four quadrants, and the survivors are compacted into one
-// LDS list PER QUADRANT with wave ballots + prefixes (order preserved, original list position kept for
-// n_contrib): a wave only walks the entries that can reach its own 64 pixels.  Every pixel then walks its
-// quadrant's batch from LDS (broadcast reads) with the reference's exact per-pixel sequence (forward.cu:329-368).
+// The workgroup first sorts the tile's list together (merge_sort_u64; lists over kFusedSortMax arrive sorted) -- the only
+// cooperative phase.  After it THE FOUR WAVES RUN INDEPENDENTLY (round 5; the round-4 form staged 256 entries per batch together
+// and met at two barriers per batch, so every batch lasted as long as its slowest quadrant -- the k_render_bwd trace of round 5
+// priced that wait at ~a quarter of a workgroup's life): per trip of 64 list entries each lane fetches one entry
+// (id -> xy, conic/opacity, rgb+depth; the next trip's gathers are in flight during the blend), runs the conservative test
+// against the wave's OWN quadrant, and the survivors are compacted into the wave's private LDS list with one ballot + prefix
+// (order preserved, original list position kept for n_contrib).  Every pixel then walks that list from LDS (broadcast reads)
+// with the reference's exact per-pixel sequence (forward.cu:329-368).  A wave stops as soon as ITS 64 pixels are finished.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
 {
-    __shared__ float2 s_xy4[4][256];   // one compacted list per quadrant (= per wave)
-    __shared__ float4 s_co4[4][256];
-    __shared__ float4 s_cd4[4][256];
-    __shared__ uint32_t s_pos4[4][256];
-    __shared__ uint4 s_wcount[4];
+    __shared__ float2 s_xy4[4][64];   // one compacted list per quadrant (= per wave)
+    __shared__ float4 s_co4[4][64];
+    __shared__ float4 s_cd4[4][64];
+    __shared__ uint32_t s_pos4[4][64];
 
     const int tile = (int)a.tile_order[blockIdx.x];
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const int px = tx * 16 + (w & 1) * 8 + (lane & 7);      // wave w owns the 8x8 quadrant (w & 1, w >> 1)
-    const int py = ty * 16 + (w >> 1) * 8 + (lane >> 3);
+    const int qx = tx * 16 + (w & 1) * 8, qy = ty * 16 + (w >> 1) * 8;   // wave w owns the 8x8 quadrant (w & 1, w >> 1)
+    const int px = qx + (lane & 7);
+    const int py = qy + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pixfx = (float)px, pixfy = (float)py;
-    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
+    const float qx0 = (float)qx, qy0 = (float)qy;
 
     const uint32_t r0 = a.ranges[2 * tile];
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;  // overflowed forward: render background, status already flagged
+    const uint32_t n = r1 - r0;
 
     // ---- fused per-tile sort (the k_sort_tiles<0> work, done by the workgroup that consumes the list) ----
-    // A separate sort launch lasts as long as its longest list (a chain of ~60 barrier-separated LDS stages) while most
+    // A separate sort launch lasts as long as its longest list (a chain of barrier-separated LDS stages) while most
     // of the GPU idles; here that chain overlaps with the other tiles' blending.
     extern __shared__ uint64_t s_sort_lds[];   // 2 x kFusedSortMax entries (+ the occupancy pad)
     uint64_t* s_sorted = s_sort_lds;
-    const bool sorted_here = a.fused_sort && (r1 - r0) <= kFusedSortMax;
-    if (sorted_here && r1 > r0) {
-        const uint32_t n = r1 - r0;
+    const bool sorted_here = a.fused_sort && n <= kFusedSortMax;
+    if (sorted_here && n) {
         uint64_t* g = a.bucket + r0;
         for (uint32_t i = tid; i < n; i += 256) s_sorted[i] = g[i];
         __syncthreads();
@@ -582,62 +584,44 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
             a.keys[r0 + i] = thi | (e >> 32);
         }
     }
+    // ---- from here on no workgroup barrier: each wave blends its quadrant on its own ----
 
     float T = inside ? 1.0f : 0.0f, T_keep = 1.0f;   // live transmittance (0 = pixel finished) / value kept for the background
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    float2* const s_xy = s_xy4[w];
+    float4* const s_co = s_co4[w];
+    float4* const s_cd = s_cd4[w];
+    uint32_t* const s_pos = s_pos4[w];
 
-    // The records of batch b + 256 are fetched while batch b is blended (the gather id -> means2D / conic / colour is
+    // The records of trip b + 64 are fetched while trip b is blended (the gather id -> means2D / conic / colour is
     // two dependent trips to L2 that would otherwise sit between two blend loops).
     float2 nxy = make_float2(0.f, 0.f);
     float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), ncd = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GVD_FETCH(E)                                                                              \
-        if ((E) < r1) {                                                                           \
-            const uint32_t id = sorted_here ? (uint32_t)s_sorted[(E) - r0] : a.point_list[E];     \
+        if ((E) < n) {                                                                            \
+            const uint32_t id = sorted_here ? (uint32_t)s_sorted[E] : a.point_list[r0 + (E)];     \
             nxy = reinterpret_cast<const float2*>(a.means2D)[id];                                 \
             nco = reinterpret_cast<const float4*>(a.conic_opacity)[id];                           \
             ncd = reinterpret_cast<const float4*>(a.rgbd)[id];                                    \
         }
-    GVD_FETCH(r0 + tid)
-    for (uint32_t b = r0; b < r1; b += 256) {
-        const int num_done = __syncthreads_count(T == 0.0f);
-        if (num_done == 256) break;
-        // ---- stage + cull per quadrant + compact into the four quadrant lists ----
-        const uint32_t e = b + tid;
-        uint32_t smask = 0;
+    GVD_FETCH((uint32_t)lane)
+    for (uint32_t b = 0; b < n; b += 64) {
+        if (__builtin_amdgcn_ballot_w64(T != 0.0f) == 0ull) break;  // wave-uniform: this quadrant is finished
+        // ---- stage + cull against this quadrant + compact ----
+        const uint32_t e = b + (uint32_t)lane;
         const float2 xy = nxy;
         const float4 co = nco, cd = ncd;
-        if (e < r1) smask = quad_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, x0, y0);
-        GVD_FETCH(e + 256)
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const unsigned long long m0 = __ballot(smask & 1u), m1 = __ballot(smask & 2u), m2 = __ballot(smask & 4u),
-                                 m3 = __ballot(smask & 8u);
-        if (lane == 0) s_wcount[w] = make_uint4((uint32_t)__popcll(m0), (uint32_t)__popcll(m1), (uint32_t)__popcll(m2), (uint32_t)__popcll(m3));
-        __syncthreads();
-        uint4 base = make_uint4(0, 0, 0, 0), tot = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint4 c = s_wcount[i];
-            if (i < w) { base.x += c.x; base.y += c.y; base.z += c.z; base.w += c.w; }
-            tot.x += c.x; tot.y += c.y; tot.z += c.z; tot.w += c.w;
+        const bool keep = e < n && rect_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, qx0, qy0, 7.0f, 7.0f);
+        GVD_FETCH(e + 64u)
+        const unsigned long long m = __ballot(keep);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (keep) {
+            const uint32_t slot = (uint32_t)__popcll(m & below);
+            s_xy[slot] = xy; s_co[slot] = co; s_cd[slot] = cd;
+            s_pos[slot] = e + 1;  // value of `contributor` when this entry is visited
         }
-        const uint32_t pos_e = e - r0 + 1;  // value of `contributor` when this entry is visited
-#define GVD_PUT(S, M, B)                                                                          \
-        if (smask & (1u << S)) {                                                                  \
-            const uint32_t slot = (B) + (uint32_t)__popcll((M) & below);                          \
-            s_xy4[S][slot] = xy; s_co4[S][slot] = co; s_cd4[S][slot] = cd; s_pos4[S][slot] = pos_e; \
-        }
-        GVD_PUT(0, m0, base.x)
-        GVD_PUT(1, m1, base.y)
-        GVD_PUT(2, m2, base.z)
-        GVD_PUT(3, m3, base.w)
-#undef GVD_PUT
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w == 0 ? tot.x : w == 1 ? tot.y : w == 2 ? tot.z : tot.w));
-        const float2* s_xy = s_xy4[w];
-        const float4* s_co = s_co4[w];
-        const float4* s_cd = s_cd4[w];
-        const uint32_t* s_pos = s_pos4[w];
-        __syncthreads();
         // ---- blend ----
         // Branch-free, 4 entries per trip: the per-entry geometry (power, exp, alpha) of the 4 entries
         // is independent work the scheduler can overlap with the LDS latency, and only the short
@@ -670,7 +654,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
             last_contributor = (go && hit) ? (POS) : last_contributor;                            \
         }
         uint32_t j = 0;
-        for (; j + 4 <= n; j += 4) {
+        for (; j + 4 <= cnt; j += 4) {
             if (__builtin_amdgcn_ballot_w64(T != 0.0f) == 0ull) break;  // wave-uniform: this quadrant is finished
             const float2 xy0 = s_xy[j], xy1 = s_xy[j + 1], xy2 = s_xy[j + 2], xy3 = s_xy[j + 3];
             const float4 co0 = s_co[j], co1 = s_co[j + 1], co2 = s_co[j + 2], co3 = s_co[j + 3];
@@ -681,7 +665,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
             GVD_BLEND_ONE(xy2, co2, cd2, p2)
             GVD_BLEND_ONE(xy3, co3, cd3, p3)
         }
-        for (; j < n; j++) {
+        for (; j < cnt; j++) {
             const float2 xy0 = s_xy[j];
             const float4 co0 = s_co[j];
             const float4 cd0 = s_cd[j];
