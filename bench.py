@@ -254,7 +254,12 @@ def raster_run(args, dev, rank, world):
     # N > 1: the headline is the per-camera sharding of the path itself (no collective); the width-2 training step with its
     # gradient all-reduce is measured right after and reported next to it.
     reduce_grads = False
-    elapsed = timed_region(args.warmup, args.steps, True)
+    # The timed region carries NO instrumentation (round 5): the per-kernel HIP event pairs the roofline needs -- two event records
+    # per bracketed launch, each a barrier packet in the stream -- are recorded in an instrumented pass of the same K steps right
+    # after it, in the same process on the same inputs (as the `ddim` object has done since round 3).  Round 4 bracketed the two
+    # blend kernels inside the timed region: 26 us of the 375 us step the driver timed were those four packets.
+    elapsed = timed_region(args.warmup, args.steps, False)
+    elapsed_instr = timed_region(2, args.steps, True)
     # the K-step region above is short (the driver passes --steps 20: ~7 ms); next to it, the rate over a >= 1 s window
     sustained = None
     if world == 1:
@@ -427,6 +432,10 @@ def raster_run(args, dev, rank, world):
                        f"per-camera shards: {world} ranks, each rasterizes its own cameras forward + backward on a replica of the "
                        "Gaussians (no data-path collective)"},
             "sustained": sustained,
+            "instrumented_pass": {"ms_per_step": round(1e3 * elapsed_instr / args.steps, 4), "steps": args.steps,
+                                  "what": "the same K steps again with HIP event pairs around k_render_fwd / k_render_bwd on the launch stream "
+                                          "(gvd_profile level 1): where roofline.avg_us comes from; the timed region above carries none"},
+            "step_minus_kernel_sum_us": round(1e6 * elapsed / args.steps - sum(v["avg_us"] for v in kern.values()), 1) if world == 1 else None,
             "headline": "`value` = the K timed steps the bench contract asks for (20 steps = 7 ms at the driver's flags: host-jitter bound); "
                         "`sustained` = the same loop over a >= 1 s window, the steadier figure",
             "two_view_step": two_view,

@@ -79,10 +79,10 @@ struct ProfScope {
 };
 
 // Host-side state of a forward call, one slot per (host thread, device): the host-visible mirror of {num_rendered, max tile
-// list} that k_tilescan writes and the host reads after its wait, and the event that marks the end of stage 1.  Nothing here
+// list, ticket} that the tile scan writes and the host reads after its wait, and the ticket counter of the slot.  Nothing here
 // is shared between threads or devices, so concurrent forwards on different streams / devices cannot read each other's R
-// (the C-ABI only forbids re-entrancy on ONE stream).  Slots live as long as their thread (64 pinned bytes + one event).
-struct HostSlot { uint32_t* mirror = nullptr; hipEvent_t ev = nullptr; };
+// (the C-ABI only forbids re-entrancy on ONE stream).  Slots live as long as their thread (64 pinned bytes).
+struct HostSlot { uint32_t* mirror = nullptr; uint32_t ticket = 0; };
 HostSlot* host_slot()
 {
     int dev = 0;
@@ -94,7 +94,6 @@ HostSlot* host_slot()
         if (hipHostMalloc((void**)&s.mirror, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { s.mirror = nullptr; return nullptr; }
         memset((void*)s.mirror, 0, 64);
     }
-    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) s.ev = nullptr;   // created on `dev`
     return &s;
 }
 
@@ -162,8 +161,11 @@ struct FwdIn {
     int* radii;
 };
 
+// Stage 1: preprocess + column scan (+ the tile scan as its own launch when `scan_launch`; otherwise *ts_out is handed to the
+// scatter launch, which then carries the scan: forward_stage2 with fused_scan).
 int forward_stage1(const FwdIn& in, const gvd::Layout& L, char* geom, char* img, uint32_t capacity,
-                   int32_t* d_status, volatile uint32_t* mirror, hipStream_t stream)
+                   int32_t* d_status, volatile uint32_t* mirror, uint32_t ticket, bool scan_launch, gvd::TileScanArgs* ts_out,
+                   hipStream_t stream)
 {
     using namespace gvd;
     const int debug = in.debug;
@@ -199,12 +201,14 @@ int forward_stage1(const FwdIn& in, const gvd::Layout& L, char* geom, char* img,
     ta.tile_order = (uint32_t*)(img + L.tile_order);
     ta.d_status = d_status;
     ta.host_mirror = mirror;
+    ta.ticket = ticket;
     if (L.lds_hist) {
         ProfScope ps("colscan", stream);
         launch_colscan((uint32_t*)(geom + L.hist), tile_count, L.bin_blocks, L.T, stream);
     }
     AFTER_LAUNCH("colscan");
-    {
+    if (ts_out) *ts_out = ta;
+    if (scan_launch) {
         ProfScope ps("tilescan", stream);
         launch_tilescan(ta, stream);
     }
@@ -213,7 +217,7 @@ int forward_stage1(const FwdIn& in, const gvd::Layout& L, char* geom, char* img,
 }
 
 int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin, char* img, uint32_t capacity,
-                   int max_class, hipStream_t stream)
+                   int max_class, const gvd::TileScanArgs* fused_scan, hipStream_t stream)
 {
     using namespace gvd;
     const int debug = in.debug;
@@ -229,7 +233,7 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     sa.pflags = t_expect_backward ? (uint32_t*)(bin + L.pflags) : nullptr;
     {
         ProfScope ps("scatter", stream);
-        launch_scatter(sa, L.bin_blocks, L.lds_hist != 0, stream);
+        launch_scatter(sa, fused_scan, L.bin_blocks, L.lds_hist != 0, stream);
     }
     AFTER_LAUNCH("scatter");
     SortArgs so{};
@@ -344,20 +348,35 @@ int gvd_raster_forward(
     volatile uint32_t* mirror = slot->mirror;
     SpecHint hint;
     if (spec_enabled() && spec_lookup(P, width, height, &hint) && hint.r_max > 0 && hint.r_max < 0x60000000u) {
-        hipEvent_t ev = slot->ev;
-        if (ev) {
+        {
             const uint32_t cap = hint.r_max + hint.r_max / 8 + 4096;
             const int class_spec = sort_class_of(hint.list_max + hint.list_max / 4);
             gvd::Layout Ls = gvd::make_layout(P, width, height, cap);
             char* bin_s = binning_alloc(binning_user, Ls.bin_bytes);
             if (!bin_s) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
             bin_s = align_up(bin_s);
-            rc = forward_stage1(in, Ls, geom, img, cap, nullptr, mirror, stream);
+            // the scatter launch carries the tile scan (one launch less in front of the blend); the host then waits for the
+            // ticket the scan writes next to {num_rendered, max list} in the pinned mirror -- a spin on host memory instead of
+            // an event: the wake-up does not wait for the end of the launch, let alone a completion signal
+            const bool fuse = Ls.lds_hist != 0;
+            const uint32_t ticket = ++slot->ticket;
+            gvd::TileScanArgs ts{};
+            rc = forward_stage1(in, Ls, geom, img, cap, nullptr, mirror, ticket, !fuse, &ts, stream);
             if (rc != GVD_OK) return rc;
-            HIP_TRY(hipEventRecord(ev, stream));
-            rc = forward_stage2(in, Ls, geom, bin_s, img, cap, class_spec, stream);
+            rc = forward_stage2(in, Ls, geom, bin_s, img, cap, class_spec, fuse ? &ts : nullptr, stream);
             if (rc != GVD_OK) return rc;
-            HIP_TRY(hipEventSynchronize(ev));   // stage 1 only: stage 2 keeps running while the host returns
+            {
+                unsigned long long spins = 0;
+                while (mirror[2] != ticket) {
+                    __builtin_ia32_pause();
+                    if ((++spins & 0xfffffull) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {   // ~every few ms: the stream died or drained
+                        if (mirror[2] == ticket) break;
+                        HIP_TRY(hipStreamSynchronize(stream));
+                        if (mirror[2] != ticket) return fail(GVD_ERR_HIP, "tile scan finished without publishing num_rendered");
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
             const uint32_t Rs = mirror[0], max_list_s = mirror[1];
             if (Rs > 0x7fffffffu) return fail(GVD_ERR_OVERFLOW, "num_rendered exceeds int32");
             spec_update(P, width, height, Rs, max_list_s);
@@ -365,7 +384,7 @@ int gvd_raster_forward(
             // guessed too small: fall through and run the exact path (stage 1 again, with no capacity limit)
         }
     }
-    rc = forward_stage1(in, L, geom, img, 0xffffffffu, nullptr, mirror, stream);
+    rc = forward_stage1(in, L, geom, img, 0xffffffffu, nullptr, mirror, ++slot->ticket, true, nullptr, stream);
     if (rc != GVD_OK) return rc;
     // the one host sync of the forward (reference: cudaMemcpy at rasterizer_impl.cu:282)
     HIP_TRY(hipStreamSynchronize(stream));
@@ -378,7 +397,7 @@ int gvd_raster_forward(
     if (!bin) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
     bin = align_up(bin);
     const int max_class = sort_class_of(max_list);
-    rc = forward_stage2(in, L, geom, bin, img, R, max_class, stream);
+    rc = forward_stage2(in, L, geom, bin, img, R, max_class, nullptr, stream);
     if (rc != GVD_OK) return rc;
     return (int)R;
 }
@@ -407,9 +426,11 @@ int gvd_raster_forward_capped(
     char* geom = align_up(geometry_chunk);
     char* img = align_up(image_chunk);
     char* bin = align_up(binning_chunk);
-    rc = forward_stage1(in, L, geom, img, capacity, d_status, nullptr, stream);
+    const bool fuse = L.lds_hist != 0;
+    gvd::TileScanArgs ts{};
+    rc = forward_stage1(in, L, geom, img, capacity, d_status, nullptr, 0, !fuse, &ts, stream);
     if (rc != GVD_OK) return rc;
-    return forward_stage2(in, L, geom, bin, img, capacity, 2, stream);
+    return forward_stage2(in, L, geom, bin, img, capacity, 2, fuse ? &ts : nullptr, stream);
 }
 
 int gvd_raster_backward_conf(

@@ -201,14 +201,16 @@ __global__ void __launch_bounds__(1024) k_colscan(uint32_t* __restrict__ hist, u
 // ------------------------------------------------------------------------------------------------
 // k_tilescan: single block (1024 threads).  ranges, num_rendered, max list length, chunk_base.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w /*16*/, uint32_t* total)
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w /*NT / 64*/, uint32_t* total)
 {
     const uint32_t incl = wave_incl_scan_u32(v);
     const int w = threadIdx.x >> 6;
     if (lane_id() == 63) s_w[w] = incl;
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
-    for (int i = 0; i < 16; i++) {
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
         const uint32_t x = s_w[i];
         if (i < w) wbase += x;
         tot += x;
@@ -237,24 +239,25 @@ __device__ __forceinline__ int xcd_region(int t, int gx)
     return ((tx >> 1) + 3 * (ty >> 1)) & 7;
 }
 
+template <int NT>
 __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
 {
-    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_w[NT / 64];
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_bins[8][256];   // per XCD region: tiles per cost bucket, then running output ranks
     __shared__ uint32_t s_rcount[8];
     const int tid = threadIdx.x;
     if (tid == 0) s_max = 0;
-    for (int i = tid; i < 8 * 256; i += 1024) (&s_bins[0][0])[i] = 0;
+    for (int i = tid; i < 8 * 256; i += NT) (&s_bins[0][0])[i] = 0;
     __syncthreads();
     // ---- tiles ----
     // Every global value this block needs is fetched once, up front and together (one round trip; the kernel is a single
     // workgroup, so each dependent trip to memory is ~1 us of GPU idle time); up to kKeep tile counts per thread stay in
     // registers, larger images re-read them (L2 hits).
-    constexpr int kKeep = 4;
-    const int per = (a.T + 1023) / 1024;
+    constexpr int kKeep = NT >= 1024 ? 4 : 8;
+    const int per = (a.T + NT - 1) / NT;
     const int t0 = tid * per, t1 = min(a.T, t0 + per);
-    const int perb = (a.B + 1023) / 1024;
+    const int perb = (a.B + NT - 1) / NT;
     const int b0 = tid * perb, b1 = min(a.B, b0 + perb);
     uint32_t kept[kKeep];
 #pragma unroll
@@ -274,7 +277,7 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
         lmax = max(lmax, c);
     }
     uint32_t total;
-    uint32_t run = block_excl_scan_1024(local, s_w, &total);
+    uint32_t run = block_excl_scan<NT>(local, s_w, &total);
 #pragma unroll 4
     for (int t = t0, i = 0; t < t1; t++, i++) {
         const uint32_t c = GVD_TILE_COUNT(t, i);
@@ -296,15 +299,15 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
     __syncthreads();
     {
         const int w = tid >> 6, lane = tid & 63;
-        if (w < 8) {   // wave w: exclusive scan of region w's 256 buckets (4 per lane)
+        for (int rg = w; rg < 8; rg += NT / 64) {   // a wave per region: exclusive scan of the region's 256 buckets (4 per lane)
             uint32_t v[4], sum = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { v[i] = s_bins[w][4 * lane + i]; sum += v[i]; }
+            for (int i = 0; i < 4; i++) { v[i] = s_bins[rg][4 * lane + i]; sum += v[i]; }
             const uint32_t incl = wave_incl_scan_u32(sum);
             uint32_t run = incl - sum;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { s_bins[w][4 * lane + i] = run; run += v[i]; }
-            if (lane == 63) s_rcount[w] = incl;
+            for (int i = 0; i < 4; i++) { s_bins[rg][4 * lane + i] = run; run += v[i]; }
+            if (lane == 63) s_rcount[rg] = incl;
         }
         __syncthreads();
         uint32_t cmin = 0xffffffffu;
@@ -327,7 +330,7 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
 #undef GVD_TILE_COUNT
     // ---- per-block instance bases (exclusive scan of block_total) ----
     uint32_t totb;
-    uint32_t runb = block_excl_scan_1024(lb, s_w, &totb);
+    uint32_t runb = block_excl_scan<NT>(lb, s_w, &totb);
     for (int b = b0; b < b1; b++) {
         a.chunk_base[b] = runb;
         runb += (b == b0) ? first_bt : a.block_total[b];
@@ -338,11 +341,16 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
         a.scalars[1] = s_max;  // longest tile list
         a.scalars[2] = (total > a.capacity) ? 1u : 0u;
         if (a.d_status) *a.d_status = (total > a.capacity) ? -4 : 0;
-        if (a.host_mirror) { a.host_mirror[0] = total; a.host_mirror[1] = s_max; }
+        if (a.host_mirror) {
+            // the host spins on word 2 (capi.hip): data first, then the ticket, each a system-scope store to pinned memory
+            a.host_mirror[0] = total; a.host_mirror[1] = s_max;
+            __threadfence_system();
+            a.host_mirror[2] = a.ticket;
+        }
     }
 }
 
-__global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a) { tilescan_body(a); }
+__global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a) { tilescan_body<1024>(a); }
 
 // (A merged k_colscan + k_tilescan launch -- the last column-scan workgroup to arrive, by an agent-scope fence and a
 // counter, runs the tile scan -- was measured at 61 us against 8.6 + 12.3 us for the two launches: on a multi-XCD part the
@@ -351,19 +359,57 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a) { tilescan_bo
 // ------------------------------------------------------------------------------------------------
 // k_scatter
 // ------------------------------------------------------------------------------------------------
-template <bool LDS_HIST>
-__global__ void __launch_bounds__(256) k_scatter(ScatterArgs a)
+// FUSED (round 5; LDS_HIST only): the launch carries the tile scan.  Workgroup 0 runs tilescan_body (ranges, tile_order,
+// num_rendered, the host mirror) for the kernels that follow; every scatter workgroup derives what IT needs from the same two
+// small arrays itself -- the exclusive scan of the T tile totals (its LDS cursors) and the sum of the block totals in front of it
+// (its instance base) -- 6 KB of L2 reads and one extra barrier per workgroup instead of a single-workgroup k_tilescan launch
+// (12 us of dependent round trips on one CU + a launch boundary) between k_colscan and k_scatter.
+template <bool LDS_HIST, bool FUSED>
+__global__ void __launch_bounds__(256) k_scatter(ScatterArgs a, TileScanArgs ts)
 {
     extern __shared__ uint32_t s_cur[];  // T cursors (LDS_HIST)
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_bw[4];
     const int tid = threadIdx.x;
-    if (LDS_HIST) {
-        const uint32_t* row = a.hist + (size_t)blockIdx.x * a.T;
+    if (FUSED && blockIdx.x == 0) {
+        tilescan_body<256>(ts);
+        return;
+    }
+    const int blk = FUSED ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    uint32_t my_base = 0;
+    if (LDS_HIST && FUSED) {
+        const uint32_t* row = a.hist + (size_t)blk * a.T;
+        const int per = (a.T + 255) / 256;
+        const int t0 = tid * per, t1 = min(a.T, t0 + per);
+        uint32_t local = 0;
+        for (int t = t0; t < t1; t++) local += ts.tile_count[t];
+        uint32_t lb = 0;
+        for (int b = tid; b < blk; b += 256) lb += ts.block_total[b];
+        const uint32_t incl = wave_incl_scan_u32(local);
+        lb = wave_sum_u32(lb);
+        const int w = tid >> 6;
+        if (lane_id() == 63) s_w[w] = incl;
+        if (lane_id() == 0) s_bw[w] = lb;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < w) wbase += s_w[i];
+            my_base += s_bw[i];
+        }
+        uint32_t run = wbase + incl - local;
+        for (int t = t0; t < t1; t++) {
+            s_cur[t] = run + row[t];
+            run += ts.tile_count[t];
+        }
+    } else if (LDS_HIST) {
+        const uint32_t* row = a.hist + (size_t)blk * a.T;
         for (int t = tid; t < a.T; t += 256) s_cur[t] = a.ranges[2 * t] + row[t];
     }
     __syncthreads();
-    uint32_t carry = a.chunk_base[blockIdx.x];
-    const int base = blockIdx.x * a.items_per_block;
+    const uint32_t first = FUSED ? my_base : a.chunk_base[blk];
+    uint32_t carry = first;
+    const int base = blk * a.items_per_block;
     for (int it = 0; it < a.items_per_block; it += 256) {
         if (base + it >= a.P) break;  // uniform
         const int idx = base + it + tid;
@@ -401,7 +447,7 @@ __global__ void __launch_bounds__(256) k_scatter(ScatterArgs a)
     // cleared here (coalesced, under this kernel's atomic latency) -- no memset launch at the head of every backward, and since
     // round 5 no 48-byte-per-instance zeroing either.
     if (a.pflags) {
-        const uint32_t beg = min(a.chunk_base[blockIdx.x], a.capacity), end = min(carry, a.capacity);
+        const uint32_t beg = min(first, a.capacity), end = min(carry, a.capacity);
         for (uint32_t i = beg + tid; i < end; i += 256) a.pflags[i] = 0u;
     }
 }
@@ -714,10 +760,13 @@ void launch_tilescan(const TileScanArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, a);
 }
-void launch_scatter(const ScatterArgs& a, int blocks, bool lds_hist, hipStream_t s)
+void launch_scatter(const ScatterArgs& a, const TileScanArgs* fused_scan, int blocks, bool lds_hist, hipStream_t s)
 {
-    if (lds_hist) hipLaunchKernelGGL(k_scatter<true>, dim3(blocks), dim3(256), (size_t)a.T * 4, s, a);
-    else hipLaunchKernelGGL(k_scatter<false>, dim3(blocks), dim3(256), 0, s, a);
+    TileScanArgs ts{};
+    if (fused_scan) ts = *fused_scan;
+    if (lds_hist && fused_scan) hipLaunchKernelGGL((k_scatter<true, true>), dim3(blocks + 1), dim3(256), (size_t)a.T * 4, s, a, ts);
+    else if (lds_hist) hipLaunchKernelGGL((k_scatter<true, false>), dim3(blocks), dim3(256), (size_t)a.T * 4, s, a, ts);
+    else hipLaunchKernelGGL((k_scatter<false, false>), dim3(blocks), dim3(256), 0, s, a, ts);
 }
 void launch_sort_tiles(const SortArgs& a, int T, int max_class, bool short_lists_too, hipStream_t s)
 {

@@ -23,6 +23,7 @@ struct TileScanArgs {
     uint32_t *ranges, *cursor, *chunk_base, *scalars, *tile_order;
     int32_t* d_status;
     volatile uint32_t* host_mirror;
+    uint32_t ticket;   // written to host_mirror[2] after the data words: the host waits for it
 };
 
 struct ScatterArgs {
@@ -86,7 +87,7 @@ struct GatherBwdArgs {
 void launch_preprocess(const PreprocessArgs& a, int blocks, bool lds_hist, hipStream_t s);
 void launch_colscan(uint32_t* hist, uint32_t* tile_count, int B, int T, hipStream_t s);
 void launch_tilescan(const TileScanArgs& a, hipStream_t s);
-void launch_scatter(const ScatterArgs& a, int blocks, bool lds_hist, hipStream_t s);
+void launch_scatter(const ScatterArgs& a, const TileScanArgs* fused_scan, int blocks, bool lds_hist, hipStream_t s);   // fused_scan: the launch also runs the tile scan (lds_hist only)
 void launch_sort_tiles(const SortArgs& a, int T, int max_class, bool short_lists_too, hipStream_t s);
 constexpr uint32_t kFusedSortMax = 2048;  // longest list a blend workgroup sorts itself (16 KiB of LDS)
 void launch_render_fwd(const RenderArgs& a, int T, hipStream_t s);
