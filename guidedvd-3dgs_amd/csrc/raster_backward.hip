@@ -410,26 +410,28 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
 // Gaussian's row of the block's LDS tile and receives only the FACTORS (kShW + k: w_k, kShRGB + c: dRGB[c], kShConf,
 // kShCount: number of basis functions of the active degree); k_gather_bwd expands them when it streams the tile out.
 constexpr int kShW = 0, kShRGB = 16, kShConf = 19, kShCount = 20, kShRow = 21;
-// Sums of one Gaussian's flagged sub-records of quadrant column q (fixed instance order; two instances' loads in flight).
+// Sums of one Gaussian's flagged sub-records of quadrant column q (fixed instance order).  Called by the four lanes of a quad
+// together: per trip the quad fetches the flag words of four instances (lane j loads instance g + j's word, the quad exchanges
+// them), then every lane has its column's up to four sub-records in flight at once -- one round trip for the flags and one for
+// the records per four instances.
 __device__ __forceinline__ void gather_column(const GatherBwdArgs& a, const uint32_t beg, const uint32_t end, const int q, float* s)
 {
-    for (uint32_t g = beg; g < end; g += 2) {
-        const bool two = g + 1 < end;
-        const uint32_t f0 = a.pflags[g], f1 = two ? a.pflags[g + 1] : 0u;
-        const bool h0 = (f0 >> (8 * q)) & 0xffu, h1 = (f1 >> (8 * q)) & 0xffu;
-        float4 r[2][3];
+    for (uint32_t g = beg; g < end; g += 4) {
+        const uint32_t mine = (g + (uint32_t)q < end) ? a.pflags[g + q] : 0u;
+        uint32_t f[4];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            if (j ? h1 : h0) {
+        for (int j = 0; j < 4; j++) f[j] = (uint32_t)__shfl((int)mine, j, 4);
+        float4 r[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((f[j] >> (8 * q)) & 0xffu) {
                 const float4* rec = reinterpret_cast<const float4*>(a.partials + ((size_t)(g + j) * 4 + q) * kPartialStride);
                 r[j][0] = rec[0]; r[j][1] = rec[1]; r[j][2] = rec[2];
-            } else {
-                r[j][0] = r[j][1] = r[j][2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            if (j ? h1 : h0) {
+        for (int j = 0; j < 4; j++) {
+            if ((f[j] >> (8 * q)) & 0xffu) {
                 s[0] += r[j][0].x; s[1] += r[j][0].y; s[2] += r[j][0].z; s[3] += r[j][0].w;
                 s[4] += r[j][1].x; s[5] += r[j][1].y; s[6] += r[j][1].z; s[7] += r[j][1].w;
                 s[8] += r[j][2].x; s[9] += r[j][2].y;
@@ -699,46 +701,51 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
     }
 }
 
-// A workgroup handles kGatherG = 64 consecutive Gaussians in two phases.
-//   Phase 1, four lanes per Gaussian: lane q adds the Gaussian's flagged sub-records of quadrant column q over its contiguous run
-//   of instances (a quad reads one instance's 192 contiguous bytes together), then the four columns meet as (q0 + q1) + (q2 + q3)
-//   -- a fixed order, so the totals are bit-identical from run to run; they go to LDS.
-//   Phase 2, one lane per Gaussian (wave 0): computeCov2D / preprocess / SH / cov3D backward on the totals.
+// A workgroup handles kGatherG = 256 consecutive Gaussians in two phases.
+//   Phase 1, four lanes per Gaussian (64 Gaussians per pass, 4 passes): lane q adds the Gaussian's flagged sub-records of quadrant
+//   column q over its contiguous run of instances (a quad reads one instance's 192 contiguous bytes together), then the four
+//   columns meet as (q0 + q1) + (q2 + q3) -- a fixed order, so the totals are bit-identical from run to run; they go to LDS.
+//   Phase 2, one lane per Gaussian: computeCov2D / preprocess / SH / cov3D backward on the totals.
 // dL_dsh is 48 floats (192 B) per Gaussian: written per thread it is a 192-byte-stride scatter (64 cache lines per store
 // instruction).  Instead each Gaussian drops the 21 factors of its row into an LDS tile (odd row stride: conflict-free) and the
 // block expands and streams the tile out as contiguous float4 (1 KiB per wave store).
-constexpr int kGatherG = 64;
+constexpr int kGatherG = 256;
 __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
 {
     extern __shared__ float s_sh[];  // [kGatherG][kShRow] when M == 16 (launch passes the size), else unused
     __shared__ float s_sum[kGatherG][kNV + 1];
     const int tid = threadIdx.x;
     {
-        const int q = tid & 3, gi = tid >> 2;
-        const int idx = blockIdx.x * kGatherG + gi;
-        float s[kNV];
+        const int q = tid & 3;
+        const bool live = a.scalars[2] == 0;   // overflowed forward: all-zero gradients
+#pragma unroll 1
+        for (int pass = 0; pass < kGatherG / 64; pass++) {
+            const int gi = pass * 64 + (tid >> 2);
+            const int idx = blockIdx.x * kGatherG + gi;
+            float s[kNV];
 #pragma unroll
-        for (int v = 0; v < kNV; v++) s[v] = 0.f;
-        if (idx < a.P && a.radii[idx] > 0 && a.scalars[2] == 0) {
-            const uint32_t beg = idx ? a.point_offsets[idx - 1] : 0u;
-            const uint32_t end = a.point_offsets[idx];
-            gather_column(a, beg, end, q, s);
-        }
+            for (int v = 0; v < kNV; v++) s[v] = 0.f;
+            if (live && idx < a.P && a.radii[idx] > 0) {
+                const uint32_t beg = idx ? a.point_offsets[idx - 1] : 0u;
+                const uint32_t end = a.point_offsets[idx];
+                gather_column(a, beg, end, q, s);
+            }
 #pragma unroll
-        for (int v = 0; v < kNV; v++) {
-            float t = s[v];
-            t += __shfl_xor(t, 1, 64);   // (q0 + q1) | (q2 + q3)
-            t += __shfl_xor(t, 2, 64);   // the same two numbers added in either order: one value in all four lanes
-            s[v] = t;
-        }
-        if (q == 0) {
+            for (int v = 0; v < kNV; v++) {
+                float t = s[v];
+                t += __shfl_xor(t, 1, 64);   // (q0 + q1) | (q2 + q3)
+                t += __shfl_xor(t, 2, 64);   // the same two numbers added in either order: one value in all four lanes
+                s[v] = t;
+            }
+            if (q == 0) {
 #pragma unroll
-            for (int v = 0; v < kNV; v++) s_sum[gi][v] = s[v];
+                for (int v = 0; v < kNV; v++) s_sum[gi][v] = s[v];
+            }
         }
     }
     __syncthreads();
     const bool stage_sh = (a.M == 16);
-    if (tid < kGatherG) {
+    {
         const int idx = blockIdx.x * kGatherG + tid;
         if (idx < a.P) {
             if (stage_sh) gather_body<true>(a, idx, &s_sum[tid][0], s_sh + tid * kShRow);
