@@ -254,6 +254,7 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     ra.out_color = in.out_color; ra.out_depth = in.out_depth; ra.out_alpha = in.out_alpha;
     ra.n_contrib = (uint32_t*)(img + L.n_contrib);
     ra.tile_order = (const uint32_t*)(img + L.tile_order);
+    ra.qmask = (uint8_t*)(bin + L.qmask);
     {
         ProfScope ps("render_fwd", stream);
         launch_render_fwd(ra, L.T, stream);
@@ -474,7 +475,7 @@ int gvd_raster_backward_conf(
     ra.scalars = (const uint32_t*)(geom + L.scalars);
     ra.radii = radii; ra.means2D = (const float*)(geom + L.means2D); ra.conic_opacity = (const float*)(geom + L.conic_opacity);
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = background; ra.alphas = alphas;
-    ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials; ra.pflags = pflags;
+    ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials; ra.pflags = pflags; ra.qmask = (const uint8_t*)(bin + L.qmask);
     {
         ProfScope ps("render_bwd", stream);
         launch_render_bwd(ra, L.T, stream);

@@ -150,20 +150,24 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     const int te = lane & (kR - 1), tg = lane / kR;
     const float gy0 = qy0 + (float)(tg * (kR / 8));   // first pixel row of this lane's group (kR / 8 rows per group)
 
-    // ---- the records of trip b + 64 are fetched while trip b is walked ----
-    uint32_t n_id = 0, n_ord = 0, n_poff = 0;
-    int n_rad = 0;
+    // ---- the records of trip b + 64 are fetched while trip b is walked: the list position's id and the forward's cull bit for this
+    // quadrant (both unit-stride), then the three record gathers for the kept entries only ----
+    const uint8_t* const my_mask = a.qmask + (size_t)quad * a.capacity + r0;
+    uint32_t n_id = 0, n_ord = 0;
+    bool n_keep = false;
     float2 n_xy = make_float2(0.f, 0.f);
     float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GVD_BWD_FETCH(BASE)                                                                       \
+    n_keep = false;                                                                               \
     if ((BASE) + (uint32_t)lane < n_walk) {                                                       \
         n_ord = n_walk - 1u - (BASE) - (uint32_t)lane;  /* value of `contributor` after its decrement */ \
         n_id = a.point_list[r0 + n_ord];                                                          \
-        n_xy = reinterpret_cast<const float2*>(a.means2D)[n_id];                                  \
-        n_co = reinterpret_cast<const float4*>(a.conic_opacity)[n_id];                            \
-        n_cd = reinterpret_cast<const float4*>(a.rgbd)[n_id];                                     \
-        n_rad = a.radii[n_id];                                                                    \
-        n_poff = n_id ? a.point_offsets[n_id - 1] : 0u;                                           \
+        n_keep = my_mask[n_ord] != 0;                                                             \
+        if (n_keep) {                                                                             \
+            n_xy = reinterpret_cast<const float2*>(a.means2D)[n_id];                              \
+            n_co = reinterpret_cast<const float4*>(a.conic_opacity)[n_id];                        \
+            n_cd = reinterpret_cast<const float4*>(a.rgbd)[n_id];                                 \
+        }                                                                                         \
     }
     GVD_BWD_FETCH(0u)
 
@@ -171,13 +175,18 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
 #ifdef GVD_RBWD_TRACE
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        // ---- stage (descending list order) + cull against this quadrant + compact ----
-        const bool valid = base + (uint32_t)lane < n_walk;
-        const uint32_t ord = n_ord, poff = n_poff;
-        const int rad = n_rad;
+        // ---- stage (descending list order) + compact the entries that passed the forward's test against this quadrant ----
+        const bool keep = n_keep;
+        const uint32_t id = n_id, ord = n_ord;
         const float2 xy = n_xy;
         const float4 co = n_co, cd = n_cd;
-        const bool keep = valid && rect_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, qx0, qy0, 7.0f, 7.0f);
+        // the kept instances' partial-record slots need two more gathers; consumed after the walk, which hides them
+        int rad = 0;
+        uint32_t poff = 0;
+        if (keep) {
+            rad = a.radii[id];
+            poff = id ? a.point_offsets[id - 1] : 0u;
+        }
         GVD_BWD_FETCH(base + 64u)
         const unsigned long long m = __ballot(keep);
         const uint32_t n = (uint32_t)__popcll(m);

@@ -661,6 +661,9 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         const float4 co = nco, cd = ncd;
         const bool keep = e < n && rect_may_contribute(xy.x, xy.y, co.x, co.y, co.z, co.w, qx0, qy0, 7.0f, 7.0f);
         GVD_FETCH(e + 64u)
+        // the cull bit travels to the backward (one byte per (entry, quadrant), 64 contiguous bytes per trip): its quadrant wave
+        // then gathers the records of the kept entries only, instead of every entry's to repeat this test
+        if (e < n) a.qmask[(size_t)w * a.capacity + r0 + e] = keep ? 1 : 0;
         const unsigned long long m = __ballot(keep);
         const uint32_t cnt = (uint32_t)__popcll(m);
         if (keep) {

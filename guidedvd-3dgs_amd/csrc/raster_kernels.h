@@ -56,6 +56,7 @@ struct RenderArgs {
     const float *means2D, *conic_opacity, *rgbd, *bg;
     float *out_color, *out_depth, *out_alpha;
     uint32_t* n_contrib;
+    uint8_t* qmask;       // [4][capacity]: plane w, list position: 1 = the entry passed wave w's quadrant test (read by k_render_bwd)
 };
 
 struct RenderBwdArgs {
@@ -68,6 +69,7 @@ struct RenderBwdArgs {
     const float *dL_dpix, *dL_dpix_depth, *dL_dalphas;
     float* partials;  // [R][4 quadrants][12]
     uint32_t* pflags; // [R]: byte q set = sub-record (instance, q) written
+    const uint8_t* qmask;  // [4][capacity]: the forward's quadrant cull bits
 };
 
 struct GatherBwdArgs {

@@ -25,7 +25,7 @@ struct Layout {
     size_t ranges, n_contrib, tile_order;
     size_t img_bytes;
     // binning chunk (depends on capacity R)
-    size_t keys, point_list, bucket, pflags, partials;
+    size_t keys, point_list, bucket, qmask, pflags, partials;
     size_t bin_bytes;
 };
 
@@ -76,6 +76,7 @@ inline Layout make_layout(int P, int W, int H, uint32_t R)
     L.keys = carve(c, Rz * 8);
     L.point_list = carve(c, Rz * 4);
     L.bucket = carve(c, Rz * 8);
+    L.qmask = carve(c, Rz * 4);                           // 4 byte planes (quadrant) x list entry: the forward's conservative cull bit
     L.pflags = carve(c, Rz * 4);                          // byte q: quadrant q of the instance wrote its sub-record
     L.partials = carve(c, Rz * 4 * kPartialStride * 4);
     L.bin_bytes = c + kAlign;
