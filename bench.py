@@ -359,8 +359,8 @@ def raster_run(args, dev, rank, world):
                             avg_us=round(kern[dom]["avg_us"], 2), alg_bytes=int(alg_bytes[dom]), valu_busy=valu_busy)
             # The blend kernels are bound by VALU issue, not by HBM (DESIGN.md sections 5, 7c): next to the HBM figure the line carries
             # the VALU-issue roofline -- (entry, quadrant) wave steps x issue cycles per step / (1024 SIMDs x 2.4 GHz) against the
-            # live kernel time.  Steps and instruction counts are the committed measurements of profiles/r04_raster_valu.json.
-            vj = os.path.join(ROOT, "profiles", "r04_raster_valu.json")
+            # live kernel time.  Steps and instruction counts are the committed measurements of profiles/r05_raster_valu.json.
+            vj = os.path.join(ROOT, "profiles", "r05_raster_valu.json")
             if os.path.exists(vj):
                 try:
                     vv = json.load(open(vj))
@@ -372,7 +372,7 @@ def raster_run(args, dev, rank, world):
                                             "frac": round(ideal / kern[kname]["avg_us"], 3)}
                     roofline["valu_issue"] = {"bound": "valu", "unit": "us per launch at 1024 SIMDs x 2.4 GHz", "kernels": issue,
                                               "useful_lane_fraction": vv.get("useful_lane_fraction"), "sustained_clock": raster_clock,
-                                              "from": "profiles/r04_raster_valu.json (lane_stats.py wave steps, ISA instruction counts at HEAD; NOT observed in this run)"}
+                                              "from": "profiles/r05_raster_valu.json (lane_stats.py wave steps, SQ_INSTS_VALU of the round-5 counter pass; NOT observed in this run)"}
                 except Exception:
                     pass
 
