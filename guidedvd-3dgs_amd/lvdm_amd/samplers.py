@@ -66,6 +66,13 @@ def _wants_batched_pair(sampler, x, c, uc):
     return x.is_cuda and x.shape[-1] * x.shape[-2] <= BATCH_CFG_MAX_PIXELS and _per_sample_model(sampler.model)
 
 
+def _is_stock_loss_guidance(fn):
+    """True when `fn` is guidance.LossGuidance with its own __call__ and frames_loss (not overridden by a subclass)."""
+    from .guidance import LossGuidance
+    t = type(fn)
+    return isinstance(fn, LossGuidance) and t.__call__ is LossGuidance.__call__ and t.frames_loss is LossGuidance.frames_loss
+
+
 class DDIMSampler(object):
     # "device": draw on the latent's device from its global generator (what the reference does on CUDA); "cpu": draw on the
     # CPU generator and move -- reproduces a CPU trajectory on the GPU (tests/test_diffusion_goldens_gpu.py).
@@ -243,19 +250,25 @@ class DDIMSamplerGuidance(DDIMSampler):
         key = (int(n_frames), int(h), int(w), str(device), float(self.decode_budget_gb))
         cache = self.__dict__.setdefault("_decode_group_cache", {})
         if key not in cache:
-            cache[key] = self._choose_decode_group(n_frames, h, w, device)
+            group, by_cap = self._choose_decode_group(n_frames, h, w, device)
+            if not by_cap:
+                # free memory, not the fixed cap, decided: that figure goes stale when the 3DGS side grows (densification) or
+                # another allocation lands -- do not keep it (advisor finding, round 4); the next step asks again
+                return group
+            cache[key] = group
         return cache[key]
 
     def _choose_decode_group(self, n_frames, h, w, device):
+        """(frames per decoder pass, True when the fixed budget cap -- not the device's free memory -- set it)."""
         per_frame = 4.0 * 2 ** 30 * (h * w) / (72.0 * 128.0)
-        budget = float(self.decode_budget_gb) * 2 ** 30
+        budget = cap = float(self.decode_budget_gb) * 2 ** 30
         if device.type == "cuda":
             free, _ = torch.cuda.mem_get_info(device)
             cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)   # the allocator's own free blocks
             budget = min(budget, 0.5 * (free + cached))
         gmax = max(1, int(budget // per_frame))
         n_groups = -(-n_frames // gmax)
-        return -(-n_frames // n_groups)
+        return -(-n_frames // n_groups), budget >= cap
 
     def _grad_ctx(self):
         return torch.enable_grad()
@@ -328,7 +341,11 @@ class DDIMSamplerGuidance(DDIMSampler):
                 D = m.differentiable_decode_first_stage(z)
                 # this package's LossGuidance evaluates the frames of a decoder pass as one set of tensor ops (same sums: a frame's
                 # loss touches its own image only); any other callable keeps the reference's per-frame protocol
+                # ... and only when it IS this package's __call__: a subclass or wrapper that customises the call (a depth term, other
+                # weights, per-index logic) keeps the per-frame protocol, index included (advisor finding, round 4)
                 fast = getattr(loss_guidance_fn, "frames_loss", None)
+                if fast is not None and not _is_stock_loss_guidance(loss_guidance_fn):
+                    fast = None
                 fast = fast(D[0], f0, f1) if fast is not None else None
                 if fast is not None:
                     total, numels = fast

@@ -167,9 +167,11 @@ class CrossAttention(nn.Module):
                     out = ops.attention(q, k_ip, v_ip, self.heads, accum=out, accum_scale=float(s))
             out = out.reshape(q_shape)
         lo, drop = self.to_out[0], self.to_out[1]
-        if residual is not None and drop.training and drop.p > 0:
-            # the reference drops the projection, not the residual stream: dropout(linear(out)) + x (attention.py:144, :241-244)
-            return drop(gemm.linear(out, lo.weight, lo.bias)) + residual
+        if drop.training and drop.p > 0:
+            # the reference drops the projection, not the residual stream: dropout(linear(out)) [+ x] (attention.py:144, :241-244);
+            # with or without a residual (advisor finding, round 4: the residual-less call skipped the dropout)
+            y = drop(gemm.linear(out, lo.weight, lo.bias))
+            return y if residual is None else y + residual
         return gemm.linear(out, lo.weight, lo.bias, residual=residual, res_grad_to=cell)   # eval / p = 0: dropout is the identity, `+ x` in the epilogue
 
 

@@ -436,17 +436,20 @@ def test_config5_eight_ranks_on_one_gpu_with_hip_kernels(layout, cfg, deliver_af
     raster replicated on eight ranks, guidance renders sharded eight ways (three ranks own no view) -- the layout DESIGN section 9
     expects to be the faster use of an 8-GPU node; D = 0.
 
-    Judged like the parity bars, because three chained guided DDIM steps (a normalised gradient step each, CFG 7.5) amplify every
-    fp16 rounding and frame shards change which rows share a workgroup (the single sharded step agrees to 1e-2 of the tensor's max:
-    test_ddim_parallel_gloo.py::test_ranks_on_one_gpu_with_hip_kernels): the same schedule runs in ONE process in fp32 (the anchor)
-    and in fp16 on the HIP kernels, and the eight-rank fp16 run must be as close to the anchor as the one-process fp16 run is,
+    THE CRITERION for the sharded diffusion path is the single-step probe: every diffusion rank runs ONE guided step on fixed inputs
+    under the layout's plan (cfg x 4 frame shards, real cross-rank reductions); it must agree with the one-process step to 1e-2 of
+    the tensor's max (fp16 rounding of a different summation order, as for the 2- and 4-rank layouts in
+    test_ddim_parallel_gloo.py::test_ranks_on_one_gpu_with_hip_kernels) and be BIT-EQUAL across the ranks.  For the schedule: identical
+    event order on every raster rank, and raster replicas BIT-IDENTICAL to each other.
 
-        |frames(8 ranks, fp16) - frames(fp32)|  <=  2 x |frames(1 process, fp16) - frames(fp32)| + 2e-3      (max over pixels, range [0, 1])
+    The end-to-end frames are only guarded against divergence, not used as a parity bar (advisor finding, round 4): three chained
+    guided DDIM steps (a normalised gradient step each, CFG 7.5) on this random-weight miniature amplify every fp16 rounding until
+    the one-process fp16 run itself sits 0.27-0.33 of the [0, 1] range from the fp32 run, so
 
-    -- sharding may move the result inside the fp16 error ball, not out of it (measured: the ball is wide, 0.27-0.33 of the range on
-    this random-weight miniature -- which is why every diffusion rank ALSO runs ONE guided step on fixed inputs under the layout's
-    plan, held to 1e-2 of the tensor's max against the one-process step and to bit-equality across the ranks).  Also: identical event order on every raster rank,
-    Gaussians to what those frames imply, raster replicas BIT-IDENTICAL to each other."""
+        |frames(8 ranks, fp16) - frames(fp32)|  <=  2 x |frames(1 process, fp16) - frames(fp32)| + 2e-3
+
+    can only fail if sharding throws the run out of that (wide) ball -- a NaN, a lost shard, a wrong hand-off.  The trajectory bar that
+    does constrain multi-step fp16 behaviour is tests/test_diffusion_trajectory_gpu.py (trained-like gains, 10 steps, one process)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm device")
     n_frames = T if layout == "disjoint" else 9      # shared: the decodes of a guided step are split over all 8 ranks (>= 1 frame each)
@@ -474,7 +477,7 @@ def test_config5_eight_ranks_on_one_gpu_with_hip_kernels(layout, cfg, deliver_af
         assert [e for e in out["events"] if e[0] != "generate"] == expect, (r, out["events"])
         err = float((out["frames"] - anchor["frames"]).abs().max())
         worst = max(worst, err)
-        assert err <= 2.0 * e1 + 2e-3, (r, err, e1)
+        assert err <= 2.0 * e1 + 2e-3, (r, err, e1)          # divergence guard only (see the docstring)
         for k, v in anchor["state"].items():
             scale = float(v.abs().max())
             e_state = float((ref["state"][k] - v).abs().max())
