@@ -123,10 +123,6 @@ class LatentDiffusion(DDPM):
     def _prepare_native(self):
         if self._native_ready or self.device.type != "cuda":
             return
-        import os
-        if os.environ.get("GVD_NO_TUNING", "0") != "1":   # recorded hipBLASLt / MIOpen solution choices (explicit, per-rank cache)
-            import lvdm_amd
-            lvdm_amd.configure_tuning()
         unet = self.model.diffusion_model
         if next(unet.parameters()).dtype == torch.float32:
             unet.half()

@@ -1,5 +1,5 @@
 # rocprofv3 kernel trace of a DDIM bench run; args are passed to bench.py.  Output: gpurun_out/prof_<TAG>/
-export MIOPEN_USER_DB_PATH=$PWD/guidedvd-3dgs_amd/lvdm_amd/miopen_db
+
 export GVD_CONV_FIND=1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
