@@ -237,6 +237,8 @@ class DDIMSamplerGuidance(DDIMSampler):
     #: (a group's saved activations past ~30 GB cost more than the fewer launches save); 320x448 -- 5 / 9 / 13 / 25 frames 299 / 289 / 289 / 287 ms
     decode_group = None
     decode_budget_gb = 25.0
+    #: scale d(loss)/d(pred_x0) by a power of two before the U-Net's 16-bit backward (exact: the update is invariant, see the step)
+    scale_guidance_gradient = True
 
     def _decode_group(self, n_frames, h, w, device):
         """Chosen ONCE per (frames, latent size, device) and kept on the sampler: the grouping decides launch shapes and the order
@@ -365,10 +367,21 @@ class DDIMSamplerGuidance(DDIMSampler):
             if decoded:
                 loss_guidance_fn.save_pred_x0(torch.cat(decoded, dim=2), index)
             G = torch.cat(grads, dim=2)
+            if plan is not None:
+                G = plan.gather_world_frames(G, n_frames)  # every rank decoded its share of the frames
+            if self.scale_guidance_gradient and G.is_cuda:
+                # d(loss)/d(pred_x0) is ~1e-5 .. 1e-8 per element after the 1/numel (a mean over ~3e5 pixels), and it enters the
+                # U-Net's 16-bit backward as is: fp16 subnormals (the reference under fp16 autocast has the same underflow; measured
+                # on the full-width anchor, tests/golden/make_golden_fullwidth_guided.py: its guidance term keeps a cosine of 0.01 with
+                # the fp32 one on small-gain weights).  The update below uses the gradient only through rho * gx with
+                # rho = rms(correction) s 0.2 w / rms(gx): invariant under any rescaling of G.  So G is scaled by a power of two
+                # (exact in binary floating point) to a largest entry in [2^-5, 2^-4) -- chosen on the device, no host sync; the
+                # same number on every rank (G is the gathered tensor).
+                gmax = G.abs().amax().clamp_min(1e-30)
+                G = G * torch.exp2(-4.0 - torch.floor(torch.log2(gmax)) - 1.0)
             if plan is None:
                 (gx,) = torch.autograd.grad(pred_x0, x, grad_outputs=G)
             else:
-                G = plan.gather_world_frames(G, n_frames)  # every rank decoded its share of the frames
                 gx, g_ec, g_eu = torch.autograd.grad(pred_x0, (x, e_cond, e_uncond), grad_outputs=G)
                 gx = gx + plan.input_gradient(graphs, g_ec, g_eu, like=gx)
             with torch.no_grad():
