@@ -42,37 +42,36 @@ __device__ unsigned long long g_rtrace[8192 * 8];
 // life in the walk, 9 % in staging and 23 % parked at the batch-end barrier waiting for the slowest quadrant (the quadrant lists of
 // a batch differ by ~25 %, and the wait repeats every batch), and the launch lasts as long as its longest tile (1100 entries,
 // ~0.17 us each under a three-way shared SIMD).  Here a wave owns its quadrant from the first list entry to the last:
-//   * it stages 64 entries per trip itself (lane = entry: id -> records, ONE rectangle test against its own quadrant, ballot
-//     compaction into its private LDS strip; the next trip's gathers are in flight during the walk), and only the list prefix in
-//     front of ITS last contributor (max n_contrib of its 64 pixels), not the tile's;
+//   * it stages 64 entries per trip itself (lane = entry: the forward's cull bit for this quadrant, then id -> records for the kept
+//     entries, ballot compaction into its private LDS strip; the next trip's gathers are in flight during the walk), and only the
+//     list prefix in front of ITS last contributor (max n_contrib of its 64 pixels), not the tile's;
 //   * its per-entry sums go to a private sub-record: partials[(4 * instance + quadrant)] (48 bytes), flagged in pflags[instance]
 //     byte `quadrant`; k_gather_bwd adds the flagged sub-records in the fixed order instance-major, quadrant-minor, so the
 //     gradients stay bitwise deterministic without any cross-wave meeting point.  The forward's k_scatter zeroes the 4-byte flag
 //     words instead of the 48-byte records.
 // 4 T independent units instead of T workgroups: the dispatcher balances quadrants, nothing waits for a neighbour, and the LDS
-// footprint (6 KiB per wave, + 8 KiB for the turn-around strip) no longer limits occupancy.
+// footprint (4 KiB per wave + 8 KiB for the turn-around strip) no longer limits occupancy.
 //
-// kRows == 0: per-pixel gradient terms + the DPP wave reduction of round 2 (wave_reduce20 / wave_reduce10).
-// kRows > 0 : the transposed turn-around.  The walk keeps only what is serial per pixel and leaves, per (entry, pixel),
+// The per-Gaussian sums are formed by an LDS TURN-AROUND, not by a cross-lane reduction per entry.  The walk keeps only what is serial
+// per pixel and leaves, per (entry, pixel),
 //     q = G * dL_dalpha   (backward.cu:577-598: every conic / mean / opacity term is q times a polynomial in (dx, dy))
 //     w = alpha * T       (backward.cu:520-537: dL_dcolor[c] = w * dL_dpixel[c])
-//   in a row of the wave's LDS strip; every kRows entries the wave turns around -- lane = (entry e, pixel group g) -- and each lane
-//   accumulates the moments sum q, q dx, q dy, q dx^2, q dx dy, q dy^2 and sum w dL_dpix[c] over its group's pixels in its own
-//   registers (13 VALU per pixel for kRows entries at once instead of 17 term + 25 reduction instructions per entry).
+// in a row of the wave's LDS strip; every kRows entries the wave turns around -- lane = (entry e, pixel group g) -- and each lane
+// accumulates the moments sum q, q dx, q dy, q dx^2, q dx dy, q dy^2 and sum w dL_dpix[c] over its group's pixels in its own
+// registers (13 VALU per pixel for kRows entries at once instead of 17 term + 25 DPP-reduction instructions per entry: the DPP form,
+// round 2's wave_reduce20, measured 141 us in this kernel against 113 us; 8 rows 134 us), the groups meet with log2(64 / kRows)
+// shuffles, and the lanes of group 0 write the entry's sub-record and flag straight to global memory.
 // DA: the caller supplied a gradient for the depth and / or the alpha image (else those recurrences are compiled out).
 // ------------------------------------------------------------------------------------------------
 template <bool DA, int kRows>
 __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
 {
-    static_assert(kRows == 0 || kRows == 8 || kRows == 16, "rows per turn-around");
-    constexpr int NVS = DA ? kNV : kNV - 1;   // value 9 (the depth term) is exactly 0 without a depth gradient
-    constexpr int kOutStride = NVS | 1;       // odd: conflict-free per-slot rows
+    static_assert(kRows == 8 || kRows == 16, "rows per turn-around");
     constexpr int kStride = 65;               // float2 per strip row: 64 pixels + the row's slot id; 130 words = 2 (mod 32)
-    __shared__ float4 s_rec[2 * 64];          // per staged entry {x, y, list position (bits), -, conic a b c, opacity}
+    __shared__ float4 s_rec[2 * 64];          // per staged entry {x, y, list position (bits), record slot (bits), conic a b c, opacity}
     __shared__ float4 s_cd[64];
-    __shared__ float s_out[64][kOutStride];
-    __shared__ float2 s_qw[kRows ? kRows : 1][kStride];
-    __shared__ float4 s_dl[kRows ? 64 : 1];   // the wave's pixels' (dL_dpix rgb, dL_ddepth)
+    __shared__ float2 s_qw[kRows][kStride];
+    __shared__ float4 s_dl[64];               // the wave's pixels' (dL_dpix rgb, dL_ddepth)
 
     // unit -> (tile, quadrant): 32 consecutive units are 8 consecutive positions of tile_order x 4 quadrants, so that unit u and
     // position p agree modulo 8 -- the XCD a workgroup lands on and the image region k_tilescan dealt to that position (its L2).
@@ -121,7 +120,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
         if (DA && a.dL_dpix_depth) dLd = a.dL_dpix_depth[pid];  // NULL == all-zero gradient
         if (DA && a.dL_dalphas) dLa = a.dL_dalphas[pid];
     }
-    if (kRows) s_dl[lane] = make_float4(dLp0, dLp1, dLp2, dLd);
+    s_dl[lane] = make_float4(dLp0, dLp1, dLp2, dLd);
     float bg_dot = 0.f;  // backward.cu:575-577 accumulation order
     bg_dot += a.bg[0] * dLp0;
     bg_dot += a.bg[1] * dLp1;
@@ -138,6 +137,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     if (n_walk == 0 && lane == 0) GVD_RT(1, __builtin_amdgcn_s_memrealtime());
 #endif
     if (n_walk == 0) return;
+
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_d = 0.f, acc_a = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
     const float nddelx_dx = -0.5f * a.W, nddely_dy = -0.5f * a.H;   // -(d delta / d mean2D): backward.cu:490-491
@@ -145,15 +145,16 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);  // wave-uniform (kernel argument)
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    // turn-around roles (kRows > 0): entry e of the strip, pixel group g (pixels g * kRows .. + kRows - 1 of the quadrant, lane order)
-    constexpr int kR = kRows ? kRows : 8;
-    const int te = lane & (kR - 1), tg = lane / kR;
-    const float gy0 = qy0 + (float)(tg * (kR / 8));   // first pixel row of this lane's group (kR / 8 rows per group)
+    // turn-around roles: entry e of the strip, pixel group g (pixels g * kRows .. + kRows - 1 of the quadrant, lane order)
+    const int te = lane & (kRows - 1), tg = lane / kRows;
+    const float gy0 = qy0 + (float)(tg * (kRows / 8));   // first pixel row of this lane's group (kRows / 8 rows per group)
 
     // ---- the records of trip b + 64 are fetched while trip b is walked: the list position's id and the forward's cull bit for this
-    // quadrant (both unit-stride), then the three record gathers for the kept entries only ----
+    // quadrant (both unit-stride), then the record gathers -- and the two gathers of the instance's partial-record slot -- for the kept
+    // entries only ----
     const uint8_t* const my_mask = a.qmask + (size_t)quad * a.capacity + r0;
-    uint32_t n_id = 0, n_ord = 0;
+    uint32_t n_id = 0, n_ord = 0, n_poff = 0;
+    int n_rad = 0;
     bool n_keep = false;
     float2 n_xy = make_float2(0.f, 0.f);
     float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,6 +168,8 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
             n_xy = reinterpret_cast<const float2*>(a.means2D)[n_id];                              \
             n_co = reinterpret_cast<const float4*>(a.conic_opacity)[n_id];                        \
             n_cd = reinterpret_cast<const float4*>(a.rgbd)[n_id];                                 \
+            n_rad = a.radii[n_id];                                                                \
+            n_poff = n_id ? a.point_offsets[n_id - 1] : 0u;                                       \
         }                                                                                         \
     }
     GVD_BWD_FETCH(0u)
@@ -177,26 +180,18 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
 #endif
         // ---- stage (descending list order) + compact the entries that passed the forward's test against this quadrant ----
         const bool keep = n_keep;
-        const uint32_t id = n_id, ord = n_ord;
-        const float2 xy = n_xy;
-        const float4 co = n_co, cd = n_cd;
-        // the kept instances' partial-record slots need two more gathers; consumed after the walk, which hides them
-        int rad = 0;
-        uint32_t poff = 0;
-        if (keep) {
-            rad = a.radii[id];
-            poff = id ? a.point_offsets[id - 1] : 0u;
-        }
-        GVD_BWD_FETCH(base + 64u)
         const unsigned long long m = __ballot(keep);
         const uint32_t n = (uint32_t)__popcll(m);
-        const uint32_t slot = (uint32_t)__popcll(m & below);
         if (keep) {
-            s_rec[2 * slot] = make_float4(xy.x, xy.y, __uint_as_float(ord), 0.f);
-            s_rec[2 * slot + 1] = co;
-            s_cd[slot] = cd;
+            const uint32_t slot = (uint32_t)__popcll(m & below);
+            // the instance's sub-record: slot in Gaussian order (point_offsets[id - 1] + row-major index of the tile in the rect), x 4 + quadrant
+            const int4 r = get_rect(n_xy.x, n_xy.y, n_rad, a.gx, a.gy);
+            const uint32_t g = n_poff + (uint32_t)((ty - r.y) * (r.z - r.x) + (tx - r.x));
+            s_rec[2 * slot] = make_float4(n_xy.x, n_xy.y, __uint_as_float(n_ord), __uint_as_float(g * 4u + (uint32_t)quad));
+            s_rec[2 * slot + 1] = n_co;
+            s_cd[slot] = n_cd;
         }
-        unsigned long long done = 0ull;   // wave-uniform: slots whose entry had an active pixel (their s_out rows are written)
+        GVD_BWD_FETCH(base + 64u)
 #ifdef GVD_RBWD_TRACE
         const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
         stage_cycles += tw0 - ts0;
@@ -218,19 +213,17 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
         /* wave-level "any lane active": the AND of the three compares' lane masks */             \
         const bool any##J = (__builtin_amdgcn_ballot_w64(ord##J < last_contributor) &             \
                              __builtin_amdgcn_ballot_w64(!(pw##J > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha##J < 1.0f / 255.0f))) != 0ull;
-// The serial part.  Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the value the next
-// active entry would have formed (fmaf(1, acc, 0 * c) == acc bit-exactly) and every term is exactly 0.
-// Leaves dopa##J = dL_dalpha (x T, + background term) and wgt##J = alpha * T.
+// The serial part and the entry's row of the strip.  Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the
+// value the next active entry would have formed (fmaf(1, acc, 0 * c) == acc bit-exactly) and q = w = 0.
 #define GVD_BWD_SERIAL(J, SL)                                                                     \
-        const float4 c##J = s_cd[SL];                                                             \
-        const float am##J = act##J ? alpha##J : 0.f;                                              \
-        const float gm##J = act##J ? G##J : 0.f;                                                  \
-        float dopa##J, wgt##J;                                                                    \
         {                                                                                         \
-            const float one_m_a = 1.f - am##J;                                                    \
+            const float4 c = s_cd[SL];                                                            \
+            const float am = act##J ? alpha##J : 0.f;                                             \
+            const float gm = act##J ? G##J : 0.f;                                                 \
+            const float one_m_a = 1.f - am;                                                       \
             const float rinv = GVD_BWD_RCP(one_m_a);                                              \
             T = T * rinv;                                                                         \
-            wgt##J = am##J * T;                                                                   \
+            const float wgt = am * T;                                                             \
             const float oml = 1.f - last_alpha;                                                   \
             acc0 = fmaf(oml, acc0, last_alpha * lc0);                                             \
             acc1 = fmaf(oml, acc1, last_alpha * lc1);                                             \
@@ -239,11 +232,11 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
                 acc_d = fmaf(oml, acc_d, last_alpha * last_depth);                                \
                 acc_a = fmaf(oml, acc_a, last_alpha);                                             \
             }                                                                                     \
-            float d_ = (c##J.x - acc0) * dLp0;                                                    \
-            d_ = fmaf(c##J.y - acc1, dLp1, d_);                                                   \
-            d_ = fmaf(c##J.z - acc2, dLp2, d_);                                                   \
+            float d_ = (c.x - acc0) * dLp0;                                                       \
+            d_ = fmaf(c.y - acc1, dLp1, d_);                                                      \
+            d_ = fmaf(c.z - acc2, dLp2, d_);                                                      \
             if (DA) {                                                                             \
-                d_ = fmaf(c##J.w - acc_d, dLd, d_);                                               \
+                d_ = fmaf(c.w - acc_d, dLd, d_);                                                  \
                 d_ = fmaf(1.f - acc_a, dLa, d_);                                                  \
             }                                                                                     \
             d_ *= T;                                                                              \
@@ -252,45 +245,13 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
                 qb = fmaf(fmaf(-one_m_a, qb, nTf), rinv, qb);                                     \
                 d_ = fmaf(qb, bg_dot, d_);                                                        \
             }                                                                                     \
-            dopa##J = d_;                                                                         \
-            lc0 = c##J.x; lc1 = c##J.y; lc2 = c##J.z; last_depth = c##J.w; last_alpha = am##J;    \
-        }
-// kRows == 0: the ten per-pixel terms of entry J (V##0..9), formed from q = o * G * dL_dalpha once
-#define GVD_BWD_TERMS(J, V)                                                                       \
-        float V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9;                         \
-        {                                                                                         \
-            V##5 = gm##J * dopa##J;                                                               \
-            const float q_ = con##J.w * V##5;                                                     \
-            const float u_ = fmaf(con##J.y, dy##J, con##J.x * dx##J);                             \
-            const float v_ = fmaf(con##J.y, dx##J, con##J.z * dy##J);                             \
-            V##0 = (q_ * nddelx_dx) * u_;                                                         \
-            V##1 = (q_ * nddely_dy) * v_;                                                         \
-            const float h_ = -0.5f * q_;                                                          \
-            const float hx_ = h_ * dx##J, hy_ = h_ * dy##J;                                       \
-            V##2 = hx_ * dx##J;                                                                   \
-            V##3 = hx_ * dy##J;                                                                   \
-            V##4 = hy_ * dy##J;                                                                   \
-            V##6 = wgt##J * dLp0;                                                                 \
-            V##7 = wgt##J * dLp1;                                                                 \
-            V##8 = wgt##J * dLp2;                                                                 \
-            V##9 = DA ? wgt##J * dLd : 0.f;                                                       \
-        }
-#define GVD_BWD_STORE10(SL, V)                                                                    \
-        wave_reduce10(V##0, V##1, V##2, V##3, V##4, V##5, V##6, V##7, V##8, V##9);                \
-        if ((lane & 31) == 31) {                                                                  \
-            float* o = &s_out[SL][(lane >> 5) * 5];                                               \
-            o[0] = V##0; o[1] = V##1; o[2] = V##2; o[3] = V##3;                                   \
-            if (DA || lane < 32) o[4] = V##4;                                                     \
-        }
-// kRows > 0: entry J's row of the strip
-#define GVD_BWD_ROW(J, SL)                                                                        \
-        {                                                                                         \
+            lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
             float2* row = &s_qw[rows][0];                                                         \
-            row[lane] = make_float2(gm##J * dopa##J, wgt##J);                                     \
+            row[lane] = make_float2(gm * d_, wgt);                                                \
             if (lane == 0) row[64] = make_float2(__uint_as_float(SL), 0.f);                       \
             rows++;                                                                               \
         }
-        // ---- the turn-around: rows [0, nrows) of the strip -> s_out[slot][0..NVS) ----
+        // ---- the turn-around: rows [0, nrows) of the strip -> the entries' sub-records ----
         auto flush = [&](const uint32_t nrows) {
 #pragma clang fp contract(fast)
             if ((uint32_t)te < nrows) {
@@ -298,11 +259,11 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
                 const uint32_t sl = __float_as_uint(row[64].x);
                 const float4 g0 = s_rec[2 * sl];
                 const float gxr = g0.x - qx0, gyr = g0.y - gy0;
-                const float2* qp = row + tg * kR;
-                const float4* dp = &s_dl[tg * kR];
+                const float2* qp = row + tg * kRows;
+                const float4* dp = &s_dl[tg * kRows];
                 float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, S6 = 0.f, S7 = 0.f, S8 = 0.f, S9 = 0.f;
 #pragma unroll
-                for (int t = 0; t < kR; t++) {
+                for (int t = 0; t < kRows; t++) {
                     const float2 qw = qp[t];
                     const float4 dl = dp[t];
                     const float dx = gxr - (float)(t & 7), dy = gyr - (float)(t >> 3);
@@ -313,7 +274,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
                     if (DA) S9 = fmaf(qw.y, dl.w, S9);
                 }
 #pragma unroll
-                for (int msk = kR; msk < 64; msk <<= 1) {
+                for (int msk = kRows; msk < 64; msk <<= 1) {
                     S0 += __shfl_xor(S0, msk, 64); S1 += __shfl_xor(S1, msk, 64); S2 += __shfl_xor(S2, msk, 64);
                     S3 += __shfl_xor(S3, msk, 64); S4 += __shfl_xor(S4, msk, 64); S5 += __shfl_xor(S5, msk, 64);
                     S6 += __shfl_xor(S6, msk, 64); S7 += __shfl_xor(S7, msk, 64); S8 += __shfl_xor(S8, msk, 64);
@@ -322,15 +283,13 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
                 if (tg == 0) {
                     const float4 con = s_rec[2 * sl + 1];
                     const float ox = con.w * nddelx_dx, oy = con.w * nddely_dy, oh = -0.5f * con.w;
-                    float* o = &s_out[sl][0];
-                    o[0] = ox * fmaf(con.y, S2, con.x * S1);   // sum (o q) (-0.5 W) (a dx + b dy)
-                    o[1] = oy * fmaf(con.y, S1, con.z * S2);
-                    o[2] = oh * S3;
-                    o[3] = oh * S4;
-                    o[4] = oh * S5;
-                    o[5] = S0;
-                    o[6] = S6; o[7] = S7; o[8] = S8;
-                    if (DA) o[9] = S9;
+                    const size_t sub = (size_t)__float_as_uint(g0.w);   // 4 * instance slot + quadrant
+                    float4* dst = reinterpret_cast<float4*>(a.partials + sub * kPartialStride);
+                    dst[0] = make_float4(ox * fmaf(con.y, S2, con.x * S1),      // sum (o q) (-0.5 W) (a dx + b dy)
+                                         oy * fmaf(con.y, S1, con.z * S2), oh * S3, oh * S4);
+                    dst[1] = make_float4(oh * S5, S0, S6, S7);
+                    dst[2] = make_float4(S8, DA ? S9 : 0.f, 0.f, 0.f);
+                    reinterpret_cast<uint8_t*>(a.pflags)[sub] = 1;
                 }
             }
         };
@@ -339,72 +298,29 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
         auto walk = [&](auto bg_tag) {
 #pragma clang fp contract(fast)  // gradient terms are tolerance-checked (1e-4), not bit-pinned
             constexpr bool BG = decltype(bg_tag)::value;
-            uint32_t rows = 0;   // wave-uniform: filled rows of the strip (kRows > 0)
+            uint32_t rows = 0;   // wave-uniform: filled rows of the strip
             uint32_t j = 0;
             for (; j + 2 <= n; j += 2) {
                 GVD_BWD_GEOM(0, j)
                 GVD_BWD_GEOM(1, j + 1)
-                if (kRows) {
-                    if (any0) { GVD_BWD_SERIAL(0, j) GVD_BWD_ROW(0, j) done |= 1ull << j; }
-                    if (any1) { GVD_BWD_SERIAL(1, j + 1) GVD_BWD_ROW(1, j + 1) done |= 2ull << j; }
-                    if (rows >= (uint32_t)kR - 1u) { flush(rows); rows = 0; }
-                } else if (any0 && any1) {
-                    GVD_BWD_SERIAL(0, j) GVD_BWD_TERMS(0, p)
-                    GVD_BWD_SERIAL(1, j + 1) GVD_BWD_TERMS(1, q)
-                    wave_reduce20(p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, q0, q1, q2, q3, q4, q5, q6, q7, q8, q9);
-                    if ((lane & 15) == 15) {  // row 0: A[0..4], row 1: B[0..4], row 2: A[5..9], row 3: B[5..9]
-                        float* o = &s_out[j + ((lane >> 4) & 1)][(lane >> 5) * 5];
-                        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3;
-                        if (DA || lane < 32) o[4] = p4;
-                    }
-                    done |= 3ull << j;
-                } else if (any0) {
-                    GVD_BWD_SERIAL(0, j) GVD_BWD_TERMS(0, p)
-                    GVD_BWD_STORE10(j, p)
-                    done |= 1ull << j;
-                } else if (any1) {
-                    GVD_BWD_SERIAL(1, j + 1) GVD_BWD_TERMS(1, q)
-                    GVD_BWD_STORE10(j + 1, q)
-                    done |= 2ull << j;
-                }
+                if (any0) GVD_BWD_SERIAL(0, j)
+                if (any1) GVD_BWD_SERIAL(1, j + 1)
+                if (rows >= (uint32_t)kRows - 1u) { flush(rows); rows = 0; }
             }
             if (j < n) {
                 GVD_BWD_GEOM(0, j)
-                if (any0) {
-                    GVD_BWD_SERIAL(0, j)
-                    if (kRows) { GVD_BWD_ROW(0, j) } else { GVD_BWD_TERMS(0, p) GVD_BWD_STORE10(j, p) }
-                    done |= 1ull << j;
-                }
+                if (any0) GVD_BWD_SERIAL(0, j)
             }
-            if (kRows && rows) flush(rows);
+            if (rows) flush(rows);
         };
         if (has_bg) walk(std::true_type{});
         else walk(std::false_type{});
-#undef GVD_BWD_ROW
-#undef GVD_BWD_STORE10
-#undef GVD_BWD_TERMS
 #undef GVD_BWD_SERIAL
 #undef GVD_BWD_GEOM
 #undef GVD_BWD_RCP
 #ifdef GVD_RBWD_TRACE
         const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
         walk_cycles += tw1 - tw0;
-#endif
-
-        // ---- one sub-record per walked (Gaussian, tile, quadrant), at the instance's Gaussian-order slot ----
-        if (keep && ((done >> slot) & 1ull)) {
-            const int4 r = get_rect(xy.x, xy.y, rad, a.gx, a.gy);
-            const uint32_t k = (uint32_t)((ty - r.y) * (r.z - r.x) + (tx - r.x));
-            const uint32_t g = poff + k;
-            const float* o = &s_out[slot][0];
-            float4* dst = reinterpret_cast<float4*>(a.partials + ((size_t)g * 4 + quad) * kPartialStride);
-            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-            dst[2] = make_float4(o[8], DA ? o[NVS - 1] : 0.f, 0.f, 0.f);
-            reinterpret_cast<uint8_t*>(a.pflags)[(size_t)g * 4 + quad] = 1;
-        }
-#ifdef GVD_RBWD_TRACE
-        tail_cycles += __builtin_amdgcn_s_memtime() - tw1;
 #endif
     }
 #undef GVD_BWD_FETCH
@@ -794,17 +710,12 @@ __global__ void __launch_bounds__(256) k_scale_cov(int n, float* __restrict__ dL
 
 void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 {
-    // A/B switch (round 5): 1 = transposed turn-around, 16 rows (shipped: 113 us on the C2 view); 2 = 8 rows (134 us);
-    // 0 = per-pixel terms + DPP wave reduction (141 us)
-    static const int variant = getenv("GVD_BWD_VARIANT") ? atoi(getenv("GVD_BWD_VARIANT")) : 1;
+    static const int rows8 = getenv("GVD_BWD_ROWS8") ? atoi(getenv("GVD_BWD_ROWS8")) : 0;   // A/B switch (round 5): 8-row strip
     const bool da = a.dL_dpix_depth || a.dL_dalphas;
     const int units = ((T + 7) / 8) * 32;   // (tile, quadrant) units, one wave each
 #define GVD_LAUNCH(K) hipLaunchKernelGGL(K, dim3(units), dim3(64), 0, s, a)
-    switch (variant) {
-    case 0: if (da) GVD_LAUNCH((k_render_bwd<true, 0>)); else GVD_LAUNCH((k_render_bwd<false, 0>)); break;
-    case 2: if (da) GVD_LAUNCH((k_render_bwd<true, 8>)); else GVD_LAUNCH((k_render_bwd<false, 8>)); break;
-    default: if (da) GVD_LAUNCH((k_render_bwd<true, 16>)); else GVD_LAUNCH((k_render_bwd<false, 16>)); break;
-    }
+    if (rows8) { if (da) GVD_LAUNCH((k_render_bwd<true, 8>)); else GVD_LAUNCH((k_render_bwd<false, 8>)); }
+    else { if (da) GVD_LAUNCH((k_render_bwd<true, 16>)); else GVD_LAUNCH((k_render_bwd<false, 16>)); }
 #undef GVD_LAUNCH
 }
 void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)

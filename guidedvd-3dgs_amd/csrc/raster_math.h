@@ -246,123 +246,4 @@ __device__ __forceinline__ uint32_t quad_mask(float mx, float my, float conA, fl
     return m;
 }
 
-// Sum of 10 per-lane values over the 64 lanes of a wave, 36 instructions in one hand-scheduled block:
-//   phase 1  v_permlane32_swap pairs (v[k], v[k+5]): after one add, lanes 0-31 carry the lane-pair sums
-//            of v[0..4] and lanes 32-63 those of v[5..9]  (5 swaps + 5 adds instead of 10 x 1 DPP step);
-//   phase 2  5 values x {quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_ror:4, row_ror:8, row_bcast:15}
-//            fused v_add_f32_dpp, interleaved over the 5 values so that every DPP read is >= 4
-//            instructions behind the VALU write of its source (DPP needs 2 wait states).
-// On return v[k] holds, in lane 31, the wave total of input v[k] and, in lane 63, the total of input
-// v[k+5]  (k = 0..4).  v[5..9] are clobbered.  All 64 lanes must be active.
-__device__ __forceinline__ void wave_reduce10(float& v0, float& v1, float& v2, float& v3, float& v4,
-                                              float& v5, float& v6, float& v7, float& v8, float& v9)
-{
-    asm(
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %5\n\t"
-        "v_permlane32_swap_b32 %1, %6\n\t"
-        "v_permlane32_swap_b32 %2, %7\n\t"
-        "v_permlane32_swap_b32 %3, %8\n\t"
-        "v_permlane32_swap_b32 %4, %9\n\t"
-        "v_add_f32 %0, %0, %5\n\t"
-        "v_add_f32 %1, %1, %6\n\t"
-        "v_add_f32 %2, %2, %7\n\t"
-        "v_add_f32 %3, %3, %8\n\t"
-        "v_add_f32 %4, %4, %9\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
-}
-
-// Two entries at once (A = a0..a9, B = b0..b9), 50 instructions instead of 2 x 36:
-//   phase 1  v_permlane32_swap (x[k], x[k+5]) + add : halves hold values k / k+5        (20 instr)
-//   phase 2  v_permlane16_swap (a'[k], b'[k]) + add : rows 0/2 hold entry A, rows 1/3 entry B (10 instr)
-//   phase 3  4 fused DPP steps inside each 16-lane row on the 5 remaining registers   (20 instr)
-// On return a[k] holds in every lane of row 0: total A[k], row 1: total B[k], row 2: total A[k+5],
-// row 3: total B[k+5].  a5..a9 and b0..b9 are clobbered.  All 64 lanes must be active.
-__device__ __forceinline__ void wave_reduce20(float& a0, float& a1, float& a2, float& a3, float& a4,
-                                              float& a5, float& a6, float& a7, float& a8, float& a9,
-                                              float& b0, float& b1, float& b2, float& b3, float& b4,
-                                              float& b5, float& b6, float& b7, float& b8, float& b9)
-{
-    asm("s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %5\n\t"
-        "v_permlane32_swap_b32 %1, %6\n\t"
-        "v_permlane32_swap_b32 %2, %7\n\t"
-        "v_permlane32_swap_b32 %3, %8\n\t"
-        "v_permlane32_swap_b32 %4, %9\n\t"
-        "v_permlane32_swap_b32 %10, %15\n\t"
-        "v_permlane32_swap_b32 %11, %16\n\t"
-        "v_permlane32_swap_b32 %12, %17\n\t"
-        "v_permlane32_swap_b32 %13, %18\n\t"
-        "v_permlane32_swap_b32 %14, %19\n\t"
-        "v_add_f32 %0, %0, %5\n\t"
-        "v_add_f32 %1, %1, %6\n\t"
-        "v_add_f32 %2, %2, %7\n\t"
-        "v_add_f32 %3, %3, %8\n\t"
-        "v_add_f32 %4, %4, %9\n\t"
-        "v_add_f32 %10, %10, %15\n\t"
-        "v_add_f32 %11, %11, %16\n\t"
-        "v_add_f32 %12, %12, %17\n\t"
-        "v_add_f32 %13, %13, %18\n\t"
-        "v_add_f32 %14, %14, %19\n\t"
-        "v_permlane16_swap_b32 %0, %10\n\t"
-        "v_permlane16_swap_b32 %1, %11\n\t"
-        "v_permlane16_swap_b32 %2, %12\n\t"
-        "v_permlane16_swap_b32 %3, %13\n\t"
-        "v_permlane16_swap_b32 %4, %14\n\t"
-        "v_add_f32 %0, %0, %10\n\t"
-        "v_add_f32 %1, %1, %11\n\t"
-        "v_add_f32 %2, %2, %12\n\t"
-        "v_add_f32 %3, %3, %13\n\t"
-        "v_add_f32 %4, %4, %14\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9),
-          "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7), "+v"(b8), "+v"(b9));
-}
-
 }  // namespace gvd
