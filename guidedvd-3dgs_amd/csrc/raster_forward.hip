@@ -28,6 +28,14 @@
 
 namespace gvd {
 
+// experiments (tests/scripts/r5_fwd_trace.py): per-workgroup stamps of k_render_fwd.  Compiled only with -DGVD_RFWD_TRACE.
+#ifdef GVD_RFWD_TRACE
+__device__ unsigned long long g_ftrace[4096 * 8];
+#define GVD_FT(i, v) do { if (blockIdx.x < 4096) g_ftrace[blockIdx.x * 8 + (i)] = (v); } while (0)
+#else
+#define GVD_FT(i, v) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // small wave/block helpers
 // ------------------------------------------------------------------------------------------------
@@ -610,6 +618,10 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;  // overflowed forward: render background, status already flagged
     const uint32_t n = r1 - r0;
+#ifdef GVD_RFWD_TRACE
+    const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) { GVD_FT(0, __builtin_amdgcn_s_memrealtime()); GVD_FT(3, (unsigned long long)n); }
+#endif
 
     // ---- fused per-tile sort (the k_sort_tiles<0> work, done by the workgroup that consumes the list) ----
     // A separate sort launch lasts as long as its longest list (a chain of barrier-separated LDS stages) while most
@@ -631,6 +643,9 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         }
     }
     // ---- from here on no workgroup barrier: each wave blends its quadrant on its own ----
+#ifdef GVD_RFWD_TRACE
+    const unsigned long long tf1 = __builtin_amdgcn_s_memtime();
+#endif
 
     float T = inside ? 1.0f : 0.0f, T_keep = 1.0f;   // live transmittance (0 = pixel finished) / value kept for the background
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, D = 0.f;
@@ -734,6 +749,14 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
         a.out_alpha[pid] = weight;
         a.out_depth[pid] = D;
     }
+#ifdef GVD_RFWD_TRACE
+    if (lane == 0) {
+        GVD_FT(4 + w, __builtin_amdgcn_s_memtime() - tf1);                 // this wave's blend phase
+        if (w == 0) { GVD_FT(2, tf1 - tf0); }                               // the sort phase
+        unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&g_ftrace[blockIdx.x * 8 + 1], t1);                       // last wave out
+    }
+#endif
 }
 
 // rasterizer_impl.cu:54-66 (checkFrustum)
@@ -807,3 +830,16 @@ void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, u
 }
 
 }  // namespace gvd
+
+#ifdef GVD_RFWD_TRACE
+extern "C" int gvd_debug_ftrace_read(unsigned long long* dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gvd::g_ftrace), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int gvd_debug_ftrace_clear(void)
+{
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(gvd::g_ftrace)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
