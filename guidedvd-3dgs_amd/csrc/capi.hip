@@ -477,6 +477,10 @@ int gvd_raster_backward_conf(
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = background; ra.alphas = alphas;
     ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials; ra.pflags = pflags; ra.qmask = (const uint8_t*)(bin + L.qmask);
     {
+        static const int split = getenv("GVD_BWD_SPLIT") ? atoi(getenv("GVD_BWD_SPLIT")) : 512;   // 0: no split (A/B)
+        ra.split_len = (uint32_t)split;
+    }
+    {
         ProfScope ps("render_bwd", stream);
         launch_render_bwd(ra, L.T, stream);
     }

@@ -27,8 +27,8 @@ constexpr int kNV = 10;  // reduced values per (Gaussian, tile)
 // experiments (tests/scripts/r5_bwd_trace.py): per-workgroup stamps of k_render_bwd -- s_memrealtime at entry / exit, XCC + HW ids,
 // the tile's walk length, and each wave's s_memtime cycles inside the walk.  Compiled only with -DGVD_RBWD_TRACE.
 #ifdef GVD_RBWD_TRACE
-__device__ unsigned long long g_rtrace[8192 * 8];
-#define GVD_RT(i, v) do { if (blockIdx.x < 8192) g_rtrace[blockIdx.x * 8 + (i)] = (v); } while (0)
+__device__ unsigned long long g_rtrace[32768 * 8];
+#define GVD_RT(i, v) do { if (blockIdx.x < 32768) g_rtrace[blockIdx.x * 8 + (i)] = (v); } while (0)
 #else
 #define GVD_RT(i, v) do { } while (0)
 #endif
@@ -73,11 +73,14 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     __shared__ float2 s_qw[kRows][kStride];
     __shared__ float4 s_dl[64];               // the wave's pixels' (dL_dpix rgb, dL_ddepth)
 
-    // unit -> (tile, quadrant): 32 consecutive units are 8 consecutive positions of tile_order x 4 quadrants, so that unit u and
+    // unit -> (tile, quadrant, segment): 128 consecutive units are 8 consecutive positions of tile_order x 4 quadrants x 4, so that unit u and
     // position p agree modulo 8 -- the XCD a workgroup lands on and the image region k_tilescan dealt to that position (its L2).
+    // Bits 5-6 of the unit index are the SEGMENT: a quadrant whose walk is longer than a.split_len entries is cut into up to
+    // kMaxSeg units (below).
     const uint32_t unit = blockIdx.x;
-    const uint32_t pos = (unit >> 5) * 8u + (unit & 7u);
+    const uint32_t pos = (unit >> 7) * 8u + (unit & 7u);
     const int quad = (int)((unit >> 3) & 3u);
+    const uint32_t seg = (unit >> 5) & 3u;
     if (pos >= (uint32_t)(a.gx * a.gy)) return;
     const int tile = (int)a.tile_order[pos];
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -108,6 +111,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     const uint32_t r0 = a.ranges[2 * tile];
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;
+    if (seg && (a.split_len == 0 || r1 - r0 <= a.split_len)) return;   // a short list has one segment: the others leave before touching a pixel
 
     const float T_final = inside ? (1.f - a.alphas[pid]) : 0.f;
     float T = T_final;
@@ -137,6 +141,20 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     if (n_walk == 0 && lane == 0) GVD_RT(1, __builtin_amdgcn_s_memrealtime());
 #endif
     if (n_walk == 0) return;
+    // LONG WALKS ARE CUT INTO SEGMENTS, ONE UNIT EACH.  The launch lasts at least as long as its longest unit -- a serial per-pixel chain
+    // of ~0.1 us per list entry, 1100 entries on the C2 view against a mean of 360 (profiles/r05_bwd_trace_*) -- and the machine drains
+    // behind it.  A walk of more than split_len entries is cut into nseg = min(4, ceil(n_walk / split_len)) parts at multiples of 64.
+    // The unit of part s first REPLAYS everything behind its part, [end_s, n_walk), in a light pass that keeps only the per-pixel
+    // recurrences (T, accum_rec, last_*: the same instructions in the same order, so the state it arrives with is bit-identical to
+    // the sequential walk's -- no checkpoint from the forward, no change in any result), then walks its own part in full.  A light
+    // step is ~32 of the ~74 VALU instructions of a full one.
+    constexpr uint32_t kMaxSeg = 4;
+    uint32_t nseg = 1;
+    if (a.split_len && n_walk > a.split_len) nseg = min(kMaxSeg, (n_walk + a.split_len - 1u) / a.split_len);
+    if (seg >= nseg) return;
+    const uint32_t per = (((n_walk + nseg - 1u) / nseg) + 63u) & ~63u;        // wave-uniform; parts are multiples of 64 entries
+    const uint32_t part_lo = min(seg * per, n_walk), part_hi = min(part_lo + per, n_walk);
+    if (part_lo >= part_hi) return;
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_d = 0.f, acc_a = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
@@ -160,21 +178,26 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GVD_BWD_FETCH(BASE)                                                                       \
     n_keep = false;                                                                               \
-    if ((BASE) + (uint32_t)lane < n_walk) {                                                       \
-        n_ord = n_walk - 1u - (BASE) - (uint32_t)lane;  /* value of `contributor` after its decrement */ \
+    if ((BASE) + (uint32_t)lane < hi - lo) {                                                      \
+        n_ord = hi - 1u - (BASE) - (uint32_t)lane;  /* value of `contributor` after its decrement */ \
         n_id = a.point_list[r0 + n_ord];                                                          \
         n_keep = my_mask[n_ord] != 0;                                                             \
         if (n_keep) {                                                                             \
             n_xy = reinterpret_cast<const float2*>(a.means2D)[n_id];                              \
             n_co = reinterpret_cast<const float4*>(a.conic_opacity)[n_id];                        \
             n_cd = reinterpret_cast<const float4*>(a.rgbd)[n_id];                                 \
-            n_rad = a.radii[n_id];                                                                \
-            n_poff = n_id ? a.point_offsets[n_id - 1] : 0u;                                       \
+            if (!LIGHT) {                                                                         \
+                n_rad = a.radii[n_id];                                                            \
+                n_poff = n_id ? a.point_offsets[n_id - 1] : 0u;                                   \
+            }                                                                                     \
         }                                                                                         \
     }
+  // entries [lo, hi) of the list, back to front; LIGHT: recurrences only (no gradient terms, no sub-records)
+  auto run = [&](const uint32_t lo, const uint32_t hi, auto light_tag) {
+    constexpr bool LIGHT = decltype(light_tag)::value;
     GVD_BWD_FETCH(0u)
 
-    for (uint32_t base = 0; base < n_walk; base += 64) {
+    for (uint32_t base = 0; base < hi - lo; base += 64) {
 #ifdef GVD_RBWD_TRACE
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -185,8 +208,11 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
         if (keep) {
             const uint32_t slot = (uint32_t)__popcll(m & below);
             // the instance's sub-record: slot in Gaussian order (point_offsets[id - 1] + row-major index of the tile in the rect), x 4 + quadrant
-            const int4 r = get_rect(n_xy.x, n_xy.y, n_rad, a.gx, a.gy);
-            const uint32_t g = n_poff + (uint32_t)((ty - r.y) * (r.z - r.x) + (tx - r.x));
+            uint32_t g = 0;
+            if (!LIGHT) {
+                const int4 r = get_rect(n_xy.x, n_xy.y, n_rad, a.gx, a.gy);
+                g = n_poff + (uint32_t)((ty - r.y) * (r.z - r.x) + (tx - r.x));
+            }
             s_rec[2 * slot] = make_float4(n_xy.x, n_xy.y, __uint_as_float(n_ord), __uint_as_float(g * 4u + (uint32_t)quad));
             s_rec[2 * slot + 1] = n_co;
             s_cd[slot] = n_cd;
@@ -223,7 +249,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
             const float one_m_a = 1.f - am;                                                       \
             const float rinv = GVD_BWD_RCP(one_m_a);                                              \
             T = T * rinv;                                                                         \
-            const float wgt = am * T;                                                             \
+            const float wgt = am * T; (void)wgt; (void)gm;                                        \
             const float oml = 1.f - last_alpha;                                                   \
             acc0 = fmaf(oml, acc0, last_alpha * lc0);                                             \
             acc1 = fmaf(oml, acc1, last_alpha * lc1);                                             \
@@ -232,24 +258,26 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
                 acc_d = fmaf(oml, acc_d, last_alpha * last_depth);                                \
                 acc_a = fmaf(oml, acc_a, last_alpha);                                             \
             }                                                                                     \
-            float d_ = (c.x - acc0) * dLp0;                                                       \
-            d_ = fmaf(c.y - acc1, dLp1, d_);                                                      \
-            d_ = fmaf(c.z - acc2, dLp2, d_);                                                      \
-            if (DA) {                                                                             \
-                d_ = fmaf(c.w - acc_d, dLd, d_);                                                  \
-                d_ = fmaf(1.f - acc_a, dLa, d_);                                                  \
-            }                                                                                     \
-            d_ *= T;                                                                              \
-            if (BG) { /* (-T_final / (1 - alpha)) * (bg . dL_dpix): quotient refined by one residual step */ \
-                float qb = nTf * rinv;                                                            \
-                qb = fmaf(fmaf(-one_m_a, qb, nTf), rinv, qb);                                     \
-                d_ = fmaf(qb, bg_dot, d_);                                                        \
+            if (!LIGHT) {                                                                         \
+                float d_ = (c.x - acc0) * dLp0;                                                   \
+                d_ = fmaf(c.y - acc1, dLp1, d_);                                                  \
+                d_ = fmaf(c.z - acc2, dLp2, d_);                                                  \
+                if (DA) {                                                                         \
+                    d_ = fmaf(c.w - acc_d, dLd, d_);                                              \
+                    d_ = fmaf(1.f - acc_a, dLa, d_);                                              \
+                }                                                                                 \
+                d_ *= T;                                                                          \
+                if (BG) { /* (-T_final / (1 - alpha)) * (bg . dL_dpix): quotient refined by one residual step */ \
+                    float qb = nTf * rinv;                                                        \
+                    qb = fmaf(fmaf(-one_m_a, qb, nTf), rinv, qb);                                 \
+                    d_ = fmaf(qb, bg_dot, d_);                                                    \
+                }                                                                                 \
+                float2* row = &s_qw[rows][0];                                                     \
+                row[lane] = make_float2(gm * d_, wgt);                                            \
+                if (lane == 0) row[64] = make_float2(__uint_as_float(SL), 0.f);                   \
+                rows++;                                                                           \
             }                                                                                     \
             lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
-            float2* row = &s_qw[rows][0];                                                         \
-            row[lane] = make_float2(gm * d_, wgt);                                                \
-            if (lane == 0) row[64] = make_float2(__uint_as_float(SL), 0.f);                       \
-            rows++;                                                                               \
         }
         // ---- the turn-around: rows [0, nrows) of the strip -> the entries' sub-records ----
         auto flush = [&](const uint32_t nrows) {
@@ -323,6 +351,9 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
         walk_cycles += tw1 - tw0;
 #endif
     }
+  };
+    if (part_hi < n_walk) run(part_hi, n_walk, std::true_type{});
+    run(part_lo, part_hi, std::false_type{});
 #undef GVD_BWD_FETCH
 #ifdef GVD_RBWD_TRACE
     if (lane == 0) { GVD_RT(5, stage_cycles); GVD_RT(6, walk_cycles); GVD_RT(7, tail_cycles); GVD_RT(1, __builtin_amdgcn_s_memrealtime()); }
@@ -712,7 +743,7 @@ void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 {
     static const int rows8 = getenv("GVD_BWD_ROWS8") ? atoi(getenv("GVD_BWD_ROWS8")) : 0;   // A/B switch (round 5): 8-row strip
     const bool da = a.dL_dpix_depth || a.dL_dalphas;
-    const int units = ((T + 7) / 8) * 32;   // (tile, quadrant) units, one wave each
+    const int units = ((T + 7) / 8) * 128;   // (tile, quadrant, segment) units, one wave each (the extra segments of short lists exit at once)
 #define GVD_LAUNCH(K) hipLaunchKernelGGL(K, dim3(units), dim3(64), 0, s, a)
     if (rows8) { if (da) GVD_LAUNCH((k_render_bwd<true, 8>)); else GVD_LAUNCH((k_render_bwd<false, 8>)); }
     else { if (da) GVD_LAUNCH((k_render_bwd<true, 16>)); else GVD_LAUNCH((k_render_bwd<false, 16>)); }

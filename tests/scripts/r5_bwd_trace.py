@@ -30,7 +30,7 @@ for it in range(4):
     torch.autograd.backward([color], [gC])
 torch.cuda.synchronize()
 L = _C.lib()
-T = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 32   # (tile, quadrant) units
+T = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 128   # (tile, quadrant, segment) units
 buf = (ctypes.c_ulonglong * (T * 8))()
 rc = L.gvd_debug_rtrace_read(buf, ctypes.c_size_t(T * 8))
 assert rc == 0, rc
