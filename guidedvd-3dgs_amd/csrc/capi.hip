@@ -112,6 +112,8 @@ struct SpecHint { int P, W, H; uint32_t r_max, list_max; };
 std::mutex g_spec_mu;
 std::vector<SpecHint> g_hints;
 std::atomic<int> g_spec_opt_in{0};
+// k_render_bwd: quadrant walks longer than this are cut into units (raster_backward.hip); GVD_BWD_SPLIT / gvd_raster_set_backward_split
+std::atomic<int> g_bwd_split{ getenv("GVD_BWD_SPLIT") ? atoi(getenv("GVD_BWD_SPLIT")) : 512 };
 // gvd_raster_expect_backward: per host thread; 1 (default) = every forward prepares its binning chunk for a backward
 thread_local int t_expect_backward = 1;
 
@@ -315,6 +317,7 @@ uint32_t gvd_raster_binning_capacity(size_t binning_chunk_bytes)
 }
 
 void gvd_raster_set_speculation(int on) { g_spec_opt_in.store(on ? 1 : 0, std::memory_order_relaxed); }
+void gvd_raster_set_backward_split(int entries) { g_bwd_split.store(entries > 0 ? entries : 0, std::memory_order_relaxed); }
 void gvd_raster_expect_backward(int yes) { t_expect_backward = yes ? 1 : 0; }
 
 int gvd_raster_forward(
@@ -476,10 +479,7 @@ int gvd_raster_backward_conf(
     ra.radii = radii; ra.means2D = (const float*)(geom + L.means2D); ra.conic_opacity = (const float*)(geom + L.conic_opacity);
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = background; ra.alphas = alphas;
     ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials; ra.pflags = pflags; ra.qmask = (const uint8_t*)(bin + L.qmask);
-    {
-        static const int split = getenv("GVD_BWD_SPLIT") ? atoi(getenv("GVD_BWD_SPLIT")) : 512;   // 0: no split (A/B)
-        ra.split_len = (uint32_t)split;
-    }
+    ra.split_len = (uint32_t)g_bwd_split.load(std::memory_order_relaxed);
     {
         ProfScope ps("render_bwd", stream);
         launch_render_bwd(ra, L.T, stream);

@@ -63,6 +63,7 @@ def lib():
         L.gvd_raster_binning_capacity.argtypes = [ctypes.c_size_t]
         L.gvd_raster_set_speculation.argtypes = [_I]
         L.gvd_raster_expect_backward.argtypes = [_I]
+        L.gvd_raster_set_backward_split.argtypes = [_I]
         # this binding hands the binning chunk's size to backward, so the forward may lay it out speculatively (gvd_raster.h)
         L.gvd_raster_set_speculation(1)
         L.gvd_raster_mark_visible.restype = _I

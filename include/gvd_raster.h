@@ -104,6 +104,12 @@ void gvd_raster_set_speculation(int on);
  * undefined.  Per host thread, sticky until changed; default 1 (the reference's contract: any forward may be followed by a
  * backward). */
 void gvd_raster_expect_backward(int yes);
+
+/* k_render_bwd cuts a quadrant's walk of more than `entries` list entries into up to four units (MI355X addition; default 512,
+ * 0 = never; also GVD_BWD_SPLIT in the environment).  A performance knob only: the units of a cut walk replay the part behind their
+ * own with the same instructions in the same order, so every gradient is bit-identical for every setting
+ * (tests/test_raster_gpu.py::test_backward_split_walks_are_bit_identical). */
+void gvd_raster_set_backward_split(int entries);
 uint32_t gvd_raster_binning_capacity(size_t binning_chunk_bytes);
 
 /* Sync-free variant (MI355X addition; no reference counterpart): the caller supplies the

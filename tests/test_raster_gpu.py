@@ -233,6 +233,48 @@ def test_operator_autograd_confidence_and_determinism():
     assert torch.allclose(gc["sh"], g1["sh"] * conf[..., None], rtol=1e-6, atol=0)
 
 
+def test_backward_split_walks_are_bit_identical():
+    """k_render_bwd cuts long quadrant walks into units that replay the part behind their own (round 5): a pure scheduling change.
+    The C2 view has lists of 1000+ entries; every gradient must be the same BITS with the cut off, at the default 512 and at 64 (every
+    walk of more than 64 entries in up to four parts) -- through the native boundary with depth / alpha gradients, and through the
+    autograd operator with the colour gradient only (the kernel instantiation without the depth / alpha recurrences)."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    sc = syn.scene_c2()
+    cam = sc["cameras"][1]
+    H, W, P = cam["image_height"], cam["image_width"], sc["means3D"].shape[0]
+    rng = np.random.default_rng(9)
+    grads = tuple(rng.normal(size=s_) / (H * W) for s_ in ((3, H, W), (H, W), (H, W)))
+    dev = torch.device("cuda:0")
+    t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev, requires_grad=rg)
+    st = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], t(sc["bg"]), 1.0, t(cam["viewmatrix"]), t(cam["projmatrix"]),
+                                       sc["sh_degree"], t(cam["campos"]), False, False, torch.ones(P, 1, device=dev))
+    gC = t(grads[0])
+
+    def operator_grads():
+        lv = dict(means3D=t(sc["means3D"], True), opacities=t(sc["opacities"], True), scales=t(sc["scales"], True),
+                  rotations=t(sc["rotations"], True), shs=t(sc["shs"], True), means2D=torch.zeros(P, 3, device=dev, requires_grad=True))
+        color, _, _, _ = GaussianRasterizer(st)(**lv)
+        torch.autograd.backward([color], [gC])
+        return {k: v.grad.cpu().numpy() for k, v in lv.items()}
+
+    L = _C.lib()
+    try:
+        ref_n = ref_o = None
+        for split in (0, 512, 64):
+            L.gvd_raster_set_backward_split(split)
+            _, g_n = run_hip(sc, cam, grads)
+            g_o = operator_grads()
+            if ref_n is None:
+                ref_n, ref_o = g_n, g_o
+                continue
+            for k in ref_n:
+                assert np.array_equal(ref_n[k], g_n[k]), (split, k)
+            for k in ref_o:
+                assert np.array_equal(ref_o[k], g_o[k]), (split, k)
+    finally:
+        L.gvd_raster_set_backward_split(512)
+
+
 def test_no_grad_renders_skip_the_backward_preparation_and_do_not_disturb_training_renders():
     """gvd_raster_expect_backward (advisor finding, round 2): a no-grad render does not zero the backward's partial records; the
     images are the same bits, and a training render (forward + backward) interleaved with no-grad renders -- same thread, the
