@@ -480,6 +480,9 @@ int gvd_raster_backward_conf(
     ra.rgbd = (const float*)(geom + L.rgbd); ra.bg = background; ra.alphas = alphas;
     ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dalphas = dL_dalphas; ra.partials = partials; ra.pflags = pflags; ra.qmask = (const uint8_t*)(bin + L.qmask);
     ra.split_len = (uint32_t)g_bwd_split.load(std::memory_order_relaxed);
+    // the longest lists come first in tile_order: only the first quarter of the positions can be cut (their extra segment units head the grid)
+    ra.split_positions = ra.split_len ? (uint32_t)((((L.T + 3) / 4) + 7) / 8 * 8) : 0u;
+    ra.extra_units = ra.split_positions * 12u;
     {
         ProfScope ps("render_bwd", stream);
         launch_render_bwd(ra, L.T, stream);

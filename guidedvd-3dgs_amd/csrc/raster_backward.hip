@@ -73,14 +73,26 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     __shared__ float2 s_qw[kRows][kStride];
     __shared__ float4 s_dl[64];               // the wave's pixels' (dL_dpix rgb, dL_ddepth)
 
-    // unit -> (tile, quadrant, segment): 128 consecutive units are 8 consecutive positions of tile_order x 4 quadrants x 4, so that unit u and
-    // position p agree modulo 8 -- the XCD a workgroup lands on and the image region k_tilescan dealt to that position (its L2).
-    // Bits 5-6 of the unit index are the SEGMENT: a quadrant whose walk is longer than a.split_len entries is cut into up to
-    // kMaxSeg units (below).
+        // unit -> (tile, quadrant, segment), such that unit u and tile_order position p agree modulo 8 -- the XCD a workgroup lands on and
+    // the image region k_tilescan dealt to that position (its L2).
+    // The grid is [extra units | main units].  Main unit m: segment 0 of (position (m >> 5) * 8 + (m & 7), quadrant (m >> 3) & 3).
+    // Extra unit e (the first a.extra_units of the grid, so that the extra segments of the LONG lists -- tile_order puts those first --
+    // start with the launch): groups of 96 = 8 positions x 4 quadrants x segments 1..3.  Only the first a.split_positions positions of
+    // tile_order can be cut; both counts are multiples of 8, so every unit u still agrees with its position modulo 8.
     const uint32_t unit = blockIdx.x;
-    const uint32_t pos = (unit >> 7) * 8u + (unit & 7u);
-    const int quad = (int)((unit >> 3) & 3u);
-    const uint32_t seg = (unit >> 5) & 3u;
+    uint32_t pos, seg;
+    int quad;
+    if (unit < a.extra_units) {
+        const uint32_t grp = unit / 96u, in = unit - grp * 96u;
+        pos = grp * 8u + (in & 7u);
+        quad = (int)((in >> 3) & 3u);
+        seg = 1u + (in >> 5);
+    } else {
+        const uint32_t m = unit - a.extra_units;
+        pos = (m >> 5) * 8u + (m & 7u);
+        quad = (int)((m >> 3) & 3u);
+        seg = 0u;
+    }
     if (pos >= (uint32_t)(a.gx * a.gy)) return;
     const int tile = (int)a.tile_order[pos];
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -111,7 +123,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     const uint32_t r0 = a.ranges[2 * tile];
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;
-    if (seg && (a.split_len == 0 || r1 - r0 <= a.split_len)) return;   // a short list has one segment: the others leave before touching a pixel
+    if (seg && r1 - r0 <= a.split_len) return;   // a short list has one segment: the others leave before touching a pixel
 
     const float T_final = inside ? (1.f - a.alphas[pid]) : 0.f;
     float T = T_final;
@@ -150,7 +162,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
     // step is ~32 of the ~74 VALU instructions of a full one.
     constexpr uint32_t kMaxSeg = 4;
     uint32_t nseg = 1;
-    if (a.split_len && n_walk > a.split_len) nseg = min(kMaxSeg, (n_walk + a.split_len - 1u) / a.split_len);
+    if (pos < a.split_positions && n_walk > a.split_len) nseg = min(kMaxSeg, (n_walk + a.split_len - 1u) / a.split_len);
     if (seg >= nseg) return;
     const uint32_t per = (((n_walk + nseg - 1u) / nseg) + 63u) & ~63u;        // wave-uniform; parts are multiples of 64 entries
     const uint32_t part_lo = min(seg * per, n_walk), part_hi = min(part_lo + per, n_walk);
@@ -743,7 +755,7 @@ void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 {
     static const int rows8 = getenv("GVD_BWD_ROWS8") ? atoi(getenv("GVD_BWD_ROWS8")) : 0;   // A/B switch (round 5): 8-row strip
     const bool da = a.dL_dpix_depth || a.dL_dalphas;
-    const int units = ((T + 7) / 8) * 128;   // (tile, quadrant, segment) units, one wave each (the extra segments of short lists exit at once)
+    const int units = (int)a.extra_units + ((T + 7) / 8) * 32;   // extra segments of the first split_positions tiles, then one unit per (tile, quadrant)
 #define GVD_LAUNCH(K) hipLaunchKernelGGL(K, dim3(units), dim3(64), 0, s, a)
     if (rows8) { if (da) GVD_LAUNCH((k_render_bwd<true, 8>)); else GVD_LAUNCH((k_render_bwd<false, 8>)); }
     else { if (da) GVD_LAUNCH((k_render_bwd<true, 16>)); else GVD_LAUNCH((k_render_bwd<false, 16>)); }

@@ -70,7 +70,8 @@ struct RenderBwdArgs {
     float* partials;  // [R][4 quadrants][12]
     uint32_t* pflags; // [R]: byte q set = sub-record (instance, q) written
     const uint8_t* qmask;  // [4][capacity]: the forward's quadrant cull bits
-    uint32_t split_len;    // quadrant walks longer than this many entries are cut into up to 4 units of about this length (0: never)
+    uint32_t split_len;    // quadrant walks longer than this many entries are cut into up to 4 units of about this length ...
+    uint32_t split_positions, extra_units;   // ... for the first split_positions positions of tile_order (multiple of 8); extra_units = 12 x that, the head of the grid
 };
 
 struct GatherBwdArgs {

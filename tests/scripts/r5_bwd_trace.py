@@ -30,7 +30,7 @@ for it in range(4):
     torch.autograd.backward([color], [gC])
 torch.cuda.synchronize()
 L = _C.lib()
-T = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 128   # (tile, quadrant, segment) units
+T = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 32 + (((((W + 15) // 16) * ((H + 15) // 16) + 3) // 4 + 7) // 8 * 8) * 12   # extra segment units + (tile, quadrant) units
 buf = (ctypes.c_ulonglong * (T * 8))()
 rc = L.gvd_debug_rtrace_read(buf, ctypes.c_size_t(T * 8))
 assert rc == 0, rc
