@@ -247,7 +247,10 @@ __device__ __forceinline__ int xcd_region(int t, int gx)
     return ((tx >> 1) + 3 * (ty >> 1)) & 7;
 }
 
-template <int NT>
+// ROLE bit 0: ranges, cursors, num_rendered / longest list / overflow (scalars, status, host mirror), per-block instance bases;
+// ROLE bit 1: tile_order.  k_tilescan does both in one workgroup; inside the k_scatter launch two workgroups share the job, so that the
+// single-workgroup chain of dependent steps (~24 us at 256 threads) is two shorter ones side by side -- and the host's ticket is out early.
+template <int NT, int ROLE>
 __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
 {
     __shared__ uint32_t s_w[NT / 64];
@@ -256,7 +259,7 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
     __shared__ uint32_t s_rcount[8];
     const int tid = threadIdx.x;
     if (tid == 0) s_max = 0;
-    for (int i = tid; i < 8 * 256; i += NT) (&s_bins[0][0])[i] = 0;
+    if (ROLE & 2) for (int i = tid; i < 8 * 256; i += NT) (&s_bins[0][0])[i] = 0;
     __syncthreads();
     // ---- tiles ----
     // Every global value this block needs is fetched once, up front and together (one round trip; the kernel is a single
@@ -271,10 +274,12 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
 #pragma unroll
     for (int i = 0; i < kKeep; i++) kept[i] = (t0 + i < t1) ? a.tile_count[t0 + i] : 0u;
     uint32_t lb = 0, first_bt = 0;
-    for (int b = b0; b < b1; b++) {
-        const uint32_t x = a.block_total[b];
-        if (b == b0) first_bt = x;
-        lb += x;
+    if (ROLE & 1) {
+        for (int b = b0; b < b1; b++) {
+            const uint32_t x = a.block_total[b];
+            if (b == b0) first_bt = x;
+            lb += x;
+        }
     }
 #define GVD_TILE_COUNT(T_, I_) ((I_) < kKeep ? kept[(I_) < kKeep ? (I_) : 0] : a.tile_count[T_])
     uint32_t local = 0, lmax = 0;
@@ -284,19 +289,24 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
         local += c;
         lmax = max(lmax, c);
     }
-    uint32_t total;
-    uint32_t run = block_excl_scan<NT>(local, s_w, &total);
+    uint32_t total = 0;
+    if (ROLE & 1) {
+        uint32_t run = block_excl_scan<NT>(local, s_w, &total);
 #pragma unroll 4
-    for (int t = t0, i = 0; t < t1; t++, i++) {
-        const uint32_t c = GVD_TILE_COUNT(t, i);
-        // untouched tiles stay (0,0) like the reference's memset (rasterizer_impl.cu:311)
-        a.ranges[2 * t] = c ? run : 0u;
-        a.ranges[2 * t + 1] = c ? run + c : 0u;
-        if (a.cursor) a.cursor[t] = run;
-        run += c;
-        atomicAdd(&s_bins[xcd_region(t, a.gx)][cost_bucket(c)], 1u);
+        for (int t = t0, i = 0; t < t1; t++, i++) {
+            const uint32_t c = GVD_TILE_COUNT(t, i);
+            // untouched tiles stay (0,0) like the reference's memset (rasterizer_impl.cu:311)
+            a.ranges[2 * t] = c ? run : 0u;
+            a.ranges[2 * t + 1] = c ? run + c : 0u;
+            if (a.cursor) a.cursor[t] = run;
+            run += c;
+        }
+        if (lmax) atomicMax(&s_max, lmax);
     }
-    if (lmax) atomicMax(&s_max, lmax);
+    if (ROLE & 2) {
+#pragma unroll 4
+        for (int t = t0, i = 0; t < t1; t++, i++) atomicAdd(&s_bins[xcd_region(t, a.gx)][cost_bucket(GVD_TILE_COUNT(t, i))], 1u);
+    }
     // ---- tile_order: the blend kernels' workgroup b works on tile_order[b].  Two goals:
     //   * longest lists first (LPT), so that the tail of the launch is short;
     //   * XCD locality: block b is observed to run on XCD b % 8 and every XCD has its own L2, so position b gets a
@@ -305,7 +315,7 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
     //   Within a region tiles are ranked by a 256-bucket counting sort on the list length; rank r of region x goes to
     //   position 8 r + x.  The ranks beyond the smallest region's size fill the end of the order. ----
     __syncthreads();
-    {
+    if (ROLE & 2) {
         const int w = tid >> 6, lane = tid & 63;
         for (int rg = w; rg < 8; rg += NT / 64) {   // a wave per region: exclusive scan of the region's 256 buckets (4 per lane)
             uint32_t v[4], sum = 0;
@@ -336,6 +346,7 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
         }
     }
 #undef GVD_TILE_COUNT
+    if (!(ROLE & 1)) return;
     // ---- per-block instance bases (exclusive scan of block_total) ----
     uint32_t totb;
     uint32_t runb = block_excl_scan<NT>(lb, s_w, &totb);
@@ -358,7 +369,7 @@ __device__ __forceinline__ void tilescan_body(const TileScanArgs& a)
     }
 }
 
-__global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a) { tilescan_body<1024>(a); }
+__global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a) { tilescan_body<1024, 3>(a); }
 
 // (A merged k_colscan + k_tilescan launch -- the last column-scan workgroup to arrive, by an agent-scope fence and a
 // counter, runs the tile scan -- was measured at 61 us against 8.6 + 12.3 us for the two launches: on a multi-XCD part the
@@ -367,8 +378,8 @@ __global__ void __launch_bounds__(1024) k_tilescan(TileScanArgs a) { tilescan_bo
 // ------------------------------------------------------------------------------------------------
 // k_scatter
 // ------------------------------------------------------------------------------------------------
-// FUSED (round 5; LDS_HIST only): the launch carries the tile scan.  Workgroup 0 runs tilescan_body (ranges, tile_order,
-// num_rendered, the host mirror) for the kernels that follow; every scatter workgroup derives what IT needs from the same two
+// FUSED (round 5; LDS_HIST only): the launch carries the tile scan.  Workgroups 0 and 1 run tilescan_body's two roles (ranges,
+// num_rendered, the host mirror | tile_order) for the kernels that follow; every scatter workgroup derives what IT needs from the same two
 // small arrays itself -- the exclusive scan of the T tile totals (its LDS cursors) and the sum of the block totals in front of it
 // (its instance base) -- 6 KB of L2 reads and one extra barrier per workgroup instead of a single-workgroup k_tilescan launch
 // (12 us of dependent round trips on one CU + a launch boundary) between k_colscan and k_scatter.
@@ -379,11 +390,12 @@ __global__ void __launch_bounds__(256) k_scatter(ScatterArgs a, TileScanArgs ts)
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bw[4];
     const int tid = threadIdx.x;
-    if (FUSED && blockIdx.x == 0) {
-        tilescan_body<256>(ts);
+    if (FUSED && blockIdx.x < 2) {   // (wave-uniform) the tile scan's two roles, side by side
+        if (blockIdx.x == 0) tilescan_body<256, 1>(ts);
+        else tilescan_body<256, 2>(ts);
         return;
     }
-    const int blk = FUSED ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    const int blk = FUSED ? (int)blockIdx.x - 2 : (int)blockIdx.x;
     uint32_t my_base = 0;
     if (LDS_HIST && FUSED) {
         const uint32_t* row = a.hist + (size_t)blk * a.T;
@@ -790,7 +802,7 @@ void launch_scatter(const ScatterArgs& a, const TileScanArgs* fused_scan, int bl
 {
     TileScanArgs ts{};
     if (fused_scan) ts = *fused_scan;
-    if (lds_hist && fused_scan) hipLaunchKernelGGL((k_scatter<true, true>), dim3(blocks + 1), dim3(256), (size_t)a.T * 4, s, a, ts);
+    if (lds_hist && fused_scan) hipLaunchKernelGGL((k_scatter<true, true>), dim3(blocks + 2), dim3(256), (size_t)a.T * 4, s, a, ts);
     else if (lds_hist) hipLaunchKernelGGL((k_scatter<true, false>), dim3(blocks), dim3(256), (size_t)a.T * 4, s, a, ts);
     else hipLaunchKernelGGL((k_scatter<false, false>), dim3(blocks), dim3(256), 0, s, a, ts);
 }
