@@ -79,9 +79,17 @@ def _err(code):
     return RuntimeError(f"gvd_raster error {code}: {msg.decode() if msg else '?'}")
 
 
+_F32 = torch.float32
+
+
 def _dev_f32(t, name, device):
-    """float32 contiguous tensor on `device`, or None for an empty ('absent') tensor."""
-    if t is None or t.numel() == 0:
+    """float32 contiguous tensor on `device`, or None for an empty ('absent') tensor.  (The common case -- right device, float32,
+    contiguous -- is three attribute reads; this function runs ~26 times per training iteration, on the path that feeds the GPU.)"""
+    if t is None:
+        return None
+    if t.device == device and t.dtype is _F32 and t.is_contiguous():
+        return t if t.numel() else None
+    if t.numel() == 0:
         return None
     if t.device != device:
         raise RuntimeError(f"{name} is on {t.device}, expected {device} (no CPU path in this build)")
@@ -245,19 +253,32 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 
 # The backward's ten gradient arrays, carved from ONE allocation, 256-byte aligned starts; the kernels write every element.
-_GRAD_WIDTHS = lambda M: (3, 3, 3, 1, 4, 1, 6, 3 * M, 3, 4)
+_GRAD_LAYOUTS = {}
+
+
+def _grad_layout(P, M):
+    """(total floats, [(shape, stride, offset)] x 10) -- computed once per (P, M)."""
+    lay = _GRAD_LAYOUTS.get((P, M))
+    if lay is None:
+        shapes = ((P, 3), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4))
+        items, total = [], 0
+        for sh in shapes:
+            n, stride = 1, []
+            for d in reversed(sh):
+                stride.append(n)
+                n *= d
+            items.append((sh, tuple(reversed(stride)), total))
+            total += (n + 63) & ~63
+        if len(_GRAD_LAYOUTS) > 64:
+            _GRAD_LAYOUTS.clear()
+        lay = _GRAD_LAYOUTS[(P, M)] = (max(total, 1), tuple(items))
+    return lay
 
 
 def _grad_arrays(P, M, dev):
-    widths = _GRAD_WIDTHS(M)
-    offs, total = [], 0
-    for w_ in widths:
-        offs.append(total)
-        total += (P * w_ + 63) & ~63
-    flat = torch.empty((max(total, 1),), dtype=torch.float32, device=dev)
-    cut = lambda i, *shape: flat[offs[i]:offs[i] + P * widths[i]].view(shape)
-    return (cut(0, P, 3), cut(1, P, 3), cut(2, P, 3), cut(3, P, 1), cut(4, P, 2, 2), cut(5, P, 1), cut(6, P, 6), cut(7, P, M, 3),
-            cut(8, P, 3), cut(9, P, 4))
+    total, items = _grad_layout(P, M)
+    flat = torch.empty((total,), dtype=torch.float32, device=dev)
+    return tuple(flat.as_strided(sh, st, off) for sh, st, off in items)
 
 
 # A forward that expects a backward allocates the backward's outputs BEFORE its native call -- while the GPU still works on the

@@ -28,6 +28,9 @@ import torch.nn as nn
 from . import _C
 
 
+_ABSENT = torch.Tensor([])   # one shared "not given" tensor (never written)
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -124,7 +127,7 @@ class GaussianRasterizer(nn.Module):
         has_sr = scales is not None or rotations is not None
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        absent = torch.Tensor([])  # empty tensor == "not given" at the native boundary
+        absent = _ABSENT  # empty tensor == "not given" at the native boundary
         pick = lambda t: absent if t is None else t
         return rasterize_gaussians(means3D, means2D, pick(shs), pick(colors_precomp), opacities, pick(scales),
                                    pick(rotations), pick(cov3D_precomp), self.raster_settings)
