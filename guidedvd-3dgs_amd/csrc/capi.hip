@@ -147,7 +147,9 @@ bool capacity_of_bytes(size_t bytes, uint32_t* cap_out)
         if (gvd::make_layout(0, 16, 16, mid).bin_bytes < bytes) lo = mid + 1; else hi = mid;
     }
     if (gvd::make_layout(0, 16, 16, lo).bin_bytes != bytes) return false;
-    *cap_out = lo;
+    // capacities 0 and 1 share one layout (every sub-array holds at least one element): report 1, or a chunk that holds exactly one
+    // instance would come back as "smaller than num_rendered requires" (found by tests/scripts/r5_raster_stress.py: P = 1, R = 1)
+    *cap_out = lo ? lo : 1u;
     return true;
 }
 inline int sort_class_of(uint32_t max_list) { return max_list > 16384 ? 2 : (max_list > 2048 ? 1 : 0); }

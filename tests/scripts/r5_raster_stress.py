@@ -1,0 +1,59 @@
+"""Raster operator stress (round 5): changing point counts (densification-like), image sizes from 17 x 17 to 2064 x 1616 (more than 12288
+tiles: the global-histogram path with the separate tile scan), SH degrees, mixed no-grad renders, every configuration rendered twice --
+images and gradients must be bit-identical between the two runs and finite.  Exercises the speculation hints (16-entry table), the parked
+gradient arrays, the walk cut, the fused two-role tile scan with tile counts that are not multiples of 8."""
+import math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "guidedvd-3dgs_amd"), os.path.join(ROOT, "tests")): sys.path.insert(0, p)
+import numpy as np, torch
+import synthetic as syn
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(7)
+t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=rg)
+
+def scene(P):
+    xyz = rng.normal(size=(P, 3)) * np.array([2.0, 1.5, 2.0]); xyz[:, 2] = np.abs(xyz[:, 2]) + 0.5
+    scales = np.exp(rng.normal(math.log(0.03), 0.5, size=(P, 3)))
+    q = rng.normal(size=(P, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    op = 1 / (1 + np.exp(-rng.normal(0, 2, size=(P, 1))))
+    sh = rng.normal(0, 0.3, size=(P, 16, 3)); sh[:, 0] = syn.rgb2sh(rng.uniform(0, 1, size=(P, 3)))
+    return xyz, scales, q, op, sh
+
+def run(P, W, H, deg, sc, cam, grad, gC):
+    xyz, scales, q, op, sh = sc
+    lv = dict(means3D=t(xyz, grad), opacities=t(op, grad), scales=t(scales, grad), rotations=t(q, grad), shs=t(sh, grad),
+              means2D=torch.zeros(P, 3, device=dev, requires_grad=grad))
+    s = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], t([0.1, 0.2, 0.3]), 1.0, t(cam["viewmatrix"]), t(cam["projmatrix"]),
+                                      deg, t(cam["campos"]), False, False, torch.ones(P, 1, device=dev))
+    if not grad:
+        with torch.no_grad():
+            c, r, d, a = GaussianRasterizer(s)(**lv)
+        return c, None
+    c, r, d, a = GaussianRasterizer(s)(**lv)
+    torch.autograd.backward([c, d], [gC, gC[:1] * 0.1])
+    return c.detach(), {k: v.grad for k, v in lv.items()}
+
+n = 0
+sizes = [(17, 17), (64, 48), (200, 120), (333, 257), (640, 480), (1000, 31), (2064, 1616)]
+for it in range(60):
+    P = int(rng.choice([1, 50, 3000, 20000, 60000]))
+    W, H = sizes[int(rng.integers(0, len(sizes)))] if it % 10 else sizes[-1]
+    deg = int(rng.integers(0, 4))
+    sc = scene(P)
+    eye = rng.normal(size=3) * 0.3 - np.array([0, 0, 3.0])
+    cam = syn.make_camera(syn.look_at(tuple(eye), (0.0, 0.0, 1.0)), math.radians(rng.uniform(40, 90)), math.radians(rng.uniform(35, 80)), W, H)
+    gC = torch.randn(3, H, W, device=dev) / (H * W)
+    outs = []
+    print(f"it {it}: P {P} {W}x{H} deg {deg}", flush=True)
+    for rep in range(2):
+        if rng.random() < 0.3:
+            run(P, W, H, deg, sc, cam, False, gC)            # a no-grad render in between (skips the backward preparation)
+        outs.append(run(P, W, H, deg, sc, cam, True, gC))
+    (c0, g0), (c1, g1) = outs
+    assert torch.isfinite(c0).all() and torch.equal(c0, c1), (it, P, W, H)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all() and torch.equal(g0[k], g1[k]), (it, P, W, H, k)
+    n += 1
+torch.cuda.synchronize()
+print(f"raster stress: {n} configurations x 2 runs, images and gradients finite and bit-identical between runs")

@@ -107,3 +107,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "raster_oracle" not in src and "oracle/" not in src.replace("CPU oracle", ""), os.path.join(dp, f)
+
+
+def test_binning_capacity_inverts_binning_bytes_and_never_reports_less_than_it_holds(capi):
+    """gvd_raster_backward_conf decodes the capacity a binning chunk was laid out for from its byte size.  Capacities 0 and 1 share a
+    layout (every sub-array holds at least one element); the decode must report 1 there -- a chunk holding exactly ONE instance was
+    rejected as too small (round 5, found by tests/scripts/r5_raster_stress.py).  Sizes that are no chunk size decode to 0xffffffff."""
+    L = capi.lib()
+    L.gvd_raster_binning_capacity.restype = ctypes.c_uint32
+    L.gvd_raster_binning_capacity.argtypes = [ctypes.c_size_t]
+    prev = 0
+    for r in (0, 1, 2, 3, 7, 64, 1000, 436438, 5_000_000):
+        b = L.gvd_raster_binning_bytes(r)
+        assert b >= prev
+        prev = b
+        cap = L.gvd_raster_binning_capacity(b)
+        assert cap == max(r, 1), (r, cap)
+        assert L.gvd_raster_binning_capacity(b + 4) == 0xffffffff

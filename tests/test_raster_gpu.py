@@ -166,6 +166,22 @@ def test_empty_and_fully_culled():
     assert all(float(x.abs().max()) == 0.0 for x in g if x.numel())
 
 
+def test_one_instance_scene():
+    """num_rendered == 1: one small Gaussian inside one tile.  Capacities 0 and 1 of the binning chunk share a byte size, and the
+    backward used to decode such a chunk as capacity 0 and refuse it (round 5, tests/scripts/r5_raster_stress.py)."""
+    sc = _tiny(11, P=1, W=17, H=17, deg=1)
+    sc["means3D"][:] = np.array([[0.05, 0.12, 3.0]], np.float32)
+    sc["scales"][:] = 0.004
+    sc["opacities"][:] = 0.8
+    cam = sc["cameras"][0] = syn.make_camera(syn.look_at((0.0, 0.0, 0.0), (0.0, 0.1, 3.0)), math.radians(70), math.radians(55), 17, 17)
+    grads = _grads(17, 17, 3)
+    st_o, g_o = run_oracle(sc, cam, grads)
+    assert int(st_o["R"]) == 1
+    st_h, g_h = run_hip(sc, cam, grads, debug=True)
+    _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=5e-4)
+    assert np.abs(g_h["dL_dmeans3D"]).max() > 0
+
+
 @pytest.mark.parametrize("P,expect_max", [(3000, 2048), (18000, 16384)])
 def test_long_tile_lists_exercise_lds_and_global_sort(P, expect_max):
     # many Gaussians piled into a 32x32 image: tile lists longer than the 2048-entry (LDS class 0)
