@@ -22,6 +22,7 @@ DDIM step (2 U-Net forwards + the fused update).  N > 1: CFG pair x frame shards
 Both carry `roofline` (dominant kernel, HIP-event timed inside the timed region) and `cpu_baseline` (host cores; baseline only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -851,9 +852,12 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         return o
 
     # ---- timed region: the product path, nothing else on the stream (no per-kernel event pairs) ----
+    mark = (lambda tag: ops.lib().gvd_profile_marker(tag, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))) if os.environ.get("GVD_BENCH_MARKERS") else (lambda tag: None)
+    mark(0)   # (profiling runs only: tests/scripts/prof_summary.py counts the launches between the two markers)
     t0 = time.perf_counter()
     for i in range(steps):
         x = one(warm + i, x)
+    mark(1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -894,12 +898,15 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
                 continue
             frames = [f for f in (ev.stack or []) if ("lvdm_amd" in f or "bench.py" in f or "lvdm/" in f) and "torch/" not in f]
             key = (ev.name, (frames[0].strip() if frames else "") + " shapes " + str(getattr(ev, "input_shapes", ""))[:150])
-            r = agg.setdefault(key, [0, 0.0])
+            r = agg.setdefault(key, [0, 0.0, 0])
             r[0] += 1
-            r[1] += getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0)
+            r[1] += getattr(ev, "self_device_time_total", 0.0)
+            r[2] += len(getattr(ev, "kernels", []) or [])
         with open(os.environ["GVD_BENCH_TORCH_PROFILE"], "w") as fh:
-            for (name, frame), (n_, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:80]:
-                fh.write(f"{us / 1e3:8.2f} ms  n={n_:5d}  {name:18s} {frame}\n")
+            fh.write(f"one step: {sum(r[2] for r in agg.values())} launches from aten ops, {sum(r[1] for r in agg.values()) / 1e3:.2f} ms of device time (self)\n")
+            for (name, frame), (n_, us, nk) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                if nk:
+                    fh.write(f"{us / 1e3:8.3f} ms  n={n_:5d} launches={nk:5d}  {name:18s} {frame}\n")
     assert torch.isfinite(x).all()
     if world > 1:  # max over ranks
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)

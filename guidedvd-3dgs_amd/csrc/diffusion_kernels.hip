@@ -1100,11 +1100,19 @@ __global__ void __launch_bounds__(256) k_geglu_bwd(const T* __restrict__ h, cons
     }
 }
 
+__global__ void k_profile_marker(int) {}
+
 }  // namespace
 
 extern "C" {
 
 const char* gvd_diff_last_error(void) { return gvdd::g_err.c_str(); }
+
+int gvd_profile_marker(int tag, void* stream_)
+{
+    hipLaunchKernelGGL(k_profile_marker, dim3(1), dim3(1), 0, (hipStream_t)stream_, tag);
+    return 0;
+}
 
 int gvd_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
                       float scale, int is_bf16, void* stream_)

@@ -236,6 +236,11 @@ int gvd_group_norm_coef(double* stats, const double* partial, int replicas, int 
 
 const char* gvd_diff_last_error(void);
 
+/* Profiling aid (no reference counterpart): one empty single-thread launch of `k_profile_marker` on `stream`.  bench.py brackets its
+ * timed region with two of them when GVD_BENCH_MARKERS is set, and tests/scripts/prof_summary.py then counts only the launches between
+ * the first and the last marker of a rocprofv3 kernel trace (model construction, weight packing and warm-up steps are left out). */
+int gvd_profile_marker(int tag, void* stream);
+
 /* NT GEMM on MFMA with the transformer-side epilogues (csrc/gemm_mfma.hip):
  *     Y[b][m][n] = epilogue( alpha * sum_k X[b][m][k] * W[b][n][k] )         X, W, Y 16-bit, fp32 accumulation
  * Replaces every nn.Linear / 1x1 convolution on token rows of the U-Net, the VAE attention block and the once-per-video encoders
