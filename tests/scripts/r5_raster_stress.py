@@ -57,3 +57,58 @@ for it in range(60):
     n += 1
 torch.cuda.synchronize()
 print(f"raster stress: {n} configurations x 2 runs, images and gradients finite and bit-identical between runs")
+
+# ---- heavy section: sizes past the bench's (each twice, bit-identical; on a side stream; strided inputs) ----
+def pile(P, spread):          # every Gaussian in front of the camera inside a small disc: one or a few very long tile lists
+    xyz = rng.normal(size=(P, 3)) * np.array([spread, spread, 0.3]); xyz[:, 2] = np.abs(xyz[:, 2]) + 2.0
+    scales = np.exp(rng.normal(math.log(0.01), 0.3, size=(P, 3)))
+    q = rng.normal(size=(P, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    op = 1 / (1 + np.exp(-rng.normal(-3, 1, size=(P, 1))))     # faint: the walks do not saturate early
+    sh = rng.normal(0, 0.3, size=(P, 16, 3)); sh[:, 0] = syn.rgb2sh(rng.uniform(0, 1, size=(P, 3)))
+    return xyz, scales, q, op, sh
+
+def blanket(P):               # huge splats: every Gaussian touches (nearly) every tile
+    xyz, scales, q, op, sh = scene(P)
+    return xyz, scales * 60.0, q, op * 0.05, sh
+
+heavy = [("2 M Gaussians, 1600 x 1200", 2_000_000, 1600, 1200, scene),
+         ("5 M Gaussians, 640 x 480", 5_000_000, 640, 480, scene),
+         ("60 k Gaussians piled on a few tiles (lists > 16384: global-memory sort)", 60_000, 320, 240, lambda P: pile(P, 0.02)),
+         ("200 k piled on ~60 tiles", 200_000, 640, 480, lambda P: pile(P, 0.25)),
+         ("400 blanket splats, 1920 x 1080", 400, 1920, 1080, blanket),
+         ("100 k Gaussians, 3840 x 2160 (32 400 tiles)", 100_000, 3840, 2160, scene)]
+side = torch.cuda.Stream()
+for name, P, W, H, make in heavy:
+    sc = make(P)
+    cam = syn.make_camera(syn.look_at((0.0, 0.0, -3.0), (0.0, 0.0, 1.0)), math.radians(70), math.radians(55), W, H)
+    gC = torch.randn(3, H, W, device=dev) / (H * W)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(2):
+        if rep:
+            with torch.cuda.stream(side):      # second run on a side stream
+                outs.append(run(P, W, H, 3, sc, cam, True, gC))
+            side.synchronize()
+        else:
+            outs.append(run(P, W, H, 3, sc, cam, True, gC))
+    (c0, g0), (c1, g1) = outs
+    assert torch.isfinite(c0).all() and torch.equal(c0, c1), name
+    for k in g0:
+        assert torch.isfinite(g0[k]).all() and torch.equal(g0[k], g1[k]), (name, k)
+    print(f"heavy: {name}: ok (|image| max {float(c0.abs().max()):.3f}, nonzero mean-gradient rows {int((g0['means3D'].abs().sum(1) > 0).sum())})", flush=True)
+    del outs, c0, g0, c1, g1, sc
+    torch.cuda.empty_cache()
+
+# strided / non-contiguous inputs: the operator must give the same result as with packed copies
+P, W, H = 5000, 320, 200
+xyz, scales, q, op, sh = scene(P)
+cam = syn.make_camera(syn.look_at((0.0, 0.0, -3.0), (0.0, 0.0, 1.0)), math.radians(70), math.radians(55), W, H)
+st = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], t([0.1, 0.2, 0.3]), 1.0, t(cam["viewmatrix"]), t(cam["projmatrix"]),
+                                   3, t(cam["campos"]), False, False, torch.ones(P, 1, device=dev))
+big = torch.zeros(P, 8, device=dev); big[:, 1:4] = t(xyz)
+shT = t(sh.transpose(1, 0, 2)).transpose(0, 1)            # [P, 16, 3] view of a [16, P, 3] tensor
+assert not big[:, 1:4].is_contiguous() and not shT.is_contiguous()
+a = GaussianRasterizer(st)(means3D=big[:, 1:4], means2D=torch.zeros(P, 3, device=dev), opacities=t(op), shs=shT, scales=t(scales), rotations=t(q))
+b = GaussianRasterizer(st)(means3D=t(xyz), means2D=torch.zeros(P, 3, device=dev), opacities=t(op), shs=t(sh), scales=t(scales), rotations=t(q))
+assert all(torch.equal(x, y) for x, y in zip(a, b)), "strided inputs change the result"
+print("strided inputs: ok")
