@@ -4,7 +4,11 @@
 // in Morton order) pairs over all other points.  How it is computed here (HBM / LDS-bound integer + fp32 work, no MFMA):
 //   k_bounds_*     two-level min/max of the cloud, initial value 0 like the reference's reduce (bounds stay on device)
 //   k_morton       30-bit Morton codes, same fp32 expression as the reference -> same codes
-//   rocprim radix sort (stable) of (code, id)                      [library sort; the reference uses cub]
+//   k_radix_*      stable LSD radix sort of (code, id), four 8-bit passes (histogram per 2048-key tile -> one exclusive scan over
+//                  (digit, tile) -> stable scatter: a key's slot is the scanned base of its (digit, tile) + the keys of the same
+//                  digit in earlier 64-key chunks of the tile + its rank among its wave's lanes with that digit, taken from eight
+//                  ballots).  The reference sorts with cub::DeviceRadixSort (simple_knn.cu:208-216); a stable sort by the whole key
+//                  has one result, so the order is the same.  No library call is left in this package.
 //   k_gather_box   sorted positions -> contiguous float4 array (kills the points[indices[i]] indirection of the
 //                  reference's inner loop) + per-1024-point box bounds
 //   k_knn          one workgroup = 256 consecutive sorted points (spatially coherent).  For every box that ANY of its
@@ -18,7 +22,6 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
 #include <string>
 
 #include "../../include/gvd_knn.h"
@@ -190,6 +193,82 @@ __global__ void __launch_bounds__(QB) k_knn(int P, const float4* __restrict__ sp
     }
 }
 
+// ---- stable LSD radix sort of (key, value) pairs, 8 bits per pass ----
+constexpr int RS_TILE = 2048, RS_THREADS = 256, RS_CHUNKS = RS_TILE / 64;   // a tile's order: chunk c = keys [64 c, 64 c + 64), lane = key
+
+// digit counts of every tile: hist[d * n_tiles + tile]
+__global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, int n, int shift, int n_tiles,
+                                                           uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+    for (int i = threadIdx.x; i < RS_TILE; i += RS_THREADS)
+        if (base + i < n) atomicAdd(&s_h[(keys[base + i] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// exclusive scan of hist in (digit, tile) order, in place, by one workgroup: thread t owns a contiguous run
+__global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* __restrict__ hist, int count)
+{
+    __shared__ uint32_t s_w[16];
+    const int per = (count + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < count ? lo + per : count;
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += hist[i];
+    uint32_t inc = sum;                                        // inclusive scan over the 1024 thread sums
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((threadIdx.x & 63) >= o) inc += t; }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += s_w[w];
+    for (int i = lo; i < hi; i++) { const uint32_t v = hist[i]; hist[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int n,
+                                                              int shift, int n_tiles, const uint32_t* __restrict__ bases,
+                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+    __shared__ uint32_t s_cnt[RS_CHUNKS][256];                 // keys of digit d in chunk c, then: ... in the chunks before c
+    for (int i = threadIdx.x; i < RS_CHUNKS * 256; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t key[RS_TILE / RS_THREADS], val[RS_TILE / RS_THREADS], rank[RS_TILE / RS_THREADS];
+#pragma unroll
+    for (int r = 0; r < RS_TILE / RS_THREADS; r++) {
+        const int chunk = r * (RS_THREADS / 64) + wave, i = base + chunk * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? keys[i] : 0u;
+        val[r] = valid ? vals[i] : 0u;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);            // lanes of this chunk holding the same digit
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        rank[r] = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank[r] == 0) s_cnt[chunk][d] = (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    {   // thread d: exclusive prefix of its digit over the tile's chunks, started at the digit's scanned base for this tile
+        uint32_t run = bases[(size_t)threadIdx.x * n_tiles + blockIdx.x];
+        for (int c = 0; c < RS_CHUNKS; c++) { const uint32_t v = s_cnt[c][threadIdx.x]; s_cnt[c][threadIdx.x] = run; run += v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_TILE / RS_THREADS; r++) {
+        const int chunk = r * (RS_THREADS / 64) + wave, i = base + chunk * 64 + lane;
+        if (i < n) {
+            const uint32_t dst = s_cnt[chunk][(key[r] >> shift) & 255u] + rank[r];
+            keys_out[dst] = key[r];
+            vals_out[dst] = val[r];
+        }
+    }
+}
+
 struct Layout {
     size_t part, bounds, codes, ids, codes_s, order, sp, boxes, sort_tmp, sort_bytes, total;
 };
@@ -210,10 +289,8 @@ Layout make_layout(int P)
     L.order = take(4 * n);
     L.sp = take(16 * n);
     L.boxes = take(sizeof(BoxMM) * nb);
-    size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32);
-    L.sort_bytes = tmp;
-    L.sort_tmp = take(tmp);
+    L.sort_bytes = 4 * 256 * ((n + RS_TILE - 1) / RS_TILE);      // the (digit, tile) histogram of a radix pass
+    L.sort_tmp = take(L.sort_bytes);
     L.total = off;
     return L;
 }
@@ -249,9 +326,21 @@ int gvd_knn_mean_dist(const float* points, int P, float* mean_dists, int* neares
     hipLaunchKernelGGL(k_bounds_partial, dim3(rb), dim3(256), 0, stream, points, P, part);
     hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, stream, (const Bounds*)part, rb, bounds);
     hipLaunchKernelGGL(k_morton, dim3((P + 255) / 256), dim3(256), 0, stream, points, P, (const Bounds*)bounds, codes, ids);
-    size_t tmp = L.sort_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, codes, codes_s, ids, order, (size_t)P, 0, 32, stream);
-    if (e != hipSuccess) return fail(-2, "rocprim::radix_sort_pairs", e);
+    {   // four stable 8-bit passes, ping-pong (codes, ids) <-> (codes_s, order): the sorted pairs end up in (codes, ids)
+        uint32_t* hist = (uint32_t*)(ws + L.sort_tmp);
+        const int n_tiles = (P + RS_TILE - 1) / RS_TILE;
+        uint32_t *k_in = codes, *v_in = ids, *k_out = codes_s, *v_out = order;
+        for (int shift = 0; shift < 32; shift += 8) {
+            hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(RS_THREADS), 0, stream, (const uint32_t*)k_in, P, shift, n_tiles, hist);
+            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, hist, 256 * n_tiles);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(RS_THREADS), 0, stream, (const uint32_t*)k_in, (const uint32_t*)v_in, P,
+                               shift, n_tiles, (const uint32_t*)hist, k_out, v_out);
+            uint32_t* t = k_in; k_in = k_out; k_out = t;
+            t = v_in; v_in = v_out; v_out = t;
+        }
+        order = v_in;   // == ids after an even number of passes
+    }
+    hipError_t e;
     hipLaunchKernelGGL(k_gather_box, dim3(n_boxes), dim3(BOX), 0, stream, points, P, (const uint32_t*)order, sp, boxes);
     hipLaunchKernelGGL(k_knn, dim3((P + QB - 1) / QB), dim3(QB), 0, stream, P, (const float4*)sp, (const BoxMM*)boxes, n_boxes,
                        mean_dists, nearest_idx);

@@ -92,7 +92,9 @@ def test_library_exports_every_declared_symbol_and_refuses_cpu_tensors():
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,P", [("gauss", 1), ("gauss", 2), ("gauss", 3), ("gauss", 4), ("gauss", 5), ("gauss", 1023),
-                                    ("gauss", 1025), ("room", 5000), ("dupes", 3000), ("lattice", 4096), ("gauss", 20000)])
+                                    ("gauss", 1025), ("room", 5000), ("dupes", 3000), ("lattice", 4096), ("gauss", 20000),
+                                    # the in-tree radix sort's 2048-key tiles and 64-key chunks: sizes around them, many equal codes
+                                    ("gauss", 2047), ("gauss", 2048), ("gauss", 2049), ("dupes", 4160), ("dupes", 100_003)])
 def test_hip_knn_is_bit_exact_against_the_oracle(kind, P):
     from simple_knn._C import distCUDA2
     pts = _cloud(kind, P, 7)
