@@ -80,3 +80,37 @@ def test_guided_and_plain_ddim_steps_launch_no_library_gemm_or_convolution():
         assert not bad, (label, bad)
         for own in OWN[label]:
             assert any(own in n for n in names), (label, own, sorted(names)[:40])
+
+
+def test_raster_step_and_knn_launch_only_this_packages_kernels():
+    """The rasterizer's forward + backward and `distCUDA2` launch nothing but `gvd::k_*` / `k_*` kernels of this package: no rocPRIM / hipCUB
+    scan or sort (the reference leans on cub for both, `rasterizer_impl.cu:278,304`, `simple_knn.cu:208`), no library memset."""
+    import math
+    import numpy as np
+    import synthetic as syn
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(3)
+    P, W, H = 4000, 320, 240
+    xyz = rng.normal(size=(P, 3)).astype(np.float32)
+    xyz[:, 2] = np.abs(xyz[:, 2]) + 1.0
+    cam = syn.make_camera(syn.look_at((0.0, 0.0, -3.0), (0.0, 0.0, 1.0)), math.radians(70), math.radians(55), W, H)
+    t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a, np.float32), device=DEV, requires_grad=rg)
+    st = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], t([0, 0, 0]), 1.0, t(cam["viewmatrix"]), t(cam["projmatrix"]),
+                                       3, t(cam["campos"]), False, False, torch.ones(P, 1, device=DEV))
+    lv = dict(means3D=t(xyz, True), means2D=torch.zeros(P, 3, device=DEV, requires_grad=True), opacities=t(rng.uniform(0.1, 0.9, (P, 1)), True),
+              shs=t(rng.normal(0, 0.3, (P, 16, 3)), True), scales=t(np.full((P, 3), 0.03), True),
+              rotations=t(np.tile([1.0, 0, 0, 0], (P, 1)), True))
+    pts = t(xyz)
+
+    def step():
+        c, r, d, a = GaussianRasterizer(st)(**lv)
+        (c.sum() + d.sum()).backward()
+        distCUDA2(pts)
+
+    names = _kernel_names(step)
+    own = [n for n in names if re.search(r"\bk_[a-z_0-9]+", n)]
+    for k in ("k_preprocess", "k_scatter", "k_render_fwd", "k_render_bwd", "k_gather_bwd", "k_radix_scatter", "k_knn"):
+        assert any(k in n for n in own), (k, sorted(names))
+    bad = sorted(n for n in names if re.search(r"rocprim|hipcub|cub::|thrust|radix_sort|DeviceScan", n))
+    assert not bad, bad
