@@ -382,10 +382,13 @@ constexpr int kShW = 0, kShRGB = 16, kShConf = 19, kShCount = 20, kShRow = 21;
 // together: per trip the quad fetches the flag words of four instances (lane j loads instance g + j's word, the quad exchanges
 // them), then every lane has its column's up to four sub-records in flight at once -- one round trip for the flags and one for
 // the records per four instances.
-__device__ __forceinline__ void gather_column(const GatherBwdArgs& a, const uint32_t beg, const uint32_t end, const int q, float* s)
+__device__ __forceinline__ void gather_column(const GatherBwdArgs& a, const uint32_t beg, const uint32_t end, const int q, uint32_t mine,
+                                              float* s)
 {
+    // `mine`: this lane's flag word of the first trip (instance beg + q), fetched by the caller for all of its Gaussians at once; the
+    // word of the NEXT trip is requested together with this trip's records, so a trip is one memory round trip, not two
     for (uint32_t g = beg; g < end; g += 4) {
-        const uint32_t mine = (g + (uint32_t)q < end) ? a.pflags[g + q] : 0u;
+        const uint32_t next = (g + 4u + (uint32_t)q < end) ? a.pflags[g + 4u + q] : 0u;
         uint32_t f[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) f[j] = (uint32_t)__shfl((int)mine, j, 4);
@@ -405,6 +408,7 @@ __device__ __forceinline__ void gather_column(const GatherBwdArgs& a, const uint
                 s[8] += r[j][2].x; s[9] += r[j][2].y;
             }
         }
+        mine = next;
     }
 }
 
@@ -686,18 +690,29 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
     {
         const int q = tid & 3;
         const bool live = a.scalars[2] == 0;   // overflowed forward: all-zero gradients
-#pragma unroll 1
-        for (int pass = 0; pass < kGatherG / 64; pass++) {
+        // the run bounds and the first flag word of all four passes' Gaussians up front: two memory round trips for the workgroup
+        // instead of three dependent ones per pass
+        constexpr int NPASS = kGatherG / 64;
+        uint32_t beg[NPASS], end[NPASS], first[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+            const int idx = blockIdx.x * kGatherG + pass * 64 + (tid >> 2);
+            beg[pass] = end[pass] = 0u;
+            if (live && idx < a.P) {
+                const int rad = a.radii[idx];
+                const uint32_t b = idx ? a.point_offsets[idx - 1] : 0u, e = a.point_offsets[idx];
+                if (rad > 0) { beg[pass] = b; end[pass] = e; }
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) first[pass] = (beg[pass] + (uint32_t)q < end[pass]) ? a.pflags[beg[pass] + q] : 0u;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
             const int gi = pass * 64 + (tid >> 2);
-            const int idx = blockIdx.x * kGatherG + gi;
             float s[kNV];
 #pragma unroll
             for (int v = 0; v < kNV; v++) s[v] = 0.f;
-            if (live && idx < a.P && a.radii[idx] > 0) {
-                const uint32_t beg = idx ? a.point_offsets[idx - 1] : 0u;
-                const uint32_t end = a.point_offsets[idx];
-                gather_column(a, beg, end, q, s);
-            }
+            gather_column(a, beg[pass], end[pass], q, first[pass], s);
 #pragma unroll
             for (int v = 0; v < kNV; v++) {
                 float t = s[v];
