@@ -23,6 +23,7 @@ Both carry `roofline` (dominant kernel, HIP-event timed inside the timed region)
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import sys
@@ -225,6 +226,7 @@ def raster_run(args, dev, rank, world):
         if profile:
             L.gvd_profile_reset()
             L.gvd_profile_enable(1)
+        gc.collect()   # the K-step window is a few ms: start it with the collector's generations empty (collection stays enabled inside)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):

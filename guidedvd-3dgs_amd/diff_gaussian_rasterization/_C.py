@@ -74,6 +74,29 @@ def lib():
     return _lib
 
 
+_EXT_PATH = os.path.join(os.path.dirname(_HERE), "lib", "_gvd_raster_torch.so")
+_ext = None
+
+
+def ext():
+    """The compiled autograd operator (csrc/raster_torch_ext.cpp: forward + backward as one torch::autograd::Function over the same
+    C-ABI library instance), or None when lib/_gvd_raster_torch.so has not been built -- the ctypes functions below then carry the
+    operator (same kernels, ~2x the host time per training iteration).  GVD_RASTER_NO_EXT=1 forces that path (A/B runs)."""
+    global _ext
+    if _ext is None:
+        if os.environ.get("GVD_RASTER_NO_EXT") or not os.path.exists(_EXT_PATH):
+            _ext = False
+        else:
+            import importlib.util
+            lib()   # the HIP library first: a missing library must raise its own message
+            spec = importlib.util.spec_from_file_location("_gvd_raster_torch", _EXT_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.init(_LIB_PATH)
+            _ext = mod
+    return _ext or None
+
+
 def _err(code):
     msg = lib().gvd_last_error()
     return RuntimeError(f"gvd_raster error {code}: {msg.decode() if msg else '?'}")
@@ -201,10 +224,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a ROCm device; got " + str(dev))
     L = lib()
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    eb = 1 if expect_backward else 0
-    if getattr(_TLS, "expect_backward", 1) != eb:   # per-thread, sticky on the native side: only touch it on a change
-        L.gvd_raster_expect_backward(eb)
-        _TLS.expect_backward = eb
+    L.gvd_raster_expect_backward(1 if expect_backward else 0)   # per host thread, sticky on the native side; set on every call (the
+                                                                # compiled operator sets the same flag: no mirror of it is kept here)
     with _on(dev):
         f = lambda t, n: _dev_f32(t, n, dev)
         bg, m3, col, opa, sc, rot, cov, vm, pm, shs, cam = (

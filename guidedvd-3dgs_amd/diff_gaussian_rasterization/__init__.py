@@ -16,8 +16,9 @@ Behaviour kept from the reference:
   * with settings.debug the native call's arguments are snapshotted to snapshot_fw.dump /
     snapshot_bw.dump when it raises (ref :83-90, :135-142).
 
-The compute is the HIP library behind `_C` (ctypes -> libgvd_raster.so, C-ABI in include/gvd_raster.h).
-There is no CPU or eager fallback.
+The compute is the HIP library behind `_C` (libgvd_raster.so, C-ABI in include/gvd_raster.h), reached through a compiled torch
+autograd operator (lib/_gvd_raster_torch.so, csrc/raster_torch_ext.cpp) or, for debug dumps, the sync-free capacity mode and the
+reference's three pybind-level entry points, through ctypes (`_C.py`).  There is no CPU or eager fallback.
 """
 import functools
 from typing import NamedTuple
@@ -105,6 +106,14 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    s = raster_settings
+    ext = _C.ext()
+    if ext is not None and not s.debug and _C._CAPACITY == 0:
+        # the same operator as _RasterizeGaussians below, compiled (csrc/raster_torch_ext.cpp): one call in, no Python in the backward
+        color, radii, depth, alpha = ext.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                                   s.bg, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+                                                   s.image_height, s.image_width, s.sh_degree, s.campos, s.prefiltered, s.confidence)
+        return color, radii, depth, alpha
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 

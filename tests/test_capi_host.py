@@ -124,3 +124,23 @@ def test_binning_capacity_inverts_binning_bytes_and_never_reports_less_than_it_h
         cap = L.gvd_raster_binning_capacity(b)
         assert cap == max(r, 1), (r, cap)
         assert L.gvd_raster_binning_capacity(b + 4) == 0xffffffff
+
+
+def test_compiled_operator_loads_and_fails_loudly_without_a_device(capi):
+    """lib/_gvd_raster_torch.so (csrc/raster_torch_ext.cpp, built by __graft_entry__.build_raster_torch_ext) imports, resolves its C-ABI
+    entry points from libgvd_raster.so and refuses CPU tensors with the binding's message -- no silent fallback."""
+    import __graft_entry__ as g
+    g.build_raster_torch_ext()
+    capi._ext = None
+    ext = capi.ext()
+    assert ext is not None and hasattr(ext, "rasterize")
+    import diff_gaussian_rasterization as dgr
+    P = 5
+    st = dgr.GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False,
+                                           torch.ones(P, 1))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        dgr.GaussianRasterizer(st)(means3D=torch.zeros(P, 3), means2D=torch.zeros(P, 3), opacities=torch.ones(P, 1), shs=torch.zeros(P, 1, 3),
+                                   scales=torch.ones(P, 3), rotations=torch.ones(P, 4))
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        dgr.GaussianRasterizer(st)(means3D=torch.zeros(P, 4), means2D=torch.zeros(P, 3), opacities=torch.ones(P, 1), shs=torch.zeros(P, 1, 3),
+                                   scales=torch.ones(P, 3), rotations=torch.ones(P, 4))

@@ -551,3 +551,61 @@ def test_colour_only_backward_equals_zero_depth_and_alpha_gradients():
     assert float(lean[3].abs().max()) > 0
     for a, b in zip(lean, full):
         assert torch.equal(a, b)
+
+
+def test_compiled_operator_equals_the_python_operator():
+    """`rasterize_gaussians` runs the compiled torch::autograd::Function of lib/_gvd_raster_torch.so (csrc/raster_torch_ext.cpp); the
+    Python `_RasterizeGaussians` over the ctypes entry points is the same operator (and carries debug dumps and the capacity mode).
+    Both must return the same bits: images, radii, every gradient (confidence-scaled, screen-space one unscaled), with gradients for a
+    subset of the outputs, under no_grad, on a retained graph, and with strided inputs."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C, GaussianRasterizationSettings, GaussianRasterizer
+    assert _C.ext() is not None, "lib/_gvd_raster_torch.so is not built / did not load"
+    dev = torch.device("cuda:0")
+    sc = _tiny(21, P=1500, W=160, H=96, deg=2)
+    cam = sc["cameras"][0]
+    P = 1500
+    t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=rg)
+    conf = torch.rand(P, 1, device=dev) + 0.5
+    st = GaussianRasterizationSettings(96, 160, cam["tanfovx"], cam["tanfovy"], t(sc["bg"]), 1.0, t(cam["viewmatrix"]), t(cam["projmatrix"]),
+                                       2, t(cam["campos"]), False, False, conf)
+    gC, gD, gA = (torch.randn(3, 96, 160, device=dev), torch.randn(1, 96, 160, device=dev), torch.randn(1, 96, 160, device=dev))
+
+    def run(which, outputs):
+        lv = dict(means3D=t(sc["means3D"], True), means2D=torch.zeros(P, 3, device=dev, requires_grad=True), opacities=t(sc["opacities"], True),
+                  shs=t(sc["shs"], True)[:, :9].contiguous().detach().requires_grad_(True), scales=t(sc["scales"], True), rotations=t(sc["rotations"], True))
+        saved = _C._ext
+        if which == "python":
+            _C._ext = False
+        try:
+            c, r, d, a = GaussianRasterizer(st)(**lv)
+            outs, grads = {"c": ([c], [gC]), "cd": ([c, d], [gC, gD]), "cda": ([c, d, a], [gC, gD, gA]), "a": ([a], [gA])}[outputs]
+            torch.autograd.backward(outs, grads, retain_graph=True)
+            g1 = {k: v.grad.clone() for k, v in lv.items()}
+            for v in lv.values():
+                v.grad = None
+            torch.autograd.backward(outs, grads)                      # a second backward over the retained graph
+            g2 = {k: v.grad.clone() for k, v in lv.items()}
+            with torch.no_grad():
+                cn = GaussianRasterizer(st)(**lv)[0]
+        finally:
+            _C._ext = saved
+        assert type(c.grad_fn).__name__ == ("_RasterizeGaussiansBackward" if which == "python" else "RasterFnBackward") or which == "ext", type(c.grad_fn)
+        return (c.detach(), r, d.detach(), a.detach(), cn), g1, g2
+
+    for outputs in ("c", "cd", "cda", "a"):
+        (o_e, g_e, g_e2), (o_p, g_p, g_p2) = run("ext", outputs), run("python", outputs)
+        for x, y in zip(o_e, o_p):
+            assert torch.equal(x, y), outputs
+        for k in g_e:
+            assert torch.equal(g_e[k], g_e2[k]), (outputs, k, "compiled: second backward differs", float((g_e[k] - g_e2[k]).abs().max()))
+            assert torch.equal(g_p[k], g_p2[k]), (outputs, k, "python: second backward differs", float((g_p[k] - g_p2[k]).abs().max()))
+            assert torch.equal(g_e[k], g_p[k]), (outputs, k, "compiled vs python", float((g_e[k] - g_p[k]).abs().max()))
+        assert float(g_e["means3D"].abs().max()) > 0
+    # the compiled path refuses what the Python path refuses
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        dgr.rasterize_gaussians(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 1, 3), torch.Tensor([]), torch.ones(4, 1), torch.ones(4, 3),
+                                torch.ones(4, 4), torch.Tensor([]), st)
+    with pytest.raises(RuntimeError, match="float32"):
+        GaussianRasterizer(st)(means3D=t(sc["means3D"]).double(), means2D=torch.zeros(P, 3, device=dev), opacities=t(sc["opacities"]),
+                               shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
