@@ -429,6 +429,8 @@ def raster_run(args, dev, rank, world):
                        "gaussians": P, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cams),
                        "num_rendered_mean": int(R_mean), "visible_mean": int(vis_mean),
                        "mean_tile_list": round(R_mean / (((W + 15) // 16) * ((H + 15) // 16)), 1),
+                       "operator": "GaussianRasterizer -> compiled torch::autograd::Function over the C-ABI (lib/_gvd_raster_torch.so)" if _C.ext() is not None
+                       else "GaussianRasterizer -> Python autograd.Function over ctypes (lib/_gvd_raster_torch.so not built or GVD_RASTER_NO_EXT set)",
                        "parallelism": "single GPU" if world == 1 else
                        f"per-camera shards: {world} ranks, each rasterizes its own cameras forward + backward on a replica of the "
                        "Gaussians (no data-path collective)"},
@@ -437,7 +439,7 @@ def raster_run(args, dev, rank, world):
                                   "what": "the same K steps again with HIP event pairs around k_render_fwd / k_render_bwd on the launch stream "
                                           "(gvd_profile level 1): where roofline.avg_us comes from; the timed region above carries none"},
             "step_minus_kernel_sum_us": round(1e6 * elapsed / args.steps - sum(v["avg_us"] for v in kern.values()), 1) if world == 1 else None,
-            "headline": "`value` = the K timed steps the bench contract asks for (20 steps = 7 ms at the driver's flags: host-jitter bound); "
+            "headline": "`value` = the K timed steps the bench contract asks for (20 steps = 5-6 ms at the driver's flags: the window also holds the pipeline's fill and drain); "
                         "`sustained` = the same loop over a >= 1 s window, the steadier figure",
             "two_view_step": two_view,
             "roofline": roofline,
