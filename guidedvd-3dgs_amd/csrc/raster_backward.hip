@@ -681,8 +681,11 @@ __device__ __forceinline__ void gather_body(const GatherBwdArgs& a, const int id
 // dL_dsh is 48 floats (192 B) per Gaussian: written per thread it is a 192-byte-stride scatter (64 cache lines per store
 // instruction).  Instead each Gaussian drops the 21 factors of its row into an LDS tile (odd row stride: conflict-free) and the
 // block expands and streams the tile out as contiguous float4 (1 KiB per wave store).
-constexpr int kGatherG = 256;
-__global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
+#ifndef GVD_GATHER_G
+#define GVD_GATHER_G 256
+#endif
+constexpr int kGatherG = GVD_GATHER_G;   // Gaussians == threads per workgroup (A/B builds: -DGVD_GATHER_G=128 / 512)
+__global__ void __launch_bounds__(kGatherG) k_gather_bwd(GatherBwdArgs a)
 {
     extern __shared__ float s_sh[];  // [kGatherG][kShRow] when M == 16 (launch passes the size), else unused
     __shared__ float s_sum[kGatherG][kNV + 1];
@@ -692,11 +695,11 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
         const bool live = a.scalars[2] == 0;   // overflowed forward: all-zero gradients
         // the run bounds and the first flag word of all four passes' Gaussians up front: two memory round trips for the workgroup
         // instead of three dependent ones per pass
-        constexpr int NPASS = kGatherG / 64;
+        constexpr int NPASS = 4, GPP = kGatherG / 4;   // four lanes per Gaussian: GPP Gaussians per pass
         uint32_t beg[NPASS], end[NPASS], first[NPASS];
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
-            const int idx = blockIdx.x * kGatherG + pass * 64 + (tid >> 2);
+            const int idx = blockIdx.x * kGatherG + pass * GPP + (tid >> 2);
             beg[pass] = end[pass] = 0u;
             if (live && idx < a.P) {
                 const int rad = a.radii[idx];
@@ -708,7 +711,7 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
         for (int pass = 0; pass < NPASS; pass++) first[pass] = (beg[pass] + (uint32_t)q < end[pass]) ? a.pflags[beg[pass] + q] : 0u;
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
-            const int gi = pass * 64 + (tid >> 2);
+            const int gi = pass * GPP + (tid >> 2);
             float s[kNV];
 #pragma unroll
             for (int v = 0; v < kNV; v++) s[v] = 0.f;
@@ -740,8 +743,8 @@ __global__ void __launch_bounds__(256) k_gather_bwd(GatherBwdArgs a)
         const size_t block_base = (size_t)blockIdx.x * kGatherG * 48;
         const size_t total = (size_t)a.P * 48;
 #pragma unroll
-        for (int k = 0; k < kGatherG * 48 / 4 / 256; k++) {
-            const int i = (k * 256 + tid) * 4;  // float index inside the block's kGatherG x 48 tile
+        for (int k = 0; k < 48 / 4; k++) {
+            const int i = (k * kGatherG + tid) * 4;  // float index inside the block's kGatherG x 48 tile
             if (block_base + i < total) {
                 const int g = i / 48, c = i - g * 48;
                 const float* r = s_sh + g * kShRow;
@@ -778,7 +781,7 @@ void launch_render_bwd(const RenderBwdArgs& a, int T, hipStream_t s)
 }
 void launch_gather_bwd(const GatherBwdArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + kGatherG - 1) / kGatherG), dim3(256), a.M == 16 ? (size_t)kGatherG * kShRow * 4 : 0, s, a);
+    hipLaunchKernelGGL(k_gather_bwd, dim3((a.P + kGatherG - 1) / kGatherG), dim3(kGatherG), a.M == 16 ? (size_t)kGatherG * kShRow * 4 : 0, s, a);
     // only needed when the caller consumes dL_dcov3D (precomputed-covariance path)
     if (a.confidence && !a.has_scales)
         hipLaunchKernelGGL(k_scale_cov, dim3((a.P * 6 + 255) / 256), dim3(256), 0, s, a.P * 6, a.dL_dcov3D, a.confidence);
