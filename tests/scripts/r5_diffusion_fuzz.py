@@ -1,0 +1,107 @@
+"""Randomised shapes through the diffusion library's three kernel families (round 5 dev tool, companion of r5_raster_stress.py): the MFMA
+GEMM (gemm_nt: ragged M / N / K, strided views, batches, bias / alpha / residual / GEGLU; linear: LayerNorm fold), flash attention (forward and
+backward: heads x widths x ragged query / key counts, shared K / V), the implicit-GEMM convolution (spatial 3x3 with and without the fused
+GroupNorm + SiLU, residual, per-sample channel add; forward and input gradient), each against fp32 torch math on the same 16-bit operands.
+Prints the worst relative error per family; fails on the first case over its bar."""
+import os, sys, math
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "guidedvd-3dgs_amd"), os.path.join(ROOT, "tests")): sys.path.insert(0, p)
+import numpy as np, torch
+import torch.nn.functional as F
+from lvdm_amd import gemm, ops, conv as mconv
+dev = "cuda:0"
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 11)
+g = torch.Generator(device=dev).manual_seed(5)
+mk = lambda *s, scale=1.0, dt=torch.float16: (torch.randn(*s, device=dev, generator=g) * scale).to(dt)
+rel = lambda a, r: float((a.float() - r).abs().max() / r.abs().max().clamp_min(1e-6))
+worst = {}
+def check(fam, err, bar, what):
+    worst[fam] = max(worst.get(fam, 0.0), err)
+    assert err < bar and math.isfinite(err), (fam, what, err)
+
+# ---- GEMM ----
+for it in range(120):
+    dt = torch.float16 if rng.random() < 0.7 else torch.bfloat16
+    tol = 2e-3 if dt == torch.float16 else 1.5e-2
+    M = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 256, 257, 300, 1000, 2304, 4099]))
+    N = 8 * int(rng.integers(1, 330)); K = 8 * int(rng.integers(1, 200))
+    B = int(rng.choice([1, 1, 1, 2, 5]))
+    geglu = rng.random() < 0.2
+    if geglu: N = 32 * max(1, N // 32)
+    xs = mk(B, M, K + 24, dt=dt)[:, :, 8:8 + K] if rng.random() < 0.4 else mk(B, M, K, dt=dt)
+    w = mk(N, K, scale=K ** -0.5, dt=dt) if rng.random() < 0.7 else mk(B, N, K, scale=K ** -0.5, dt=dt)
+    x = xs if B > 1 or w.dim() == 3 else xs[0]
+    if w.dim() == 3 and B == 1: w = w[0]
+    bias = torch.randn(N, device=dev, generator=g) if rng.random() < 0.6 else None
+    alpha = float(rng.choice([1.0, 0.5, 0.125]))
+    No = N // 2 if geglu else N
+    res = mk(*x.shape[:-1], No, dt=dt) if rng.random() < 0.3 else None
+    y = gemm.gemm_nt(x, w, alpha=alpha, bias=bias, residual=res, geglu=geglu)
+    ref = alpha * (x.float() @ w.float().transpose(-1, -2))
+    if bias is not None: ref = ref + bias
+    if geglu:
+        # gemm_nt's GEGLU epilogue expects W rows in blocks of [16 value | 16 gate] rows, half-row c holding output u(c) of the block
+        # (gemm._geglu_perm / include/gvd_diffusion.h): the random W here IS such an image, so the reference is un-permuted instead
+        c = torch.arange(16, device=dev)
+        u = 8 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3)
+        r4 = ref.reshape(*ref.shape[:-1], N // 32, 2, 16)
+        prod = r4[..., 0, :] * F.gelu(r4[..., 1, :])
+        out = torch.empty_like(prod)
+        out[..., u] = prod
+        ref = out.reshape(*ref.shape[:-1], N // 2)
+    if res is not None: ref = ref + res.float()
+    check("gemm_nt", rel(y, ref), tol, (M, N, K, B, str(dt), geglu, bias is not None, res is not None, alpha, x.stride()))
+for it in range(40):   # Linear with the LayerNorm fold / residual
+    M = int(rng.choice([77, 256, 1000, 2240, 3001])); C = int(rng.choice([64, 320, 640, 1280])); N = 8 * int(rng.integers(4, 200))
+    x = mk(2, M, C); w = mk(N, C, scale=C ** -0.5).float(); b = torch.randn(N, device=dev, generator=g)
+    ln = torch.nn.LayerNorm(C).to(dev); ln.weight.data = 1 + 0.2 * torch.randn(C, device=dev, generator=g); ln.bias.data = 0.2 * torch.randn(C, device=dev, generator=g)
+    use_ln, use_res = rng.random() < 0.7, rng.random() < 0.4
+    res = mk(2, M, N) if use_res else None
+    y = gemm.linear(x, w.half(), b.half(), ln=ln if use_ln else None, residual=res)
+    xr = F.layer_norm(x.float(), (C,), ln.weight, ln.bias, ln.eps) if use_ln else x.float()
+    ref = xr @ w.half().float().t() + b.half().float() + (res.float() if use_res else 0)
+    check("linear(ln, residual)", rel(y, ref), 4e-3, (M, C, N, use_ln, use_res))
+
+# ---- attention ----
+for it in range(60):
+    heads = int(rng.choice([1, 2, 5, 8, 10])); d = int(rng.choice([8, 40, 64, 64, 64, 80, 160]))
+    B = int(rng.choice([1, 2, 7])); Nq = int(rng.choice([1, 16, 77, 333, 1024, 2240, 3000])); Nk = int(rng.choice([1, 25, 77, 93, 333, 1500, 2240]))
+    shared = rng.random() < 0.3
+    q = mk(B, Nq, heads * d).requires_grad_(True)
+    k = mk(1 if shared else B, Nk, heads * d).requires_grad_(True); v = mk(1 if shared else B, Nk, heads * d).requires_grad_(True)
+    o = ops.attention(q, k, v, heads)
+    q32, k32, v32 = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    r = ops.attention_math(q32, k32.expand(B, -1, -1), v32.expand(B, -1, -1), heads)   # (shared K / V: one copy for the batch)
+    check("attention fwd", rel(o, r.detach()), 4e-3, (B, heads, d, Nq, Nk, shared))
+    if Nk == 1:
+        continue   # one key: every gradient but dv is exactly 0 in math, and what a 16-bit path returns there is its rounding noise
+    go = mk(*o.shape)
+    o.backward(go); r.backward(go.float())
+    for name, a, bb in (("dq", q.grad, q32.grad), ("dk", k.grad, k32.grad), ("dv", v.grad, v32.grad)):
+        # (one key: dq is exactly 0 in math; the chunked wide-head path keeps dP in 16 bit, i.e. ~3e-3 of rounding on unit-scale operands --
+        #  measure against the operands' unit scale, not against a zero reference)
+        check("attention bwd", float((a.float() - bb).abs().max() / bb.abs().max().clamp_min(1.0)), 1.2e-2, (name, B, heads, d, Nq, Nk, shared))
+
+# ---- convolution ----
+for it in range(60):
+    N = int(rng.choice([1, 2, 5])); H = int(rng.choice([5, 7, 9, 16, 20, 40, 45])); W = int(rng.choice([7, 14, 16, 28, 33, 56]))
+    Cin = 32 * int(rng.integers(1, 11)); Cout = int(rng.choice([32, 64, 128, 160, 320, 640]))
+    cv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).to(dev).half().requires_grad_(False)
+    cv.weight.data = mk(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5); cv.bias.data = mk(Cout, scale=0.1)
+    x = mk(N, H, W, Cin).requires_grad_(True)
+    use_gn = rng.random() < 0.6
+    gn = None
+    if use_gn:
+        gn = torch.nn.GroupNorm(32, Cin).to(dev); gn.weight.data = 1 + 0.2 * torch.randn(Cin, device=dev, generator=g); gn.bias.data = 0.2 * torch.randn(Cin, device=dev, generator=g)
+        gn.requires_grad_(False)
+    res = mk(N, H, W, Cout) if rng.random() < 0.4 else None
+    add = mk(N, Cout, scale=0.3) if rng.random() < 0.3 else None
+    y, _ = mconv.fused_conv(x, cv, gn=gn, silu=use_gn, residual=res, add_nc=add)
+    x32 = x.detach().float().requires_grad_(True)
+    r = mconv._reference(x32, cv.weight.float(), cv.bias.float(), mconv.SPATIAL, False, gn, use_gn, None if add is None else add.float(), None if res is None else res.float(), N)
+    check("conv fwd", rel(y, r.detach()), 6e-3, (N, H, W, Cin, Cout, use_gn, res is not None, add is not None))
+    gy = mk(*y.shape)
+    y.backward(gy); r.backward(gy.float())
+    check("conv dgrad", rel(x.grad, x32.grad), 1.5e-2, (N, H, W, Cin, Cout, use_gn))
+torch.cuda.synchronize()
+print("diffusion fuzz ok; worst relative errors:", {k: f"{v:.2e}" for k, v in worst.items()})

@@ -1,0 +1,24 @@
+"""The two randomised stress / fuzz scripts as `-m gpu` tests (each in a process of its own; ~20 s together on an MI355X):
+
+  tests/scripts/r5_raster_stress.py    60 random scene / image / SH-degree configurations of the rasterizer operator (each twice, images and
+                                       gradients bit-identical), then sizes past the bench's: 2 M and 5 M Gaussians, tile lists past 16 384
+                                       entries, blanket splats, 3840 x 2160, a side stream, strided inputs.  (Found the capacity-0 decode of a
+                                       one-instance binning chunk in round 5.)
+  tests/scripts/r5_diffusion_fuzz.py   random shapes through the MFMA GEMM (+ Linear with the LayerNorm fold), flash attention forward and
+                                       backward, the implicit-GEMM convolution forward and input gradient, against fp32 torch math."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("script,args,marker", [("r5_raster_stress.py", [], "strided inputs: ok"),
+                                                ("r5_diffusion_fuzz.py", ["11"], "diffusion fuzz ok"),
+                                                ("r5_diffusion_fuzz.py", ["23"], "diffusion fuzz ok")])
+def test_stress_script(script, args, marker):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "scripts", script)] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and marker in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
