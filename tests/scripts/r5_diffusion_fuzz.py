@@ -103,5 +103,61 @@ for it in range(60):
     gy = mk(*y.shape)
     y.backward(gy); r.backward(gy.float())
     check("conv dgrad", rel(x.grad, x32.grad), 1.5e-2, (N, H, W, Cin, Cout, use_gn))
+# ---- the other convolution forms: nearest x2 upsampling + 3x3, the two stride-2 Downsamples, the temporal (3, 1, 1) convolution ----
+for it in range(60):
+    form = rng.choice(["up", "s2", "s2hi", "temporal", "temporal_b"])
+    Cin = 32 * int(rng.integers(1, 9)); Cout = int(rng.choice([32, 64, 128, 320, 640]))
+    use_gn = rng.random() < 0.5
+    gn = None
+    if use_gn:
+        gn = torch.nn.GroupNorm(32, Cin).to(dev); gn.weight.data = 1 + 0.2 * torch.randn(Cin, device=dev, generator=g); gn.bias.data = 0.2 * torch.randn(Cin, device=dev, generator=g)
+        gn.requires_grad_(False)
+    if form in ("temporal", "temporal_b"):
+        T = int(rng.choice([2, 3, 5, 16, 25])); P = int(rng.choice([35, 140, 144, 560, 2240])); S = int(rng.choice([2, 3]))
+        Cout = Cin if rng.random() < 0.7 else Cout
+        cv = torch.nn.Conv3d(Cin, Cout, (3, 1, 1), padding=(1, 0, 0)).to(dev).half().requires_grad_(False)
+        cv.weight.data = mk(Cout, Cin, 3, 1, 1, scale=(3 * Cin) ** -0.5); cv.bias.data = mk(Cout, scale=0.1)
+        x = (mk(T, P, Cin) if form == "temporal" else mk(S, T, P, Cin)).requires_grad_(True)
+        mode, up, n_stat = mconv.TEMPORAL, False, (1 if form == "temporal" else S)
+        res = mk(*x.shape[:-1], Cout) if rng.random() < 0.4 else None
+    else:
+        N = int(rng.choice([1, 2, 5])); H = int(rng.choice([5, 7, 10, 16, 20, 40])); W = int(rng.choice([7, 14, 16, 28, 56]))
+        if form != "up" and rng.random() < 0.5: H, W = H + 1, W + 1     # odd and even inputs of the stride-2 forms
+        cv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).to(dev).half().requires_grad_(False)
+        cv.weight.data = mk(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5); cv.bias.data = mk(Cout, scale=0.1)
+        x = mk(N, H, W, Cin).requires_grad_(True)
+        mode = {"up": mconv.SPATIAL, "s2": mconv.STRIDE2, "s2hi": mconv.STRIDE2_PAD_HI}[form]
+        up, n_stat, res = form == "up", N, None
+    y, _ = mconv.fused_conv(x, cv, mode=mode, upsample=up, gn=gn, silu=use_gn, residual=res)
+    x32 = x.detach().float().requires_grad_(True)
+    r = mconv._reference(x32, cv.weight.float(), cv.bias.float(), mode, up, gn, use_gn, None, None if res is None else res.float(), n_stat)
+    assert y.shape == r.shape, (form, y.shape, r.shape)
+    check("conv forms fwd", rel(y, r.detach()), 6e-3, (form, tuple(x.shape), Cout, use_gn, res is not None))
+    if form == "s2hi":
+        continue   # the VAE encoder's Downsample is not on any differentiable path: its input gradient raises NotImplementedError by design
+    gy = mk(*y.shape)
+    y.backward(gy); r.backward(gy.float())
+    check("conv forms dgrad", rel(x.grad, x32.grad), 1.5e-2, (form, tuple(x.shape), Cout, use_gn))
+
+# ---- frame-major (temporal) attention: the wave-per-item kernel for short sequences, packed q | k | v, forward and backward ----
+for it in range(40):
+    heads = int(rng.choice([5, 10, 20])); T = int(rng.choice([2, 3, 5, 16, 25, 32])); P = int(rng.choice([1, 35, 140, 560, 1000]))
+    C = heads * 64
+    packed = rng.random() < 0.5
+    if packed:
+        qkv = mk(T, P, 3 * C).requires_grad_(True)
+        o = ops.self_attention_packed(qkv, heads, frame_major=True)
+        q32, k32, v32 = (qkv.detach()[..., i * C:(i + 1) * C].float().requires_grad_(True) for i in range(3))
+    else:
+        q, k, v = (mk(T, P, C).requires_grad_(True) for _ in range(3))
+        o = ops.attention(q, k, v, heads, frame_major=True)
+        q32, k32, v32 = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    r = ops.attention_math(q32, k32, v32, heads, frame_major=True)
+    check("temporal attention fwd", rel(o, r.detach()), 4e-3, (heads, T, P, packed))
+    go = mk(*o.shape)
+    o.backward(go); r.backward(go.float())
+    got = (qkv.grad[..., :C], qkv.grad[..., C:2 * C], qkv.grad[..., 2 * C:]) if packed else (q.grad, k.grad, v.grad)
+    for name, a, bb in zip(("dq", "dk", "dv"), got, (q32.grad, k32.grad, v32.grad)):
+        check("temporal attention bwd", float((a.float() - bb).abs().max() / bb.abs().max().clamp_min(1.0)), 1.2e-2, (name, heads, T, P, packed))
 torch.cuda.synchronize()
 print("diffusion fuzz ok; worst relative errors:", {k: f"{v:.2e}" for k, v in worst.items()})
