@@ -7,7 +7,9 @@
   tests/scripts/r5_diffusion_fuzz.py   random shapes through the MFMA GEMM (+ Linear with the LayerNorm fold), flash attention forward and
                                        backward, the implicit-GEMM convolution (all forms) forward and input gradient, against fp32 torch math.
   tests/scripts/r5_unet_shape_fuzz.py  a three-level miniature of the ViewCrafter U-Net on random (batch, frames, height, width, context length),
-                                       fp16 HIP path against the fp32 torch form, forward and input gradient."""
+                                       fp16 HIP path against the fp32 torch form, forward and input gradient.
+  tests/scripts/r5_vae_shape_fuzz.py   the same for a three-level VAE decoder miniature (512-wide mid attention head) on random (frames, height,
+                                       width, frames per call)."""
 import os
 import subprocess
 import sys
@@ -21,7 +23,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.parametrize("script,args,marker", [("r5_raster_stress.py", [], "strided inputs: ok"),
                                                 ("r5_diffusion_fuzz.py", ["11"], "diffusion fuzz ok"),
                                                 ("r5_diffusion_fuzz.py", ["23"], "diffusion fuzz ok"),
-                                                ("r5_unet_shape_fuzz.py", ["3", "16"], "unet shape fuzz ok")])
+                                                ("r5_unet_shape_fuzz.py", ["3", "16"], "unet shape fuzz ok"),
+                                                ("r5_vae_shape_fuzz.py", ["5", "12"], "vae shape fuzz ok")])
 def test_stress_script(script, args, marker):
     r = subprocess.run([sys.executable, os.path.join(HERE, "scripts", script)] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and marker in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
