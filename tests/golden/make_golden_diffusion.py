@@ -166,6 +166,22 @@ def main():
         xp, p0 = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
                                  guidance_rescale=0.7, loss_guidance_fn=LG(gi_, gm_))
         out[f"guided{index}_xprev"], out[f"guided{index}_x0"] = xp.numpy(), p0.numpy()
+    # G8b (round 5): the same step with recur_steps = 2 (viewcrafter_wrapper.py:51 default of LossGuidance; train_guidedvd.py passes
+    # opt.guidance_recur_steps = 1): two passes of the loop, four noise draws (sigma noise + re-noise per pass, ddim_guidance.py:287,360).
+    # The two extra noises come from a generator of their own so that every array above keeps its bits.
+    class LG2(LG):
+        recur_steps = 2
+    g3 = torch.Generator().manual_seed(333)
+    noises4 = noises + [torch.randn(1, 4, 5, 6, 7, generator=g3) for _ in range(2)]
+    out["step_noise2"], out["step_noise3"] = noises4[2].numpy(), noises4[3].numpy()
+    s = CPUGuided(duck)
+    s.make_schedule(50, "uniform_trailing", 1.0, verbose=False)
+    t = torch.full((1,), int(s.ddim_timesteps[40]), dtype=torch.long)
+    it = iter(noises4)
+    ddg_mod.noise_like = lambda shape, device, repeat=False: next(it)
+    xp, p0 = s.p_sample_ddim(x, cond, t, index=40, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                             guidance_rescale=0.7, loss_guidance_fn=LG2(gi_, gm_))
+    out["guided40_recur2_xprev"], out["guided40_recur2_x0"] = xp.numpy(), p0.numpy()
     # ---------------- G6b: a U-Net whose heads are 64 wide (the ViewCrafter head size) on a 16x24 latent: the case the
     # `-m gpu` tests push through the fp16 HIP path (MFMA attention needs d = 64; the convolution tiles need > 8x8) ----
     cfg64 = dict(cfg, num_head_channels=64, context_dim=64)
@@ -188,7 +204,12 @@ def main():
     gi = torch.randn(img.shape, generator=g2)
     (gz,) = torch.autograd.grad(img, z, gi)
     out["dec64_z"], out["dec64_img"], out["dec64_gi"], out["dec64_gz"] = z.detach().numpy(), img.detach().numpy(), gi.numpy(), gz.numpy()
-    np.savez_compressed(os.path.join(HERE, "diffusion_ref.npz"), **out)
+    path = os.path.join(HERE, "diffusion_ref.npz")
+    if os.path.exists(path):   # regenerating must not move an array that is already pinned
+        old = np.load(path)
+        moved = [k for k in old.files if k not in out or not np.array_equal(old[k], out[k])]
+        print("arrays that differ from the existing fixture:", moved or "none")
+    np.savez_compressed(path, **out)
     print("wrote", os.path.getsize(os.path.join(HERE, "diffusion_ref.npz")), "bytes;", len(out), "arrays")
 
 

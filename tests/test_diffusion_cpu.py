@@ -179,6 +179,32 @@ def test_guided_ddim_step_matches_reference(index):
     np.testing.assert_allclose(xp1.numpy(), xp.numpy(), rtol=1e-5, atol=1e-6 * np.abs(ref_xp).max())
 
 
+def test_guided_ddim_step_with_two_recurrence_passes_matches_reference():
+    """recur_steps = 2 (the default of the reference's LossGuidance, viewcrafter_wrapper.py:51; ddim_guidance.py:245-248,262-360): two passes
+    of guide -> update -> re-noise, four noise draws in the order sigma noise, re-noise, sigma noise, re-noise.  Against the golden of the
+    reference's sampler on the same stand-in model; the draws come from the sampler's generator hook in that order."""
+    from lvdm_amd.guidance import LossGuidance
+    from lvdm_amd.samplers import DDIMSamplerGuidance
+    duck = _Duck()
+    s = DDIMSamplerGuidance(duck)
+    s.make_schedule(50, "uniform_trailing", 1.0)
+    x, cond, uc = _duck_inputs()
+    lg = LossGuidance(ddim_steps=50, recur_steps=2)
+    lg.set_hw(6, 7)
+    lg.set_guidance_images(torch.tensor(G["guide_imgs"]))
+    lg.set_guidance_masks(torch.tensor(G["guide_masks"]))
+    draws = iter(torch.tensor(G[f"step_noise{i}"]) for i in range(4))
+    s._randn = lambda shape, device: next(draws)
+    t = torch.full((1,), int(s.ddim_timesteps[40]), dtype=torch.long)
+    xp, p0 = s.p_sample_ddim(x, cond, t, index=40, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                             guidance_rescale=0.7, loss_guidance_fn=lg)
+    assert next(draws, None) is None, "the step must consume exactly four noise tensors"
+    ref_xp, ref_p0 = G["guided40_recur2_xprev"], G["guided40_recur2_x0"]
+    assert float(np.abs(ref_xp - G["guided40_xprev"]).max()) > 1e-3        # the second pass moved the result
+    np.testing.assert_allclose(p0.numpy(), ref_p0, rtol=1e-4, atol=1e-5 * np.abs(ref_p0).max())
+    np.testing.assert_allclose(xp.numpy(), ref_xp, rtol=2e-4, atol=2e-5 * np.abs(ref_xp).max())
+
+
 def test_sampler_api_end_to_end_and_rng_order():
     """sample() signature/returns (ddim.py:61-134) and the generator draw order (x_T, then one draw per step)."""
     from lvdm_amd.samplers import DDIMSampler
