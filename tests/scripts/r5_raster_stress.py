@@ -9,7 +9,7 @@ import numpy as np, torch
 import synthetic as syn
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 dev = torch.device("cuda:0")
-rng = np.random.default_rng(7)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)   # (the -m gpu test runs seed 7; other seeds by hand)
 t = lambda a, rg=False: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=rg)
 
 def scene(P):
