@@ -663,6 +663,50 @@ __global__ void __launch_bounds__(256) k_gn_stats_nsc(const T* __restrict__ x, d
     for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[(long long)n * 2 * G + i], sh_g[i]);
 }
 
+// Channel concatenation of two token-major tensors (the U-Net decoder's `torch.cat([h, skip], dim=1)`, openaimodel3d.py:592) fused with
+// the statistics pass of the GroupNorm that follows it (the first norm of the ResBlock the concatenation feeds): one read of both
+// sources, one write of the concatenated rows, the sums on the way -- instead of a copy kernel and a second read of its result.
+// Lane map of k_gn_stats_nsc over the octets of the OUTPUT row; an octet lies entirely in one source (Ca, Cb multiples of 8).
+template <typename T>
+__global__ void __launch_bounds__(256) k_cat2_stats_nsc(const T* __restrict__ xa, const T* __restrict__ xb, T* __restrict__ out,
+                                                        double* __restrict__ stats, int Ca, int Cb, int G, long long S, int rows_per_block)
+{
+    typedef typename Tr<T>::vec8 vec8;
+    extern __shared__ double sh_g[];  // [G][2]
+    const int C = Ca + Cb, n = blockIdx.y, cpg = C / G, oct = C / 8, oct_a = Ca / 8;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh_g[i] = 0.0;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < S) ? r0 + rows_per_block : S;
+    const T* ba = xa + (long long)n * S * Ca;
+    const T* bb = xb + (long long)n * S * Cb;
+    T* bo = out + (long long)n * S * C;
+    const int Wd = oct_width(oct), rstep = 256 / Wd, lane_row = threadIdx.x / Wd;
+    for (int o = threadIdx.x % Wd; o < oct && lane_row < rstep; o += Wd) {
+        const bool from_a = o < oct_a;
+        const T* src = from_a ? ba + o * 8 : bb + (o - oct_a) * 8;
+        const long long pitch = from_a ? Ca : Cb;
+        float s[8], q[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s[k] = 0.f; q[k] = 0.f; }
+#pragma unroll 4
+        for (long long r = r0 + lane_row; r < r1; r += rstep) {
+            const vec8 v = *reinterpret_cast<const vec8*>(src + r * pitch);
+            *reinterpret_cast<vec8*>(bo + r * C + o * 8) = v;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float f = to_f(v[k]); s[k] += f; q[k] = fmaf(f, f, q[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int g = (o * 8 + k) / cpg;
+            atomicAdd(&sh_g[2 * g], (double)s[k]);
+            atomicAdd(&sh_g[2 * g + 1], (double)q[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&stats[(long long)n * 2 * G + i], sh_g[i]);
+}
+
 // NSC apply: same lane map as the statistics kernel -- a thread keeps the (a, b) pairs of its channel octet in registers and
 // streams down its rows (the earlier flat-index version re-read 64 B of coefficients per 16 B of data and paid a 64-bit division
 // per vector).
@@ -1265,6 +1309,25 @@ int gvd_group_norm_stats(const void* x, double* stats, int N, int C, long long S
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "launch k_gn_stats_*", e);
+    return 0;
+}
+
+int gvd_cat2_group_norm_stats(const void* xa, int Ca, const void* xb, int Cb, void* out, double* stats, int N, long long S, int G,
+                              int is_bf16, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const int C = Ca + Cb;
+    if (!xa || !xb || !out || !stats || N <= 0 || S <= 0 || Ca <= 0 || Cb <= 0 || G <= 0 || (Ca & 7) || (Cb & 7) || C % G)
+        return fail(-1, "gvd_cat2_group_norm_stats: channel counts must be positive multiples of 8 and Ca + Cb a multiple of G");
+    if (((uintptr_t)xa | (uintptr_t)xb | (uintptr_t)out) & 15) return fail(-1, "gvd_cat2_group_norm_stats: tensors must be 16-byte aligned");
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(double), stream);
+    if (e != hipSuccess) return fail(-2, "hipMemsetAsync(stats)", e);
+    const int rows = gn_stat_rows(N, S);
+    dim3 grid((unsigned)((S + rows - 1) / rows), (unsigned)N);
+    if (is_bf16) hipLaunchKernelGGL(k_cat2_stats_nsc<__bf16>, grid, dim3(256), (size_t)G * 16, stream, (const __bf16*)xa, (const __bf16*)xb, (__bf16*)out, stats, Ca, Cb, G, S, rows);
+    else hipLaunchKernelGGL(k_cat2_stats_nsc<_Float16>, grid, dim3(256), (size_t)G * 16, stream, (const _Float16*)xa, (const _Float16*)xb, (_Float16*)out, stats, Ca, Cb, G, S, rows);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(-2, "launch k_cat2_stats_nsc", e);
     return 0;
 }
 

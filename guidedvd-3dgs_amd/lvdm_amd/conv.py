@@ -179,6 +179,35 @@ def norm_state(gn, x=None, partial=None, n_stat=None, merge=1, group=None, S_tot
     return NormState(buf, N, C, G, S, gn.eps, g32, group)
 
 
+def cat_with_stats(a, b, gn):
+    """torch.cat([a, b], -1) of two token-major tensors [N, H, W, Ca] / [N, H, W, Cb] plus the NormState of GroupNorm `gn` over the result
+    (per-sample statistics), in ONE pass over the sources (gvd_cat2_group_norm_stats): the U-Net decoder's skip concatenation feeds a
+    ResBlock whose first norm would otherwise re-read the 0.3-0.6 GB tensor the copy kernel just wrote.  Inference path only (no autograd)."""
+    P, LL = ctypes.c_void_p, ctypes.c_longlong
+    N, H, W, Ca = a.shape
+    Cb = b.shape[-1]
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((N, H, W, Ca + Cb), dtype=a.dtype, device=a.device)
+    G = gn.num_groups
+    g32, b32 = ops._f32_param(gn.weight), ops._f32_param(gn.bias)
+    C, S = Ca + Cb, H * W
+    buf = torch.empty(2 * N * G + N * C, dtype=torch.float64, device=a.device)
+    L, st = ops.lib(), P(ops._stream())
+    with ops._on(a.device):
+        ops._check(L.gvd_cat2_group_norm_stats(P(a.data_ptr()), Ca, P(b.data_ptr()), Cb, P(out.data_ptr()), P(buf.data_ptr()), N, LL(S), G,
+                                               1 if a.dtype == torch.bfloat16 else 0, st))
+        ops._check(L.gvd_group_norm_coef(P(buf.data_ptr()), None, 1, 1, P(g32.data_ptr()), P(b32.data_ptr()), N, C, LL(S), G,
+                                         ctypes.c_float(gn.eps), st))
+    return out, NormState(buf, N, C, G, S, gn.eps, g32, None)
+
+
+def cat_with_stats_ok(a, b, gn):
+    """The fused concatenation applies: 16-bit token-major device tensors of one dtype, channel counts in octets, no gradient wanted."""
+    return (a.is_cuda and a.dtype in (torch.float16, torch.bfloat16) and b.dtype == a.dtype and a.shape[:-1] == b.shape[:-1]
+            and a.shape[-1] % 8 == 0 and b.shape[-1] % 8 == 0 and (a.shape[-1] + b.shape[-1]) % gn.num_groups == 0
+            and not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)) and not os.environ.get("GVD_NO_FUSED_CAT"))
+
+
 class _ZeroArena:
     """Zeroed fp64 scratch for the statistics accumulators of the convolution epilogues.  Every statistics-producing launch needs its
     own zeroed [replicas, samples, groups, 2] block (~110 per U-Net forward, 0.5-200 KB each); a `torch.zeros` per launch is a ~4 us

@@ -425,7 +425,7 @@ class ResBlock(nn.Module):
             h = _img(self.temopral_conv.forward_tokens(_tok(h), batch_size))
         return h
 
-    def _fwd_fused(self, x, emb, batch_size):
+    def _fwd_fused(self, x, emb, batch_size, norm1=None):
         """Two launches of the MFMA convolution (+ the 1x1 skip GEMM when channels change): both GroupNorm+SiLU pairs live in
         the operand loads, `+ emb_out`, `+ skip` and the 16-bit rounding in the epilogues; the first convolution leaves the
         statistics of its output for the second norm, the second for the temporal block's first norm."""
@@ -436,7 +436,8 @@ class ResBlock(nn.Module):
         # tok feeds conv1's norm and the skip path: the skip side hands its gradient to conv1's backward (ops.GradCell), which sums
         # it inside the GroupNorm-backward apply kernel -- no accumulation kernel where the two branches meet
         cell = _cell(tok)
-        h, part = mconv.fused_conv(tok, conv1, gn=gn1, silu=True, add_nc=emb_out, stats_groups=gn2.num_groups, grad_add=cell)
+        # norm1: the state of gn1 when the caller already has it (the decoder's fused skip concatenation, UNetModel.forward)
+        h, part = mconv.fused_conv(tok, conv1, gn=gn1, norm=norm1, silu=True, add_nc=emb_out, stats_groups=gn2.num_groups, grad_add=cell)
         ns2 = mconv.norm_state(gn2, partial=part)
         identity = isinstance(self.skip_connection, nn.Identity)
         if identity:
@@ -451,9 +452,9 @@ class ResBlock(nn.Module):
             h = self.temopral_conv.forward_tokens(h, batch_size, stats=part)
         return _img(h)
 
-    def forward(self, x, emb, batch_size=None):
+    def forward(self, x, emb, batch_size=None, norm1=None):
         if _fused(x, self):
-            return _run(lambda a, e: self._fwd_fused(a, e, batch_size), self.use_checkpoint, x, emb)
+            return _run(lambda a, e: self._fwd_fused(a, e, batch_size, norm1), self.use_checkpoint, x, emb)
         return _run(lambda a, e: self._fwd(a, e, batch_size), self.use_checkpoint, x, emb)
 
 
@@ -482,10 +483,10 @@ class Upsample(nn.Module):
 class TimestepEmbedSequential(nn.Sequential):
     """openaimodel3d.py:30-48: routes (emb | context | batch size) to the children that take them."""
 
-    def forward(self, x, emb, context=None, batch_size=None, shared_frames=1):
-        for layer in self:
+    def forward(self, x, emb, context=None, batch_size=None, shared_frames=1, norm1=None):
+        for i, layer in enumerate(self):
             if isinstance(layer, ResBlock):
-                x = layer(x, emb, batch_size=batch_size)
+                x = layer(x, emb, batch_size=batch_size, norm1=norm1 if i == 0 else None)
             elif isinstance(layer, SpatialTransformer):
                 x = layer(x, context, shared_frames)
             elif isinstance(layer, TemporalTransformer):
@@ -615,7 +616,16 @@ class UNetModel(nn.Module):
             hs.append(h)
         h = self.middle_block(h, emb, context, b, shared)
         for module in self.output_blocks:
-            h = module(torch.cat([h, hs.pop()], dim=1), emb, context, b, shared)
+            skip = hs.pop()
+            first = module[0]
+            if (shard is None and isinstance(first, ResBlock) and not first.training and h.is_cuda and h.dtype in (torch.float16, torch.bfloat16)
+                    and h.is_contiguous(memory_format=torch.channels_last) and skip.is_contiguous(memory_format=torch.channels_last)
+                    and mconv.cat_with_stats_ok(_tok(h), _tok(skip), first.in_layers[0])):
+                # the skip concatenation and the statistics of the ResBlock's first norm in one pass (inference; conv.cat_with_stats)
+                cat, ns = mconv.cat_with_stats(_tok(h), _tok(skip), first.in_layers[0])
+                h = module(_img(cat), emb, context, b, shared, norm1=ns)
+            else:
+                h = module(torch.cat([h, skip], dim=1), emb, context, b, shared)
         if _fused(h, self):
             y = _img(mconv.fused_conv(_tok(h), self.out[2], gn=self.out[0], silu=True)[0]).to(xin_dtype)
         else:

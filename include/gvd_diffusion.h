@@ -92,6 +92,12 @@ int gvd_group_norm(const void* x, void* y, const float* gamma, const float* beta
  * across the shard group, then _apply with S_total = the global element count per (sample, channel). */
 int gvd_group_norm_stats(const void* x, double* stats, int N, int C, long long S, int G, int channels_last, int is_bf16,
                          void* stream);
+/* torch.cat([a, b], channel dim) of two token-major tensors a [N][S][Ca], b [N][S][Cb] (the U-Net decoder's skip concatenation,
+ * openaimodel3d.py:592) fused with gvd_group_norm_stats of the result for the GroupNorm that follows (the first norm of the ResBlock the
+ * concatenation feeds, openaimodel3d.py:152): writes out [N][S][Ca + Cb] and the first 2*N*G doubles of `stats` in one pass over the
+ * sources.  Ca, Cb multiples of 8, (Ca + Cb) % G == 0.  Form the affine with gvd_group_norm_coef(stats, NULL, 1, 1, ...). */
+int gvd_cat2_group_norm_stats(const void* xa, int Ca, const void* xb, int Cb, void* out, double* stats, int N, long long S, int G,
+                              int is_bf16, void* stream);
 int gvd_group_norm_apply(const void* x, void* y, const float* gamma, const float* beta, double* stats,
                          int N, int C, long long S, long long S_total, int G, float eps, int silu, int channels_last,
                          int is_bf16, void* stream);

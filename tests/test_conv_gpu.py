@@ -473,3 +473,57 @@ def test_xcd_aware_grid_readings_are_permutations_of_the_same_work():
         assert r.returncode == 0 and lines, (tag, r.stdout[-500:], r.stderr[-2000:])
         digests[tag] = lines[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_fused_skip_concatenation_with_group_norm_statistics():
+    """conv.cat_with_stats (gvd_cat2_group_norm_stats): the decoder's `torch.cat([h, skip], channel)` and the statistics of the ResBlock's
+    first GroupNorm in one pass.  The concatenated rows must be the copy's bits; the (a, b) affine must equal the one a statistics pass over
+    the concatenated tensor gives (same per-lane partial sums, fp64 accumulation: equal to fp32 rounding), for equal and unequal halves,
+    groups that straddle no boundary and groups that do, f16 and bf16; and the U-Net must give the same output with the fused
+    concatenation as with torch.cat (GVD_NO_FUSED_CAT=1)."""
+    import os
+    from lvdm_amd import conv as mconv
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for dtype in (torch.float16, torch.bfloat16):
+        for (N, H, W, Ca, Cb) in ((3, 9, 16, 320, 320), (2, 18, 33, 640, 320), (5, 5, 7, 1280, 1280), (1, 40, 56, 64, 32), (2, 7, 5, 8, 24)):
+            a = (torch.randn(N, H, W, Ca, device=DEV, generator=g) * 1.5 + 0.3).to(dtype)
+            b = (torch.randn(N, H, W, Cb, device=DEV, generator=g) * 0.7 - 0.2).to(dtype)
+            gn = torch.nn.GroupNorm(32 if (Ca + Cb) % 32 == 0 else 8, Ca + Cb).to(DEV)
+            gn.weight.data = 1 + 0.2 * torch.randn(Ca + Cb, device=DEV, generator=g)
+            gn.bias.data = 0.2 * torch.randn(Ca + Cb, device=DEV, generator=g)
+            assert mconv.cat_with_stats_ok(a, b, gn)
+            out, ns = mconv.cat_with_stats(a, b, gn)
+            ref = torch.cat([a, b], dim=-1)
+            assert torch.equal(out, ref)
+            ns_ref = mconv.norm_state(gn, x=ref, n_stat=N)
+            k = 2 * N * gn.num_groups
+            assert torch.allclose(ns.buf[:k], ns_ref.buf[:k], rtol=1e-12, atol=0.0)            # fp64 sums: atomics order only
+            co, co_ref = ns.buf[k:].view(torch.float32), ns_ref.buf[k:].view(torch.float32)
+            assert torch.allclose(co, co_ref, rtol=1e-6, atol=1e-7), float((co - co_ref).abs().max())
+    # with a gradient wanted the fused form steps aside
+    assert not mconv.cat_with_stats_ok(a.requires_grad_(True), b, gn)
+    # the network: same output either way
+    from test_diffusion_goldens_gpu import UNET64
+    from lvdm_amd.unet import UNetModel
+    from fill_by_name import fill_by_name
+    unet = fill_by_name(UNetModel(**UNET64)).half().eval().to(DEV).to_token_major().requires_grad_(False)
+    x = torch.randn(1, 8, 4, 16, 24, device=DEV, generator=g).half()
+    ctx = torch.randn(1, 93, 64, device=DEV, generator=g).half()
+    calls = {"n": 0}
+    orig = mconv.cat_with_stats
+
+    def counted(*a_, **k_):
+        calls["n"] += 1
+        return orig(*a_, **k_)
+    mconv.cat_with_stats = counted
+    try:
+        with torch.no_grad():
+            y_fused = unet(x, torch.tensor([300], device=DEV), context=ctx, fs=torch.tensor([10], device=DEV))
+            n_fused = calls["n"]
+            os.environ["GVD_NO_FUSED_CAT"] = "1"
+            y_plain = unet(x, torch.tensor([300], device=DEV), context=ctx, fs=torch.tensor([10], device=DEV))
+    finally:
+        os.environ.pop("GVD_NO_FUSED_CAT", None)
+        mconv.cat_with_stats = orig
+    assert n_fused == len(unet.output_blocks) and calls["n"] == n_fused, (n_fused, calls["n"])
+    assert float((y_fused.float() - y_plain.float()).abs().max()) <= 2e-3 * float(y_plain.float().abs().max())
