@@ -6,6 +6,7 @@
                                        one-instance binning chunk in round 5.)
   tests/scripts/r5_raster_threads.py   two host threads on two streams rendering + back-propagating concurrently through the compiled operator (GIL
                                        released in the native call): bit-identical to the single-threaded results.
+  tests/scripts/r5_raster_soak.py      12 000 training iterations with densification-like changes of the point count: device and host memory flat.
   tests/scripts/r5_diffusion_fuzz.py   random shapes through the MFMA GEMM (+ Linear with the LayerNorm fold), flash attention forward and
                                        backward, the implicit-GEMM convolution (all forms) forward and input gradient, against fp32 torch math.
   tests/scripts/r5_unet_shape_fuzz.py  a three-level miniature of the ViewCrafter U-Net on random (batch, frames, height, width, context length),
@@ -24,6 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("script,args,marker", [("r5_raster_stress.py", [], "strided inputs: ok"),
                                                 ("r5_raster_threads.py", [], "bit-identical to the single-threaded run"),
+                                                ("r5_raster_soak.py", ["12000"], "raster soak ok"),
                                                 ("r5_diffusion_fuzz.py", ["11"], "diffusion fuzz ok"),
                                                 ("r5_diffusion_fuzz.py", ["23"], "diffusion fuzz ok"),
                                                 ("r5_unet_shape_fuzz.py", ["3", "16"], "unet shape fuzz ok"),
