@@ -9,6 +9,8 @@
   tests/scripts/r5_raster_soak.py      12 000 training iterations with densification-like changes of the point count: device and host memory flat.
   tests/scripts/r5_diffusion_fuzz.py   random shapes through the MFMA GEMM (+ Linear with the LayerNorm fold), flash attention forward and
                                        backward, the implicit-GEMM convolution (all forms) forward and input gradient, against fp32 torch math.
+  tests/scripts/r5_guided_soak.py      240 guided + 240 plain DDIM steps on the miniature: allocator and host memory flat (GradCells, norm states,
+                                       caches, autograd graphs all released).
   tests/scripts/r5_unet_shape_fuzz.py  a three-level miniature of the ViewCrafter U-Net on random (batch, frames, height, width, context length),
                                        fp16 HIP path against the fp32 torch form, forward and input gradient.
   tests/scripts/r5_vae_shape_fuzz.py   the same for a three-level VAE decoder miniature (512-wide mid attention head) on random (frames, height,
@@ -28,6 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
                                                 ("r5_raster_soak.py", ["12000"], "raster soak ok"),
                                                 ("r5_diffusion_fuzz.py", ["11"], "diffusion fuzz ok"),
                                                 ("r5_diffusion_fuzz.py", ["23"], "diffusion fuzz ok"),
+                                                ("r5_guided_soak.py", ["240"], "guided soak ok"),
                                                 ("r5_unet_shape_fuzz.py", ["3", "16"], "unet shape fuzz ok"),
                                                 ("r5_vae_shape_fuzz.py", ["5", "12"], "vae shape fuzz ok")])
 def test_stress_script(script, args, marker):
