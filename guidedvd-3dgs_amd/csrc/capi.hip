@@ -38,11 +38,15 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
     } while (0)
 
 // CHECK_CUDA of auxiliary.h:166-173: in debug mode synchronise after each launch and report.
+// GVD_RASTER_TRACE_LAUNCHES=1 (environment): the same synchronisation for every caller plus one stderr line per launch -- the last line
+// printed before a GPU memory fault names the kernel.
+static const bool g_trace_launches = getenv("GVD_RASTER_TRACE_LAUNCHES") != nullptr;
 #define AFTER_LAUNCH(name)                                                              \
     do {                                                                                \
         hipError_t e_ = hipGetLastError();                                              \
         if (e_ != hipSuccess) return fail(GVD_ERR_HIP, "launch " name, e_);             \
-        if (debug) {                                                                    \
+        if (debug || g_trace_launches) {                                                \
+            if (g_trace_launches) { fprintf(stderr, "[gvd] sync after %s\n", name); fflush(stderr); }   \
             e_ = hipStreamSynchronize(stream);                                          \
             if (e_ != hipSuccess) return fail(GVD_ERR_HIP, "kernel " name, e_);         \
         }                                                                               \
@@ -259,6 +263,8 @@ int forward_stage2(const FwdIn& in, const gvd::Layout& L, char* geom, char* bin,
     ra.n_contrib = (uint32_t*)(img + L.n_contrib);
     ra.tile_order = (const uint32_t*)(img + L.tile_order);
     ra.qmask = (uint8_t*)(bin + L.qmask);
+    // what the sorts queued above cover (k_sort_tiles<1>: <= 16384, <2>: any length; the blend kernel's own sort: <= kFusedSortMax)
+    ra.sorted_limit = max_class >= 2 ? 0xffffffffu : (max_class == 1 ? 16384u : kFusedSortMax);
     {
         ProfScope ps("render_fwd", stream);
         launch_render_fwd(ra, L.T, stream);

@@ -629,6 +629,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a)
     const uint32_t r0 = a.ranges[2 * tile];
     uint32_t r1 = a.ranges[2 * tile + 1];
     if (r1 > a.capacity) r1 = r0;  // overflowed forward: render background, status already flagged
+    if (r1 - r0 > a.sorted_limit) r1 = r0;   // mis-guessed sort class (speculative forward): this list was never sorted, its ids are garbage
     const uint32_t n = r1 - r0;
 #ifdef GVD_RFWD_TRACE
     const unsigned long long tf0 = __builtin_amdgcn_s_memtime();

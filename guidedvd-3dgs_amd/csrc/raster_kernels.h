@@ -57,6 +57,9 @@ struct RenderArgs {
     float *out_color, *out_depth, *out_alpha;
     uint32_t* n_contrib;
     uint8_t* qmask;       // [4][capacity]: plane w, list position: 1 = the entry passed wave w's quadrant test (read by k_render_bwd)
+    uint32_t sorted_limit; // longest list that has been sorted for this launch (by the sort kernels queued before it, or here): a speculative
+                           // forward guesses the sort class; a list longer than the guess covers has NO point_list yet (uninitialised ids)
+                           // and must not be walked -- the host re-runs the exact path for such a forward anyway
 };
 
 struct RenderBwdArgs {

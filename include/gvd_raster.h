@@ -27,7 +27,8 @@
  * (P, width, height) on, stage 2 is queued speculatively BEFORE that wait, see capi.hip),
  * unless the caller passes a capacity through gvd_raster_forward_capped (no sync).
  * Environment switches (read once): GVD_RASTER_SPECULATE=0 (wait, then launch stage 2), GVD_RASTER_FUSED_SORT=0
- * (separate per-tile sort launch instead of sorting inside the forward blend kernel), GVD_RASTER_LIB (Python side: path
+ * (separate per-tile sort launch instead of sorting inside the forward blend kernel), GVD_RASTER_TRACE_LAUNCHES=1 (synchronise after
+ * every launch and print its name to stderr first: the last line before a GPU memory fault names the kernel), GVD_RASTER_LIB (Python side: path
  * of this library).  None of them changes a result.
  * Not re-entrant on one stream from several host threads.
  *

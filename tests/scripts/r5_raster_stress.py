@@ -25,7 +25,7 @@ def run(P, W, H, deg, sc, cam, grad, gC):
     lv = dict(means3D=t(xyz, grad), opacities=t(op, grad), scales=t(scales, grad), rotations=t(q, grad), shs=t(sh, grad),
               means2D=torch.zeros(P, 3, device=dev, requires_grad=grad))
     s = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], t([0.1, 0.2, 0.3]), 1.0, t(cam["viewmatrix"]), t(cam["projmatrix"]),
-                                      deg, t(cam["campos"]), False, False, torch.ones(P, 1, device=dev))
+                                      deg, t(cam["campos"]), False, bool(os.environ.get("GVD_STRESS_DEBUG")), torch.ones(P, 1, device=dev))
     if not grad:
         with torch.no_grad():
             c, r, d, a = GaussianRasterizer(s)(**lv)
@@ -46,10 +46,16 @@ for it in range(60):
     gC = torch.randn(3, H, W, device=dev) / (H * W)
     outs = []
     print(f"it {it}: P {P} {W}x{H} deg {deg}", flush=True)
+    skip = it < int(os.environ.get("GVD_STRESS_FROM", "0"))   # (replaying a seed from iteration k on: same random draws, no renders before k)
+    if os.environ.get("GVD_STRESS_ONLY"):
+        skip = str(it) not in os.environ["GVD_STRESS_ONLY"].split(",")
     for rep in range(2):
-        if rng.random() < 0.3:
+        if rng.random() < 0.3 and not skip:
             run(P, W, H, deg, sc, cam, False, gC)            # a no-grad render in between (skips the backward preparation)
-        outs.append(run(P, W, H, deg, sc, cam, True, gC))
+        if not skip:
+            outs.append(run(P, W, H, deg, sc, cam, True, gC))
+    if skip:
+        continue
     (c0, g0), (c1, g1) = outs
     assert torch.isfinite(c0).all() and torch.equal(c0, c1), (it, P, W, H)
     for k in g0:

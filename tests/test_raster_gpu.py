@@ -464,6 +464,39 @@ def test_speculative_stage2_misprediction_falls_back_exactly():
     assert Rs[1] > 1.5 * Rs[0], Rs   # the second render really overflows the speculative capacity
 
 
+def test_speculative_forward_with_a_mis_guessed_sort_class_never_walks_an_unsorted_list():
+    """The speculative stage 2 also guesses the SORT CLASS from the longest tile list seen for a (P, W, H).  When a later render of that size
+    has lists past the guess (here: <= 2048 entries first, then > 2048 and > 16384 in one 32 x 32 image), the sort kernels queued
+    speculatively do not cover them, so `point_list` holds whatever the allocator handed out -- and `k_render_fwd` used to walk it: a GPU
+    memory fault on ids from recycled memory (round 5, tests/scripts/r5_raster_stress.py seed 203; the Python operator's heap layout had hidden it).
+    The freed blocks the binning chunk will be carved from are poisoned with huge ids first; the mis-guessed forward must blend nothing from such
+    a list and the exact re-run must match the oracle."""
+    dev = torch.device("cuda:0")
+    for P, W, expect in ((6000, 128, 2048), (40000, 256, 16384)):
+        wide = _tiny(9, P=P, W=W, H=W, deg=0, spread=2.2)             # spread over the whole image: many instances, short lists
+        wide["opacities"][:] = 0.02
+        cam = wide["cameras"][0]
+        grads = _grads(W, W, 9)
+        st_o, g_o = run_oracle(wide, cam, grads)
+        R_wide = int(st_o["R"])
+        assert (st_o["ranges"][:, 1] - st_o["ranges"][:, 0]).max() * 1.25 <= expect      # the guessed class stops at `expect`
+        st_h, g_h = run_hip(wide, cam, grads)                         # sets the hint for (P, W, W): capacity ~ R_wide, the lower sort class
+        _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, n_contrib_outliers=2e-3, img_outliers=2e-3)
+        pile = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in wide.items()}
+        rng = np.random.default_rng(4)
+        pile["means3D"][:, :2] = (rng.normal(size=(P, 2)) * 0.01 + np.array([0.3, 0.3])).astype(np.float32)   # one small pile inside a tile
+        pile["means3D"][:, 2] = (3.5 + rng.uniform(-0.5, 0.5, size=P)).astype(np.float32)
+        pile["scales"] = (wide["scales"] * 0.2).astype(np.float32)
+        st_o, g_o = run_oracle(pile, cam, grads)
+        lens = st_o["ranges"][:, 1] - st_o["ranges"][:, 0]
+        assert lens.max() > expect and int(st_o["R"]) <= R_wide, (int(lens.max()), int(st_o["R"]), R_wide)   # fits the capacity, not the class
+        for _ in range(3):                                            # poison what the caching allocator will hand out next
+            junk = [torch.full((n,), 0x7f7f7f7f, dtype=torch.int32, device=dev) for n in (1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24)]
+            del junk
+        st_h, g_h = run_hip(pile, cam, grads)                         # speculative with the stale class -> must not fault -> exact re-run
+        _check(compare(st_h, st_o, g_h, g_o, verbose=False), grad_tol=2e-3, n_contrib_outliers=2e-3, img_outliers=2e-3)
+
+
 def test_many_outstanding_speculative_forwards_then_backward():
     """80 renders of the same size are kept alive (all but the first laid out speculatively, every one in its own
     binning chunk) and differentiated afterwards in reverse order: each gradient must equal the one obtained from a
