@@ -64,6 +64,36 @@ for it in range(60):
 torch.cuda.synchronize()
 print(f"raster stress: {n} configurations x 2 runs, images and gradients finite and bit-identical between runs")
 
+# ---- training-like section: ONE scene and image size, a different camera every iteration (what the speculation hints see in a training
+#      run): distances from inside the cloud to far away make num_rendered and the longest tile list jump by orders of magnitude, so the
+#      speculative stage 2 mis-guesses capacity and sort class again and again.  Two passes over the same camera sequence: the hint
+#      state differs between them (exact path / speculative / re-run), the results must not ----
+P, W, H = 30000, 320, 240
+sc = scene(P)
+crng = np.random.default_rng(int(rng.integers(1 << 30)))
+cams = []
+for i in range(100):
+    dist = float(np.exp(crng.uniform(np.log(0.05), np.log(12.0))))
+    eye = crng.normal(size=3); eye = eye / np.linalg.norm(eye) * dist + np.array([0.0, 0.0, 1.5])
+    cams.append(syn.make_camera(syn.look_at(tuple(eye), (0.0, 0.0, 1.5)), math.radians(crng.uniform(25, 100)), math.radians(crng.uniform(20, 90)), W, H))
+gC = torch.randn(3, H, W, device=dev) / (H * W)
+passes = []
+for pas in range(2):
+    res = []
+    for i, cam in enumerate(cams):
+        if (i + pas) % 7 == 0:
+            run(P, W, H, 3, sc, cam, False, gC)
+        c, g_ = run(P, W, H, 3, sc, cam, True, gC)
+        res.append((c, g_))
+    passes.append(res)
+for i, ((c0, g0), (c1, g1)) in enumerate(zip(*passes)):
+    assert torch.isfinite(c0).all() and torch.equal(c0, c1), ("camera", i)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all() and torch.equal(g0[k], g1[k]), ("camera", i, k)
+torch.cuda.synchronize()
+print("training-like: 100 cameras x 2 passes over one scene, bit-identical between passes")
+del passes
+
 # ---- heavy section: sizes past the bench's (each twice, bit-identical; on a side stream; strided inputs) ----
 def pile(P, spread):          # every Gaussian in front of the camera inside a small disc: one or a few very long tile lists
     xyz = rng.normal(size=(P, 3)) * np.array([spread, spread, 0.3]); xyz[:, 2] = np.abs(xyz[:, 2]) + 2.0

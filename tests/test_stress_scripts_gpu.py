@@ -1,9 +1,10 @@
 """The two randomised stress / fuzz scripts as `-m gpu` tests (each in a process of its own; ~20 s together on an MI355X):
 
   tests/scripts/r5_raster_stress.py    60 random scene / image / SH-degree configurations of the rasterizer operator (each twice, images and
-                                       gradients bit-identical), then sizes past the bench's: 2 M and 5 M Gaussians, tile lists past 16 384
+                                       gradients bit-identical), one scene under 100 cameras from inside the cloud to far away (two passes with different
+                                       speculation state, bit-identical), then sizes past the bench's: 2 M and 5 M Gaussians, tile lists past 16 384
                                        entries, blanket splats, 3840 x 2160, a side stream, strided inputs.  (Found the capacity-0 decode of a
-                                       one-instance binning chunk in round 5.)
+                                       one-instance binning chunk and the unsorted-list walk of a mis-guessed speculative forward in round 5.)
   tests/scripts/r5_raster_threads.py   two host threads on two streams rendering + back-propagating concurrently through the compiled operator (GIL
                                        released in the native call): bit-identical to the single-threaded results.
   tests/scripts/r5_raster_soak.py      12 000 training iterations with densification-like changes of the point count: device and host memory flat.
