@@ -730,3 +730,32 @@ def test_packed_self_attention_reads_and_writes_the_projection_in_place(frame_ma
             assert torch.equal(base, full)
             acc = ops.attention(q, ctx_kv[..., :C], ctx_kv[..., C:], H, accum=o2.detach(), accum_scale=1.0)
             assert torch.equal(acc, o2.detach() + base)
+
+
+def test_reloaded_weights_are_not_served_from_stale_packed_caches():
+    """The MFMA paths cache re-laid-out weight images on the parameters (packed convolution slabs, LayerNorm-folded / GEGLU-permuted / concatenated
+    GEMM images, fp32 copies of norm parameters).  A checkpoint loaded INTO a model that has already run (load_state_dict copies in place: same
+    tensors, same addresses, a version bump) must invalidate every one of them: the U-Net and the VAE decoder evaluated after the reload must equal
+    fresh models built with the new weights bit for bit."""
+    import copy
+    from lvdm_amd.unet import UNetModel
+    from lvdm_amd.vae import AutoencoderKLDecoder
+    from test_ddim_parallel_gloo import SMALL_UNET, SMALL_VAE
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(1, 8, 3, 16, 24, device=DEV, generator=g).half()
+    ctx = torch.randn(1, 93, 64, device=DEV, generator=g).half()
+    z = torch.randn(2, 4, 12, 20, device=DEV, generator=g).half()
+    t, fs = torch.tensor([300], device=DEV), torch.tensor([10], device=DEV)
+    mk_u = lambda std: fill_by_name(UNetModel(**SMALL_UNET), std=std).half().eval().to(DEV).to_token_major().requires_grad_(False)
+    mk_v = lambda std: fill_by_name(AutoencoderKLDecoder(SMALL_VAE), std=std).half().eval().to(DEV).to_token_major().requires_grad_(False)
+    with torch.no_grad():
+        u_old, v_old = mk_u(0.05), mk_v(0.05)
+        y_old, d_old = u_old(x, t, context=ctx, fs=fs), v_old.decode(z)            # fills every cache with the OLD weights
+        u_new, v_new = mk_u(0.03), mk_v(0.03)
+        y_new, d_new = u_new(x, t, context=ctx, fs=fs), v_new.decode(z)
+        assert float((y_new.float() - y_old.float()).abs().max()) > 1e-3           # the two weight sets do differ
+        u_old.load_state_dict(copy.deepcopy(u_new.state_dict()))                   # in place: same parameter tensors, new contents
+        v_old.load_state_dict(copy.deepcopy(v_new.state_dict()))
+        y_re, d_re = u_old(x, t, context=ctx, fs=fs), v_old.decode(z)
+    assert torch.equal(y_re, y_new), float((y_re.float() - y_new.float()).abs().max())
+    assert torch.equal(d_re, d_new), float((d_re.float() - d_new.float()).abs().max())
