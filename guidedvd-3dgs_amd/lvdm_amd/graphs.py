@@ -48,9 +48,20 @@ class GraphedApplyModel:
     def __init__(self, model, warmup=2):
         self.model, self.warmup = model, warmup
         self._graphs = {}
+        self._params = None      # (parameter, version at capture): a graph holds the ADDRESSES of the packed weight images of its capture
+
+    def _weights_changed(self):
+        """A checkpoint loaded in place after a capture (load_state_dict: a version bump per parameter) re-packs the weight images at new
+        addresses on the next eager call -- a captured graph would keep replaying the old (freed) ones.  ~700 attribute reads per call."""
+        if self._params is None:
+            return False
+        return any(p._version != v for p, v in self._params)
 
     @torch.no_grad()
     def apply(self, x, t, cond, **kw):
+        if self._weights_changed():
+            self._graphs.clear()
+            self._params = None
         key = (_sig(x), _sig(t), _sig(cond), _sig(kw))
         ent = self._graphs.get(key)
         if ent is None:
@@ -75,4 +86,7 @@ class GraphedApplyModel:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.model.apply_model(sx, st, sc, **skw)
+        if self._params is None:
+            ps = list(self.model.parameters()) if hasattr(self.model, "parameters") else []
+            self._params = [(p, p._version) for p in ps]
         return sx, st, sc, skw, graph, out

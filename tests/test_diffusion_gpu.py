@@ -568,6 +568,44 @@ def test_graph_replayed_unet_evaluation_matches_eager():
         assert float((a - b).abs().max()) < 3e-3 * float(a.abs().max())
 
 
+def test_graph_replay_after_an_in_place_checkpoint_load_uses_the_new_weights():
+    """graphs.GraphedApplyModel: a captured hipGraph holds the addresses of the packed weight images of its capture.  A checkpoint loaded in
+    place afterwards (load_state_dict: same parameters, version bump) re-packs them elsewhere -- the graph must be dropped and re-captured,
+    not replayed on the old (freed) images (round 5)."""
+    import copy
+    from lvdm_amd.graphs import GraphedApplyModel
+    from lvdm_amd.unet import UNetModel
+    from test_ddim_parallel_gloo import SMALL_UNET
+    mk_u = lambda std: fill_by_name(UNetModel(**SMALL_UNET), std=std).half().eval().to(DEV).to_token_major().requires_grad_(False)
+
+    class M(torch.nn.Module):
+        def __init__(self, unet):
+            super().__init__()
+            self.unet = unet
+
+        def apply_model(self, x, t, cond, **kw):
+            return self.unet(x, t, context=cond["ctx"], fs=kw.get("fs"))
+
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(1, 8, 3, 16, 24, device=DEV, generator=g).half()
+    cond = {"ctx": torch.randn(1, 93, 64, device=DEV, generator=g).half()}
+    t, fs = torch.tensor([300], device=DEV), torch.tensor([10], device=DEV)
+    m = M(mk_u(0.05))
+    gm = GraphedApplyModel(m)
+    with torch.no_grad():
+        y_old = gm.apply(x, t, cond, fs=fs)
+        assert float((y_old.float() - m.apply_model(x, t, cond, fs=fs).float()).abs().max()) <= 3e-3 * float(y_old.float().abs().max())
+        fresh = mk_u(0.03)
+        m.unet.load_state_dict(copy.deepcopy(fresh.state_dict()))
+        for _ in range(4):                                   # recycle freed blocks: a stale graph would now read other tensors' bytes
+            junk = [torch.full((n,), 3.0, dtype=torch.float16, device=DEV) for n in (1 << 14, 1 << 16, 1 << 18, 1 << 20)]
+            del junk
+        y_new = gm.apply(x, t, cond, fs=fs)
+        ref = fresh(x, t, context=cond["ctx"], fs=fs)
+    assert float((ref.float() - y_old.float()).abs().max()) > 1e-3
+    assert float((y_new.float() - ref.float()).abs().max()) <= 3e-3 * float(ref.float().abs().max())
+
+
 @pytest.mark.parametrize("seed", list(range(14)))
 def test_attention_randomized_shapes_and_score_ranges(seed):
     """Seeded sweep around the kernel's tile boundaries (32-query blocks, 64-key tiles, the 64 / 512-query dispatch
