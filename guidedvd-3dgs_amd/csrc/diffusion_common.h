@@ -17,12 +17,14 @@ int fail(int code, const char* what, hipError_t e = hipSuccess);   // records th
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Tr;
 template <> struct Tr<_Float16> {
     typedef h8 vec8;
     static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f4v mfma16(vec8 a, vec8 b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi)
     {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -42,6 +44,7 @@ template <> struct Tr<_Float16> {
 template <> struct Tr<__bf16> {
     typedef b8 vec8;
     static __device__ __forceinline__ f16v mfma(vec8 a, vec8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f4v mfma16(vec8 a, vec8 b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi)
     {
         typedef __bf16 b2 __attribute__((ext_vector_type(2)));

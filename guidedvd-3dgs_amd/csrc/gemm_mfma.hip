@@ -57,6 +57,9 @@ struct GemmArgs {
 #ifndef GVD_GEMM_KUNROLL5
 #define GVD_GEMM_KUNROLL5 4   // (2 measured 1-3 % slower once the kernels stopped spilling)
 #endif
+#ifndef GVD_GEMM_RDAHEAD
+#define GVD_GEMM_RDAHEAD 2   // A fragments read ahead of their MFMAs (steps of 4 MFMAs)
+#endif
 #ifndef GVD_GEMM_NT_STORE
 #define GVD_GEMM_NT_STORE 1   // the output rows leave as non-temporal stores (0: plain, for A/B builds): a 150-590 MB output of the level-0 shapes only
                               // passes through the caches on its way out -- 230 400 x 960 x 320 0.259 -> 0.234 ms, x 2560 0.588 -> 0.551, DDIM step
@@ -65,7 +68,7 @@ struct GemmArgs {
 #ifndef GVD_GEMM_DBG
 #define GVD_GEMM_DBG 0   // experiments only (tests/scripts/build_gemm_variants.sh): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue, 8 = one K-tile only, 16 = no global stores
 #endif
-constexpr int BM = 256, NI = 2, WN = 4;   // tokens per tile: 4 wave columns x 2 blocks of 32
+constexpr int BM = 256, WN = 4;   // tokens per tile: 4 wave columns x 4 blocks of 16
 __device__ const uint4 g_zero16 = { 0u, 0u, 0u, 0u };   // source of K-tail slots
 #ifdef GVD_GEMM_TRACE
 __device__ unsigned long long g_trace[1024];   // experiments: s_memtime stamps of workgroup 0, every wave (128 slots = 16 tiles each): tests/scripts/r4_gemm_trace.py
@@ -104,36 +107,42 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 {
     typedef typename Tr<T>::vec8 vec8;
     typedef T T2 __attribute__((ext_vector_type(2)));
-    constexpr int NT = WM * WN * 64, ROWB = BK * 2, SPR = ROWB / 16, KS = BK / 16;
+    constexpr int NT = WM * WN * 64, ROWB = BK * 2, SPR = ROWB / 16, KS2 = BK / 32;
+    constexpr int MB = MI * 2, NB = 4;              // 16-row blocks of a wave: MB along the channels (A operand), NB along the tokens (B operand)
     constexpr int BN = WM * MI * 32;
     constexpr int STAGE = (BN + BM) * ROWB;
     constexpr int NQ = STAGE / 16;                  // 16-byte DMA pieces per stage
     constexpr int NP = (NQ + NT - 1) / NT;          // ... per thread
-    constexpr int KUNROLL = (MI == 5 && KS == 4) ? GVD_GEMM_KUNROLL5 : KS;   // (5-block tiles sit at the register cap: see tile_n)
     constexpr int EP_PITCH = MI * 64 + 16;          // epilogue staging: one token row of a wave (MI * 32 channels, 16 bit) + pad
     static_assert(NQ % 64 == 0 && (BN * SPR) % 64 == 0, "a wave's DMA instruction is one kind of row");
-    // XOR of the 16-byte slot that makes the ds_read_b128 operand reads (16-lane groups {0-3,12-15,20-27} ...) conflict free
-    auto swz = [](int row) { return SPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+    // XOR of a row's 16-byte slots that makes the ds_read_b128 operand reads conflict free.  A 16 x 16 x 32 operand read has lane
+    // (r16 = lane & 15, g4 = lane >> 4) fetch slot 4 ks + g4 of row r16 of its block; the LDS serves the 16-lane groups {0-3, 12-15,
+    // 20-27}, {4-11, 16-19, 28-31} (+ 32), i.e. rows {0-3, 12-15 | 4-11} at slots {g | g + 1}.  128-byte rows (two rows per 64-bank
+    // line): slot ^ ((row >> 1) & 7) gives each group 8 distinct slots x 2 row parities.  64-byte rows (four rows per line): slot ^
+    // perm[(row >> 2) & 3] with perm = (0, 2, 3, 1) gives 4 distinct slots x 4 rows-mod-4 in every group (the plain (row >> 2) & 3
+    // of the 32 x 32 x 16 reads would put rows 0-3 and 4-7 of a group on the same slot).  Both depend on row mod 16 only.
+    auto swz = [](int row) { return SPR == 8 ? ((row >> 1) & 7) : ((0x78 >> (((row >> 2) & 3) * 2)) & 3); };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // Per-lane geometry.  Re-derived from the thread id at the top of every tile (behind an opaque asm): kept live across the
     // whole persistent loop these ~25 values were spilled to scratch by the 5-block kernels (160 accumulators + fragments at the
     // 256-register cap) and reloaded with exposed latency (~10k cycles per tile); recomputing them is ~30 VALU instructions.
-    int lane, wave, hi, r32, wm, wn, lrow, lslot;
-    int a_off[KS], b_off[NI];   // MFMA operand addresses within a stage (32-row block offsets do not change swz(row))
+    int lane, wave, g4, r16, wm, wn, lrow, lslot;
+    int a_base, sl[KS2], b_off[NB];   // MFMA operand addresses within a stage (16-row block offsets do not change swz(row))
     auto geometry = [&]() {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
         lane = t & 63; wave = t >> 6;
         wave = __builtin_amdgcn_readfirstlane(wave);
-        hi = lane >> 5; r32 = lane & 31;
+        g4 = lane >> 4; r16 = lane & 15;
         wm = wave / WN; wn = wave % WN;
         lrow = lane / SPR;
-        lslot = (lane % SPR) ^ (SPR == 8 ? ((wave * 4 + (lane >> 4)) & 7) : ((wave * 4 + (lane >> 4)) & 3));
+        lslot = (lane % SPR) ^ swz(lane / SPR + wave * (64 / SPR));
+        a_base = (wm * MI * 32 + r16) * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) a_off[ks] = (wm * MI * 32 + r32) * ROWB + (((2 * ks + hi) ^ swz(r32)) << 4);
+        for (int ks = 0; ks < KS2; ks++) sl[ks] = ((4 * ks + g4) ^ swz(r16)) << 4;
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) b_off[ni] = (BN + (wn * NI + ni) * 32 + r32) * ROWB;
+        for (int ni = 0; ni < NB; ni++) b_off[ni] = (BN + (wn * NB + ni) * 16 + r16) * ROWB;
     };
     geometry();
     const int nk = (a.K + BK - 1) / BK, nk_full = a.K / BK;
@@ -233,13 +242,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
         //      The per-column vectors travel through wave-private LDS (the wave's epilogue staging area, untouched until the K
         //      loop's first barrier): two loads per lane instead of forty, and the wait for them is the wait for the tile's first DMA.
         GVD_STAMP(0);
-        f16v acc[MI][NI];
-        float rscale[NI];
+        f4v acc[MB][NB];
+        float rscale[NB];
         {
             // (the wave's OWN epilogue staging area: free once its previous epilogue is done -- other waves may still be inside
             //  theirs, so no other part of stage 1 may be touched here)
             float* const vec = reinterpret_cast<float*>(lds + STAGE + wave * (32 * EP_PITCH));
-            float rinv[NI], rmean[NI];
+            float rinv[NB], rmean[NB];
             const bool vecs = a.bias != nullptr || a.row_stats != nullptr;      // (uniform)
             if (vecs) {
                 const int c = cn0 + wm * MI * 32 + lane * 4;
@@ -247,10 +256,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = bv;
                 if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cs);
                 if (a.row_stats) sv = *reinterpret_cast<const float4*>(a.col_sum + cs);
-                float2 st[NI];
+                float2 st[NB];
 #pragma unroll
-                for (int ni = 0; ni < NI; ni++) {
-                    const int m = cm0 + (wn * NI + ni) * 32 + r32;
+                for (int ni = 0; ni < NB; ni++) {
+                    const int m = cm0 + (wn * NB + ni) * 16 + r16;
                     st[ni] = a.row_stats ? (a.row_stats + (size_t)cb * a.M)[m < a.M ? m : a.M - 1] : make_float2(0.f, a.alpha);
                 }
                 if (lane < MI * 8) {
@@ -259,26 +268,23 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
                     *reinterpret_cast<float4*>(vec + MI * 32 + lane * 4) = sv;
                 }
 #pragma unroll
-                for (int ni = 0; ni < NI; ni++) { rscale[ni] = st[ni].y; rinv[ni] = __builtin_amdgcn_rcpf(st[ni].y); rmean[ni] = st[ni].x; }
+                for (int ni = 0; ni < NB; ni++) { rscale[ni] = st[ni].y; rinv[ni] = __builtin_amdgcn_rcpf(st[ni].y); rmean[ni] = st[ni].x; }
             } else {
 #pragma unroll
-                for (int ni = 0; ni < NI; ni++) { rscale[ni] = a.alpha; rinv[ni] = 0.f; rmean[ni] = 0.f; }
+                for (int ni = 0; ni < NB; ni++) { rscale[ni] = a.alpha; rinv[ni] = 0.f; rmean[ni] = 0.f; }
             }
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = bv;
-                    if (vecs) {
-                        bv = *reinterpret_cast<const float4*>(vec + mi * 32 + 8 * rg + 4 * hi);
-                        sv = *reinterpret_cast<const float4*>(vec + MI * 32 + mi * 32 + 8 * rg + 4 * hi);
-                    }
-                    const float bq[4] = { bv.x, bv.y, bv.z, bv.w }, sq[4] = { sv.x, sv.y, sv.z, sv.w };
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) acc[mi][ni][4 * rg + e] = fmaf(bq[e], rinv[ni], -rmean[ni] * sq[e]);
+            for (int mi = 0; mi < MB; mi++) {
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = bv;
+                if (vecs) {
+                    bv = *reinterpret_cast<const float4*>(vec + mi * 16 + 4 * g4);
+                    sv = *reinterpret_cast<const float4*>(vec + MI * 32 + mi * 16 + 4 * g4);
                 }
+                const float bq[4] = { bv.x, bv.y, bv.z, bv.w }, sq[4] = { sv.x, sv.y, sv.z, sv.w };
+#pragma unroll
+                for (int ni = 0; ni < NB; ni++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[mi][ni][e] = fmaf(bq[e], rinv[ni], -rmean[ni] * sq[e]);
             }
         }
 
@@ -297,25 +303,51 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
             else if (kt + 1 < nk) issue_tail(kt + 1, (kt + 1) & 1);
 #endif
             const unsigned char* st = lds + (kt & 1) * STAGE;
-#pragma unroll(KUNROLL)
-            for (int ks = 0; ks < KS; ks++) {
-                vec8 af[MI], bf[NI];
+            // Operand fragments are read AHEAD of the MFMAs that use them (GVD_GEMM_RDAHEAD steps of 4 MFMAs each; the compiler's own
+            // order is read, wait for it, multiply: the full LDS latency in front of every group of 8 MFMAs).  Liveness, not the
+            // array shapes, sets the register cost: B fragments of one k-step + RDAHEAD + 1 A fragments.
+            vec8 af[KS2][MB], bf[KS2][NB];
+            auto rd_a = [&](int ks, int mi) { af[ks][mi] = *reinterpret_cast<const vec8*>(st + a_base + sl[ks] + mi * 16 * ROWB); };
+            auto rd_b = [&](int ks, int ni) { bf[ks][ni] = *reinterpret_cast<const vec8*>(st + b_off[ni] + sl[ks]); };
 #pragma unroll
-                for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const vec8*>(st + a_off[ks] + mi * 32 * ROWB);
+            for (int ni = 0; ni < NB; ni++) rd_b(0, ni);
 #pragma unroll
-                for (int ni = 0; ni < NI; ni++)
-                    bf[ni] = *reinterpret_cast<const vec8*>(st + b_off[ni] + (((2 * ks + hi) ^ swz(r32)) << 4));
+            for (int d = 0; d < GVD_GEMM_RDAHEAD; d++) rd_a(0, d);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+#pragma unroll
+                for (int mi = 0; mi < MB; mi++) {
+                    if (mi + GVD_GEMM_RDAHEAD < MB) rd_a(ks, mi + GVD_GEMM_RDAHEAD);
+                    else if (ks + 1 < KS2) {
+                        const int d = mi + GVD_GEMM_RDAHEAD - MB;      // 0 .. RDAHEAD - 1: the next k-step's B fragments ride with its first A fragments
+                        if (d == 0) { rd_b(ks + 1, 0); rd_b(ks + 1, 1); }
+                        if (d == GVD_GEMM_RDAHEAD - 1) { rd_b(ks + 1, 2); rd_b(ks + 1, 3); }
+                        rd_a(ks + 1, d);
+                    }
 #if GVD_GEMM_DBG & 2
 #pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++) acc[mi][ni][0] += (float)af[mi][0] * (float)bf[ni][0];
+                    for (int ni = 0; ni < NB; ni++) acc[mi][ni][0] += (float)af[ks][mi][0] * (float)bf[ks][ni][0];
 #else
 #pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
+                    for (int ni = 0; ni < NB; ni++) acc[mi][ni] = Tr<T>::mfma16(af[ks][mi], bf[ks][ni], acc[mi][ni]);
 #endif
+                }
+            }
+            // the same order for the machine scheduler (which otherwise sinks every read to just in front of its first use)
+            static_assert(NB == 4 && GVD_GEMM_RDAHEAD >= 2 && GVD_GEMM_RDAHEAD <= 4, "group sizes below are literals");
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + GVD_GEMM_RDAHEAD, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+#pragma unroll
+                for (int mi = 0; mi < MB; mi++) {
+                    if (mi + GVD_GEMM_RDAHEAD < MB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else if (ks + 1 < KS2) {
+                        const int d = mi + GVD_GEMM_RDAHEAD - MB;
+                        if (d == 0 || d == GVD_GEMM_RDAHEAD - 1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
             }
         }
         GVD_STAMP(4);
@@ -332,11 +364,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
             issue_first();
         }
 
-        // ---- epilogue.  A lane holds, per 32x32 block (mi, ni), 4 x 4 consecutive channels (8 rg + 4 hi + e) of ONE token:
+        // ---- epilogue.  A lane holds, per 16 x 16 block (mi, ni), the 4 consecutive channels 16 mi + 4 g4 + e of ONE token (16 ni + r16):
         //      scale, LayerNorm fold, bias (and the GEGLU gate) in fp32 registers, 16-bit rounding, then a WAVE-PRIVATE transposition
-        //      through LDS (no barriers) so that the global stores are row-contiguous: 20 (16) consecutive lanes cover the wave's
-        //      320 (256) bytes of one token row.  (Row-per-lane stores straight from the registers -- 32-byte pieces of 32 rows per
-        //      instruction -- ran at a fraction of the write bandwidth: the store path handles a row segment per cycle.) ----
+        //      through LDS (8-byte writes of a lane's four channels, no barriers) so that the global stores are row-contiguous: 20 (16)
+        //      consecutive lanes cover the wave's 320 (256) bytes of one token row.  (Row-per-lane stores straight from the registers
+        //      ran at a fraction of the write bandwidth: the store path handles a row segment per cycle.) ----
 #if GVD_GEMM_DBG & 4
         if (!more) break;
         continue;
@@ -349,35 +381,30 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
         constexpr int NIT = NOCT * 32 / 64;                                  // read-back sweeps of a 32-token block
         const int wcol = GEGLU ? (tn0 >> 1) + wm * MI * 16 : tn0 + wm * MI * 32, ncols = GEGLU ? (a.N >> 1) : a.N;
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) {
-            const int mrow = tm0 + (wn * NI + ni) * 32;
+        for (int hp = 0; hp < NB / 2; hp++) {                               // 32 tokens (two 16-token blocks) per staging pass
+            const int mrow = tm0 + (wn * NB + 2 * hp) * 16;
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-                f16v v = acc[mi][ni];
-                if (scaled) {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) v[q] *= rscale[ni];
-                }
+            for (int h = 0; h < 2; h++) {
+                const int ni = 2 * hp + h;
+                unsigned char* const row = ep + (h * 16 + r16) * EP_PITCH + g4 * 8;   // this lane's token row, its 4-channel column
                 if (GEGLU) {
-                    // tile columns 0-15 of the block are values, 16-31 their gates (same rg & 1, hi, e): this lane owns the 8
-                    // consecutive outputs 8 hi + 4 rg + e (rg = 0, 1) of the block's 16 -- one 16-byte chunk, no exchange
-                    float o[8];
+                    // W rows come as [16 values | 16 gates] of 16 consecutive outputs: value block 2 j, gate block 2 j + 1 -- this lane
+                    // holds value and gate of the 4 outputs 16 j + 4 g4 + e
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        o[q] = v[q] * gelu_erf(v[8 + q]);   // fp32 through the gate: one rounding, at the store (the unfused pair rounds the projection and the gate first)
+                    for (int j = 0; j < MI; j++) {
+                        f4v v = acc[2 * j][ni], gt = acc[2 * j + 1][ni];
+                        if (scaled) { v *= rscale[ni]; gt *= rscale[ni]; }
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = v[e] * gelu_erf(gt[e]);   // fp32 through the gate: one rounding, at the store
+                        *reinterpret_cast<uint2*>(row + j * 32) = pack4<T>(o[0], o[1], o[2], o[3]);
                     }
-                    const uint4 w = make_uint4(Tr<T>::pack2(o[0], o[1]), Tr<T>::pack2(o[2], o[3]), Tr<T>::pack2(o[4], o[5]), Tr<T>::pack2(o[6], o[7]));
-                    *reinterpret_cast<uint4*>(ep + r32 * EP_PITCH + (mi * 2 + hi) * 16) = w;
                 } else {
-                    // the two wave halves hold channels 8 rg + [0, 4) and 8 rg + [4, 8): one v_permlane32_swap per dword gives
-                    // lanes 0-31 the whole octet of rg = 0 / 2 and lanes 32-63 the octet of rg = 1 / 3
 #pragma unroll
-                    for (int pr = 0; pr < 2; pr++) {
-                        const uint2 p0 = pack4<T>(v[8 * pr], v[8 * pr + 1], v[8 * pr + 2], v[8 * pr + 3]);
-                        const uint2 p1 = pack4<T>(v[8 * pr + 4], v[8 * pr + 5], v[8 * pr + 6], v[8 * pr + 7]);
-                        const auto sl = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
-                        const auto sh = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
-                        *reinterpret_cast<uint4*>(ep + r32 * EP_PITCH + (mi * 4 + 2 * pr + hi) * 16) = make_uint4(sl[0], sh[0], sl[1], sh[1]);
+                    for (int mi = 0; mi < MB; mi++) {
+                        f4v v = acc[mi][ni];
+                        if (scaled) v *= rscale[ni];
+                        *reinterpret_cast<uint2*>(row + mi * 32) = pack4<T>(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -688,6 +715,8 @@ static int tile_n(long long M, int N, int batch)
 }
 
 int gvd_gemm_tile_n(int M, int N, int batch) { return tile_n(M, N, batch); }
+
+int gvd_gemm_geglu_layout(void) { return 1; }   // 1: [16 values | 16 gates] in natural order (16 x 16 x 32 MFMA blocks); see gvd_diffusion.h
 
 int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
                 void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,

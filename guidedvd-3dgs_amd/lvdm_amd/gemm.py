@@ -102,12 +102,17 @@ def _tag(t):
 
 def _geglu_perm(n2, device):
     """Row order of the GEGLU projection for the kernel's register epilogue (include/gvd_diffusion.h): per block of 32 tile rows,
-    rows 0-15 are the VALUES and rows 16-31 the GATES of 16 consecutive outputs; within each half, row c = 8 rg + 4 hi + e holds
-    output u = 8 hi + 4 rg + e -- so that a lane of the MFMA accumulator layout owns value and gate of 8 consecutive outputs.
-    (value rows 0 .. n-1, gate rows n .. 2n-1 of the projection.)"""
+    rows 0-15 are the VALUES and rows 16-31 the GATES of 16 consecutive outputs, each half in natural order -- a lane of the
+    16 x 16 x 32 MFMA accumulator layout then owns value and gate of 4 consecutive outputs.  (value rows 0 .. n-1, gate rows
+    n .. 2n-1 of the projection.)  A library of rounds 3-5 (A/B runs through GVD_DIFFUSION_LIB) has no gvd_gemm_geglu_layout and
+    wants the 32 x 32 x 16 order: within each half, row c = 8 rg + 4 hi + e holds output 8 hi + 4 rg + e."""
     n = n2 // 2
     c = torch.arange(16, device=device)
-    u = 8 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3)                       # output index within the block for half-row c
+    L = ops.lib()
+    if hasattr(L, "gvd_gemm_geglu_layout") and L.gvd_gemm_geglu_layout() == 1:
+        u = c
+    else:
+        u = 8 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3)                   # output index within the block for half-row c
     blocks = torch.arange(n // 16, device=device)[:, None] * 16 + u[None, :]   # [n / 16, 16] value rows
     return torch.cat([blocks, blocks + n], dim=1).reshape(-1)
 

@@ -257,10 +257,11 @@ int gvd_profile_marker(int tag, void* stream);
  *   LayerNorm fold   row_stats [batch][M] (mean, rstd) pairs (gvd_row_stats) and col_sum [N]:  v = rstd[m] * (v - mean[m] * col_sum[n])
  *                    -- with W pre-multiplied by the norm's weight this IS  LayerNorm(x) W^T  (attention.py:283-285 + the Linear);
  *   bias [N]         v += bias[n]   (for the fold: sum_k beta[k] W[n][k] + the Linear's bias);
- *   geglu            W rows come in blocks of 32 = [16 value rows | 16 gate rows] of 16 consecutive outputs, and within each half
- *                    row c = 8 rg + 4 hi + e holds output 8 hi + 4 rg + e (the MFMA accumulator's lane map: a lane then owns the
- *                    value and the gate of 8 consecutive outputs): out[m][j] = value * gelu_erf(gate), Y has N / 2 columns
- *                    (attention.py:415-423), rounded like the unfused pair.  N % 32 == 0;
+ *   geglu            W rows come in blocks of 32 = [16 value rows | 16 gate rows] of 16 consecutive outputs, each half in natural
+ *                    order (a lane of the 16 x 16 x 32 MFMA accumulator layout then owns value and gate of 4 consecutive outputs):
+ *                    out[m][j] = value * gelu_erf(gate), Y has N / 2 columns (attention.py:415-423), rounded like the unfused pair.
+ *                    N % 32 == 0.  gvd_gemm_geglu_layout() names the row order the library expects (1 = this one; the 32 x 32 x 16
+ *                    kernels of rounds 3-5 used 0: row c = 8 rg + 4 hi + e of a half held output 8 hi + 4 rg + e);
  *   residual         Y += R[b][m][n] (row stride ldr, batch stride stride_r), the 16-bit sum of the rounded GEMM result and R. */
 int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
                 void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
@@ -270,6 +271,7 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
 /* Channel-tile width (320 / 256: 8-wave workgroups; 160 / 128: 4-wave workgroups for problems that would under-fill the chip)
  * gvd_gemm_nt uses for an M x N problem with `batch` batches. */
 int gvd_gemm_tile_n(int M, int N, int batch);
+int gvd_gemm_geglu_layout(void);
 
 /* (mean, rstd = 1 / sqrt(var + eps)) of every row of x [M, C] (row stride ldx; C % 8 == 0, C <= 4096) as float pairs:
  * the per-row half of the LayerNorm fold above (nn.LayerNorm's biased variance, attention.py:283-285). */
