@@ -54,9 +54,6 @@ struct GemmArgs {
     int geglu;                             // W rows in [16 value | 16 gate] blocks (gvd_diffusion.h); y has N / 2 columns
 };
 
-#ifndef GVD_GEMM_KUNROLL5
-#define GVD_GEMM_KUNROLL5 4   // (2 measured 1-3 % slower once the kernels stopped spilling)
-#endif
 #ifndef GVD_GEMM_RDAHEAD
 #define GVD_GEMM_RDAHEAD 2   // A fragments read ahead of their MFMAs (steps of 4 MFMAs)
 #endif
@@ -64,9 +61,6 @@ struct GemmArgs {
 #define GVD_GEMM_NT_STORE 1   // the output rows leave as non-temporal stores (0: plain, for A/B builds): a 150-590 MB output of the level-0 shapes only
                               // passes through the caches on its way out -- 230 400 x 960 x 320 0.259 -> 0.234 ms, x 2560 0.588 -> 0.551, DDIM step
                               // 238.2 -> 234.7 ms (profiles/r04_nt_stores.txt); neutral on the small shapes
-#endif
-#ifndef GVD_GEMM_DBG
-#define GVD_GEMM_DBG 0   // experiments only (tests/scripts/build_gemm_variants.sh): 1 = no DMA in the K loop, 2 = no MFMAs, 4 = no epilogue, 8 = one K-tile only, 16 = no global stores
 #endif
 constexpr int BM = 256, WN = 4;   // tokens per tile: 4 wave columns x 4 blocks of 16
 __device__ const uint4 g_zero16 = { 0u, 0u, 0u, 0u };   // source of K-tail slots
@@ -100,35 +94,50 @@ __device__ __forceinline__ float gelu_erf(float g)
 template <typename T>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(Tr<T>::pack2(a, b), Tr<T>::pack2(c, d)); }
 
-// WM: wave rows (channel halves) -- 2: 8 waves, one workgroup per CU; 1: 4 waves, two workgroups per CU (one's epilogue
-// stores drain under the other's K loop).  BK: K-step (64 / 32 channels = 128 / 64-byte LDS rows).
+// WM: wave rows (channel halves) -- 2: 8 waves, one workgroup per CU, a RING of four 32-channel K slots (below); 1: 4 waves, two
+// workgroups per CU (one's epilogue stores drain under the other's K loop), two K stages of 32 channels.
+//
+// The 8-wave K loop (RING).  A trace of the two-stage form (profiles/r06_gemm_wave_timeline_ktile.txt) showed what a K-tile costs beyond
+// its MFMAs: the two waves of a SIMD run their MFMA streams one after the other (the older wave wins the pipe), the older one then waits at
+// the K-tile's barrier, and after the barrier BOTH wait for their first operand fragments -- ~500 of 2750 cycles per 64-channel K-tile with
+// no MFMA in flight on the SIMD.  Here K is cut in 32-channel half-tiles h = 0, 1, ... living in slot h & 3 of a ring of four; during half-tile
+// h the workgroup's DMA for h + 3 goes out (into the slot of h - 1, free since the barrier that ended h - 1), every wave waits at the END of h
+// for its own pieces of h + 2 (one full half-tile after their issue: `s_waitcnt vmcnt(pieces of h + 3)`), and the barrier that follows makes
+// h + 2 visible to everyone -- so the fragments that OPEN half-tile h + 1 can be read during h, ahead of the barrier, and the MFMA stream of a
+// wave continues across it without a gap.  The DMA instructions are hand-written (hipcc counts a builtin LDS-DMA as a pending LDS write and
+// drains it -- vmcnt(0) -- in front of the next LDS read it cannot tell apart) and issued between the MFMA steps; the three half-tiles that
+// open the NEXT tile go out before this tile's epilogue, whose staging lives in slot 3 and the space behind it.
 template <typename T, int MI, int WM, int BK, bool GEGLU>
 __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 {
     typedef typename Tr<T>::vec8 vec8;
     typedef T T2 __attribute__((ext_vector_type(2)));
-    constexpr int NT = WM * WN * 64, ROWB = BK * 2, SPR = ROWB / 16, KS2 = BK / 32;
+    constexpr bool RING = WM == 2;
+    static_assert(BK == 32, "32-channel K slots: 64-byte LDS rows");
+    constexpr int NT = WM * WN * 64, ROWB = BK * 2, SPR = ROWB / 16;
     constexpr int MB = MI * 2, NB = 4;              // 16-row blocks of a wave: MB along the channels (A operand), NB along the tokens (B operand)
     constexpr int BN = WM * MI * 32;
     constexpr int STAGE = (BN + BM) * ROWB;
     constexpr int NQ = STAGE / 16;                  // 16-byte DMA pieces per stage
-    constexpr int NP = (NQ + NT - 1) / NT;          // ... per thread
+    constexpr int NP = (NQ + NT - 1) / NT;          // ... per thread (the last sweep may be partial)
     constexpr int EP_PITCH = MI * 64 + 16;          // epilogue staging: one token row of a wave (MI * 32 channels, 16 bit) + pad
+    constexpr int EP_WAVE = 16 * EP_PITCH;          // ... 16 tokens per pass
+    constexpr int EP_BASE = RING ? 3 * STAGE : STAGE;                                  // staging: behind the slots that receive the next tile
+    constexpr int VEC_BASE = RING ? EP_BASE + WM * WN * EP_WAVE : EP_BASE;             // per-column vectors of the accumulator initialisation
     static_assert(NQ % 64 == 0 && (BN * SPR) % 64 == 0, "a wave's DMA instruction is one kind of row");
     // XOR of a row's 16-byte slots that makes the ds_read_b128 operand reads conflict free.  A 16 x 16 x 32 operand read has lane
-    // (r16 = lane & 15, g4 = lane >> 4) fetch slot 4 ks + g4 of row r16 of its block; the LDS serves the 16-lane groups {0-3, 12-15,
-    // 20-27}, {4-11, 16-19, 28-31} (+ 32), i.e. rows {0-3, 12-15 | 4-11} at slots {g | g + 1}.  128-byte rows (two rows per 64-bank
-    // line): slot ^ ((row >> 1) & 7) gives each group 8 distinct slots x 2 row parities.  64-byte rows (four rows per line): slot ^
-    // perm[(row >> 2) & 3] with perm = (0, 2, 3, 1) gives 4 distinct slots x 4 rows-mod-4 in every group (the plain (row >> 2) & 3
-    // of the 32 x 32 x 16 reads would put rows 0-3 and 4-7 of a group on the same slot).  Both depend on row mod 16 only.
-    auto swz = [](int row) { return SPR == 8 ? ((row >> 1) & 7) : ((0x78 >> (((row >> 2) & 3) * 2)) & 3); };
+    // (r16 = lane & 15, g4 = lane >> 4) fetch slot g4 of row r16 of its block; the LDS serves the 16-lane groups {0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31} (+ 32), i.e. rows {0-3, 12-15 | 4-11} at slots {g | g + 1}.  With 64-byte rows (four rows per 64-bank line)
+    // slot ^ perm[(row >> 2) & 3], perm = (0, 2, 3, 1), gives 4 distinct slots x 4 rows-mod-4 in every group (the plain (row >> 2) & 3
+    // of the 32 x 32 x 16 reads of rounds 3-5 would put rows 0-3 and 4-7 of a group on the same slot).  Depends on row mod 16 only.
+    auto swz = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // Per-lane geometry.  Re-derived from the thread id at the top of every tile (behind an opaque asm): kept live across the
-    // whole persistent loop these ~25 values were spilled to scratch by the 5-block kernels (160 accumulators + fragments at the
+    // whole persistent loop these values were spilled to scratch by the 5-block kernels (160 accumulators + fragments at the
     // 256-register cap) and reloaded with exposed latency (~10k cycles per tile); recomputing them is ~30 VALU instructions.
     int lane, wave, g4, r16, wm, wn, lrow, lslot;
-    int a_base, sl[KS2], b_off[NB];   // MFMA operand addresses within a stage (16-row block offsets do not change swz(row))
+    int a_off, b_off[NB];             // MFMA operand addresses within a slot (16-row block offsets do not change swz(row))
     auto geometry = [&]() {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
@@ -138,11 +147,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
         wm = wave / WN; wn = wave % WN;
         lrow = lane / SPR;
         lslot = (lane % SPR) ^ swz(lane / SPR + wave * (64 / SPR));
-        a_base = (wm * MI * 32 + r16) * ROWB;
+        const int sl = (g4 ^ swz(r16)) << 4;
+        a_off = (wm * MI * 32 + r16) * ROWB + sl;
 #pragma unroll
-        for (int ks = 0; ks < KS2; ks++) sl[ks] = ((4 * ks + g4) ^ swz(r16)) << 4;
-#pragma unroll
-        for (int ni = 0; ni < NB; ni++) b_off[ni] = (BN + (wn * NB + ni) * 16 + r16) * ROWB;
+        for (int ni = 0; ni < NB; ni++) b_off[ni] = (BN + (wn * NB + ni) * 16 + r16) * ROWB + sl;
     };
     geometry();
     const int nk = (a.K + BK - 1) / BK, nk_full = a.K / BK;
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
     };
 
     // ---- DMA source map: piece q = p * NT + tid of a stage fills LDS bytes [16 q, 16 q + 16): row q / SPR, physical slot q % SPR,
-    //      which holds the row's LOGICAL slot (q % SPR) ^ swz(row) -- the permutation stays inside the row's own 64 / 128-byte
+    //      which holds the row's LOGICAL slot (q % SPR) ^ swz(row) -- the permutation stays inside the row's own 64-byte
     //      line, so the global reads stay coalesced ----
     // A wave's DMA instruction of sweep p covers 64 / SPR consecutive rows: row = R0(p, wave) + lane / SPR, physical slot
     // lane % SPR; the row's swizzle depends on (wave, lane) only (R0's contribution to the swizzled bits is 0), so the per-lane
@@ -190,8 +198,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
         wlim = a.N - 1 - n0;
         xlim = a.M - 1 - m0;
     };
-    auto piece_src = [&](int p, int kt) {
-        const int q0 = p * NT + wave * 64;                   // (wave-uniform) first piece of this instruction
+    // -- the 4-wave form: builtin LDS-DMA, a K-tile's pieces as one block in front of its MFMAs --
+    auto piece_src = [&](int p, int kt, int lrow) {          // (lrow: the caller's opaque copy -- keeps these ~10 instructions per piece inside the
+        const int q0 = p * NT + wave * 64;                   //  K loop instead of NP hoisted 64-bit addresses in registers the loop does not have)
         const bool isw = q0 < WQ;
         int r = q0 / SPR - (isw ? 0 : BN) + lrow;
         const int lim = isw ? wlim : xlim;
@@ -201,25 +210,68 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
     };
     auto issue = [&](int kt, int stage) {                    // a full K-tile
         unsigned char* dst = lds + stage * STAGE + wave * 1024;
+        int lr = lrow;
+        asm volatile("" : "+v"(lr));
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             if ((p + 1) * NT > NQ && p * NT + wave * 64 >= NQ) continue;     // (last, partial sweep: wave-uniform)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)piece_src(p, kt),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)piece_src(p, kt, lr),
                                              (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
         }
     };
     auto issue_tail = [&](int kt, int stage) {               // the last, partial K-tile: slots past K read zeros
         unsigned char* dst = lds + stage * STAGE + wave * 1024;
+        int lr = lrow;
+        asm volatile("" : "+v"(lr));
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             if ((p + 1) * NT > NQ && p * NT + wave * 64 >= NQ) continue;
-            const char* g = piece_src(p, kt);
+            const char* g = piece_src(p, kt, lr);
             if (kt * BK + lslot * 8 >= a.K) g = reinterpret_cast<const char*>(&g_zero16);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
         }
     };
-    auto issue_first = [&]() { if (nk_full > 0) issue(0, 0); else issue_tail(0, 0); };
+    // -- the ring form: one piece of half-tile `h` as a hand-written instruction group: the base (tile origin + K position) is scalar, the
+    //    lane adds (clamped row) x (row stride) + its slot -- three vector instructions.  `on` (wave-uniform; 0 = off) switches the piece off
+    //    without a branch (EXEC = 0), so that ONE copy of the MFMA stream serves every half-tile (two copies joined by a branch cost the
+    //    accumulators their fixed registers: 200-380 spilled VGPRs).  hipcc does not count these loads: the waits below do.  In the last,
+    //    partial sweep (5-block tiles: 4.5 pieces per wave) waves 4-7 repeat the piece of waves 0-3 -- the same bytes to the same place --
+    //    so that every wave has the same number of loads in flight for the counted waits. --
+    auto ring_piece = [&](int p, int h, unsigned on) {
+        int q0 = p * NT + wave * 64;
+        if ((p + 1) * NT > NQ && q0 >= NQ) q0 -= NT / 2;
+        const bool isw = q0 < WQ;
+        const int R0 = q0 / SPR - (isw ? 0 : BN), lim = isw ? wlim : xlim;
+        int r = R0 + lrow;
+        r = r < lim ? r : lim;
+        const unsigned voff = (unsigned)r * ((unsigned)(isw ? a.ldw : a.ldx) * 2u) + (unsigned)lslot * 16u;
+        const char* sb = (isw ? wbase : xbase) + (size_t)h * ROWB;
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds + (h & 3) * STAGE + q0 * 16);
+        unsigned keep_m0;
+        unsigned long long keep_exec;
+        // (five scalar instructions between any producer of the operands and the load: covers the M0 and VALU-written-SGPR wait states)
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "s_mov_b64 %1, exec\n\t"
+                     "s_cmp_lg_u32 %4, 0\n\t"
+                     "s_cselect_b64 exec, exec, 0\n\t"
+                     "global_load_lds_dwordx4 %2, %5\n\t"
+                     "s_mov_b64 exec, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(voff), "s"(dst), "s"(on), "s"(sb) : "memory", "scc");
+    };
+    auto pos = [](int d) { return (unsigned)(d & ~(d >> 31)); };   // d > 0 ? d : 0 in integer form (a compare would reach the asm operand as a vector register)
+    auto ring_open = [&]() {                                  // the three half-tiles that open a tile
+#pragma unroll
+        for (int h = 0; h < 3; h++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) ring_piece(p, h, pos(nk - h));
+    };
+    auto issue_first = [&]() {
+        if constexpr (RING) ring_open();
+        else { if (nk_full > 0) issue(0, 0); else issue_tail(0, 0); }
+    };
 
     int slot = next_valid(blockIdx.x);
     if (slot >= total) return;
@@ -238,16 +290,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
         //      16-bit pack and the stores: with  y = scale_m (sum_k x w' + init),
         //        LayerNorm fold:  scale_m = rstd_m,  init = c_n / rstd_m - mean_m s_n     (== rstd (acc - mean s) + c)
         //        otherwise:       scale   = alpha,   init = bias_n / alpha
-        //      The vector loads behind this sit in the shadow of the tile's first DMA wait. ----
-        //      The per-column vectors travel through wave-private LDS (the wave's epilogue staging area, untouched until the K
-        //      loop's first barrier): two loads per lane instead of forty, and the wait for them is the wait for the tile's first DMA.
+        //      The per-column vectors travel through wave-private LDS: two loads per lane instead of forty. ----
         GVD_STAMP(0);
         f4v acc[MB][NB];
         float rscale[NB];
         {
-            // (the wave's OWN epilogue staging area: free once its previous epilogue is done -- other waves may still be inside
-            //  theirs, so no other part of stage 1 may be touched here)
-            float* const vec = reinterpret_cast<float*>(lds + STAGE + wave * (32 * EP_PITCH));
+            // (4-wave form: the wave's OWN epilogue staging area, free once its previous epilogue is done -- other waves may still be inside
+            //  theirs, so no other part of stage 1 may be touched here; ring form: its own area behind the staging)
+            float* const vec = reinterpret_cast<float*>(lds + VEC_BASE + wave * (RING ? MI * 64 * 4 : EP_WAVE));
             float rinv[NB], rmean[NB];
             const bool vecs = a.bias != nullptr || a.row_stats != nullptr;      // (uniform)
             if (vecs) {
@@ -287,74 +337,119 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
                     for (int e = 0; e < 4; e++) acc[mi][ni][e] = fmaf(bq[e], rinv[ni], -rmean[ni] * sq[e]);
             }
         }
-
         GVD_STAMP(1);
-#if GVD_GEMM_DBG & 8
-        for (int kt = 0; kt < 1; kt++) {
-#else
-        for (int kt = 0; kt < nk; kt++) {
-#endif
+
+        static_assert(NB == 4 && GVD_GEMM_RDAHEAD >= 2 && GVD_GEMM_RDAHEAD <= 4, "the scheduling groups below are literals");
+        if constexpr (RING) {
+            // ---- half-tiles 0, 1 of this tile landed (issued before the previous epilogue; the wait also drains that epilogue's stores) ----
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                 // tile kt landed for everyone; stage (kt + 1) & 1 is free
-            if (kt == 0) GVD_STAMP(2);
-            if (kt == 1) GVD_STAMP(3);
-#if !(GVD_GEMM_DBG & 1)
-            if (kt + 1 < nk_full) issue(kt + 1, (kt + 1) & 1);
-            else if (kt + 1 < nk) issue_tail(kt + 1, (kt + 1) & 1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#if !(defined(GVD_GEMM_TRACE) && GVD_GEMM_TRACE == 2)
+            GVD_STAMP(2);
 #endif
-            const unsigned char* st = lds + (kt & 1) * STAGE;
-            // Operand fragments are read AHEAD of the MFMAs that use them (GVD_GEMM_RDAHEAD steps of 4 MFMAs each; the compiler's own
-            // order is read, wait for it, multiply: the full LDS latency in front of every group of 8 MFMAs).  Liveness, not the
-            // array shapes, sets the register cost: B fragments of one k-step + RDAHEAD + 1 A fragments.
-            vec8 af[KS2][MB], bf[KS2][NB];
-            auto rd_a = [&](int ks, int mi) { af[ks][mi] = *reinterpret_cast<const vec8*>(st + a_base + sl[ks] + mi * 16 * ROWB); };
-            auto rd_b = [&](int ks, int ni) { bf[ks][ni] = *reinterpret_cast<const vec8*>(st + b_off[ni] + sl[ks]); };
+            // fragments that open half-tile 0
+            vec8 bfc[NB], afc[GVD_GEMM_RDAHEAD];
 #pragma unroll
-            for (int ni = 0; ni < NB; ni++) rd_b(0, ni);
+            for (int ni = 0; ni < NB; ni++) bfc[ni] = *reinterpret_cast<const vec8*>(lds + b_off[ni]);
 #pragma unroll
-            for (int d = 0; d < GVD_GEMM_RDAHEAD; d++) rd_a(0, d);
+            for (int d = 0; d < GVD_GEMM_RDAHEAD; d++) afc[d] = *reinterpret_cast<const vec8*>(lds + a_off + d * 16 * ROWB);
+            // two half-tiles per trip (K % 64 == 0: the launcher's condition for this form): the fragments read across a barrier change
+            // hands between two register sets instead of being copied at the top of every half-tile
+            vec8 bfd[NB], afd[GVD_GEMM_RDAHEAD];
+            auto half_tile = [&](int h, vec8 (&bin)[NB], vec8 (&ain)[GVD_GEMM_RDAHEAD], vec8 (&bout)[NB], vec8 (&aout)[GVD_GEMM_RDAHEAD]) {
+                const unsigned char* cur = lds + (h & 3) * STAGE;
+                const unsigned char* nxt = lds + ((h + 1) & 3) * STAGE;
+                const unsigned dma_on = pos(nk - 3 - h);                     // half-tile h + 3 exists
+                vec8 af[MB];
 #pragma unroll
-            for (int ks = 0; ks < KS2; ks++) {
+                for (int d = 0; d < GVD_GEMM_RDAHEAD; d++) af[d] = ain[d];
 #pragma unroll
                 for (int mi = 0; mi < MB; mi++) {
-                    if (mi + GVD_GEMM_RDAHEAD < MB) rd_a(ks, mi + GVD_GEMM_RDAHEAD);
-                    else if (ks + 1 < KS2) {
-                        const int d = mi + GVD_GEMM_RDAHEAD - MB;      // 0 .. RDAHEAD - 1: the next k-step's B fragments ride with its first A fragments
-                        if (d == 0) { rd_b(ks + 1, 0); rd_b(ks + 1, 1); }
-                        if (d == GVD_GEMM_RDAHEAD - 1) { rd_b(ks + 1, 2); rd_b(ks + 1, 3); }
-                        rd_a(ks + 1, d);
+                    // operand fragments are read GVD_GEMM_RDAHEAD steps (of 4 MFMAs) ahead of their use; the last steps read what opens h + 1
+                    if (mi + GVD_GEMM_RDAHEAD < MB) af[mi + GVD_GEMM_RDAHEAD] = *reinterpret_cast<const vec8*>(cur + a_off + (mi + GVD_GEMM_RDAHEAD) * 16 * ROWB);
+                    else {
+                        const int d = mi + GVD_GEMM_RDAHEAD - MB;      // 0 .. RDAHEAD - 1
+                        if (d == 0) { bout[0] = *reinterpret_cast<const vec8*>(nxt + b_off[0]); bout[1] = *reinterpret_cast<const vec8*>(nxt + b_off[1]); }
+                        if (d == GVD_GEMM_RDAHEAD - 1) { bout[2] = *reinterpret_cast<const vec8*>(nxt + b_off[2]); bout[3] = *reinterpret_cast<const vec8*>(nxt + b_off[3]); }
+                        aout[d] = *reinterpret_cast<const vec8*>(nxt + a_off + d * 16 * ROWB);
                     }
-#if GVD_GEMM_DBG & 2
+                    if ((mi & 1) && mi / 2 < NP) ring_piece(mi / 2, h + 3, dma_on);
 #pragma unroll
-                    for (int ni = 0; ni < NB; ni++) acc[mi][ni][0] += (float)af[ks][mi][0] * (float)bf[ks][ni][0];
-#else
-#pragma unroll
-                    for (int ni = 0; ni < NB; ni++) acc[mi][ni] = Tr<T>::mfma16(af[ks][mi], bf[ks][ni], acc[mi][ni]);
-#endif
+                    for (int ni = 0; ni < NB; ni++) acc[mi][ni] = Tr<T>::mfma16(af[mi], bin[ni], acc[mi][ni]);
                 }
-            }
-            // the same order for the machine scheduler (which otherwise sinks every read to just in front of its first use)
-            static_assert(NB == 4 && GVD_GEMM_RDAHEAD >= 2 && GVD_GEMM_RDAHEAD <= 4, "group sizes below are literals");
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + GVD_GEMM_RDAHEAD, 0);
-#pragma unroll
-            for (int ks = 0; ks < KS2; ks++) {
+                // the same order for the machine scheduler (which otherwise sinks every read to just in front of its first use)
 #pragma unroll
                 for (int mi = 0; mi < MB; mi++) {
                     if (mi + GVD_GEMM_RDAHEAD < MB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    else if (ks + 1 < KS2) {
+                    else {
                         const int d = mi + GVD_GEMM_RDAHEAD - MB;
                         if (d == 0 || d == GVD_GEMM_RDAHEAD - 1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                         else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
+#if defined(GVD_GEMM_TRACE) && GVD_GEMM_TRACE == 2   // half-tile 5: 2 before the DMA wait, 3 after it, 4 after the barrier; 5: the same point one half-tile later
+                if (h == 5) GVD_STAMP(2);
+#endif
+                // my pieces of h + 2 have landed when at most the NP pieces of h + 3 are still in flight
+                if (dma_on) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(GVD_GEMM_TRACE) && GVD_GEMM_TRACE == 2
+                if (h == 5) GVD_STAMP(3);
+#endif
+                // (my reads of slot h have been consumed by MFMAs above: complete; the reads that opened h + 1 may cross the barrier --
+                //  their slot is refilled only after the NEXT one)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#if defined(GVD_GEMM_TRACE) && GVD_GEMM_TRACE == 2
+                if (h == 5) GVD_STAMP(4);
+                if (h == 6) GVD_STAMP(5);
+#else
+                if (h == 0) GVD_STAMP(3);
+#endif
+            };
+            for (int h = 0; h < nk; h += 2) {
+                half_tile(h, bfc, afc, bfd, afd);
+                half_tile(h + 1, bfd, afd, bfc, afc);
             }
+#if !(defined(GVD_GEMM_TRACE) && GVD_GEMM_TRACE == 2)
+            GVD_STAMP(4);
+            GVD_STAMP(5);
+#endif
+        } else {
+            for (int kt = 0; kt < nk; kt++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                 // tile kt landed for everyone; stage (kt + 1) & 1 is free
+                if (kt == 0) GVD_STAMP(2);
+                if (kt == 1) GVD_STAMP(3);
+                if (kt + 1 < nk_full) issue(kt + 1, (kt + 1) & 1);
+                else if (kt + 1 < nk) issue_tail(kt + 1, (kt + 1) & 1);
+                const unsigned char* st = lds + (kt & 1) * STAGE;
+                vec8 af[MB], bf[NB];
+#pragma unroll
+                for (int ni = 0; ni < NB; ni++) bf[ni] = *reinterpret_cast<const vec8*>(st + b_off[ni]);
+#pragma unroll
+                for (int d = 0; d < GVD_GEMM_RDAHEAD; d++) af[d] = *reinterpret_cast<const vec8*>(st + a_off + d * 16 * ROWB);
+#pragma unroll
+                for (int mi = 0; mi < MB; mi++) {
+                    if (mi + GVD_GEMM_RDAHEAD < MB) af[mi + GVD_GEMM_RDAHEAD] = *reinterpret_cast<const vec8*>(st + a_off + (mi + GVD_GEMM_RDAHEAD) * 16 * ROWB);
+#pragma unroll
+                    for (int ni = 0; ni < NB; ni++) acc[mi][ni] = Tr<T>::mfma16(af[mi], bf[ni], acc[mi][ni]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + GVD_GEMM_RDAHEAD, 0);
+#pragma unroll
+                for (int mi = 0; mi < MB; mi++) {
+                    if (mi + GVD_GEMM_RDAHEAD < MB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+            GVD_STAMP(4);
+            __syncthreads();   // all operand reads retired: both stages are free
+            GVD_STAMP(5);
         }
-        GVD_STAMP(4);
-        __syncthreads();   // all operand reads retired: both stages are free
-        GVD_STAMP(5);
 
-        // ---- the next tile's first K-tile goes out now: its latency hides under this tile's epilogue ----
+        // ---- the next tile's opening K-tile(s) go out now: their latency hides under this tile's epilogue ----
         const int tb = cb, tm0 = cm0, tn0 = cn0;
         slot = next_valid(slot + gridDim.x);
         more = slot < total;
@@ -366,94 +461,76 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 
         // ---- epilogue.  A lane holds, per 16 x 16 block (mi, ni), the 4 consecutive channels 16 mi + 4 g4 + e of ONE token (16 ni + r16):
         //      scale, LayerNorm fold, bias (and the GEGLU gate) in fp32 registers, 16-bit rounding, then a WAVE-PRIVATE transposition
-        //      through LDS (8-byte writes of a lane's four channels, no barriers) so that the global stores are row-contiguous: 20 (16)
-        //      consecutive lanes cover the wave's 320 (256) bytes of one token row.  (Row-per-lane stores straight from the registers
-        //      ran at a fraction of the write bandwidth: the store path handles a row segment per cycle.) ----
-#if GVD_GEMM_DBG & 4
-        if (!more) break;
-        continue;
-#endif
+        //      through LDS (8-byte writes of a lane's four channels, 16 tokens per pass, no barriers) so that the global stores are
+        //      row-contiguous: 20 (16) consecutive lanes cover the wave's 320 (256) bytes of one token row.  (Row-per-lane stores straight
+        //      from the registers ran at a fraction of the write bandwidth: the store path handles a row segment per cycle.) ----
         GVD_STAMP(6);
         T* __restrict__ yb = (T*)a.y + (size_t)tb * a.sy;
         const T* __restrict__ rb = a.res ? (const T*)a.res + (size_t)tb * a.sr : nullptr;
-        unsigned char* const ep = lds + STAGE + wave * (32 * EP_PITCH);     // (stage 0 is receiving the next tile)
+        unsigned char* const ep = lds + EP_BASE + wave * EP_WAVE;
         constexpr int NOCT = GEGLU ? MI * 2 : MI * 4;                        // 16-byte chunks per token row of this wave
-        constexpr int NIT = NOCT * 32 / 64;                                  // read-back sweeps of a 32-token block
+        constexpr int NIT = (NOCT * 16 + 63) / 64;                           // read-back sweeps of a 16-token block (the last may be partial)
         const int wcol = GEGLU ? (tn0 >> 1) + wm * MI * 16 : tn0 + wm * MI * 32, ncols = GEGLU ? (a.N >> 1) : a.N;
 #pragma unroll
-        for (int hp = 0; hp < NB / 2; hp++) {                               // 32 tokens (two 16-token blocks) per staging pass
-            const int mrow = tm0 + (wn * NB + 2 * hp) * 16;
+        for (int ni = 0; ni < NB; ni++) {
+            const int mrow = tm0 + (wn * NB + ni) * 16;
+            unsigned char* const row = ep + r16 * EP_PITCH + g4 * 8;         // this lane's token row, its 4-channel column
+            if (GEGLU) {
+                // W rows come as [16 values | 16 gates] of 16 consecutive outputs: value block 2 j, gate block 2 j + 1 -- this lane
+                // holds value and gate of the 4 outputs 16 j + 4 g4 + e
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int ni = 2 * hp + h;
-                unsigned char* const row = ep + (h * 16 + r16) * EP_PITCH + g4 * 8;   // this lane's token row, its 4-channel column
-                if (GEGLU) {
-                    // W rows come as [16 values | 16 gates] of 16 consecutive outputs: value block 2 j, gate block 2 j + 1 -- this lane
-                    // holds value and gate of the 4 outputs 16 j + 4 g4 + e
+                for (int j = 0; j < MI; j++) {
+                    f4v v = acc[2 * j][ni], gt = acc[2 * j + 1][ni];
+                    if (scaled) { v *= rscale[ni]; gt *= rscale[ni]; }
+                    float o[4];
 #pragma unroll
-                    for (int j = 0; j < MI; j++) {
-                        f4v v = acc[2 * j][ni], gt = acc[2 * j + 1][ni];
-                        if (scaled) { v *= rscale[ni]; gt *= rscale[ni]; }
-                        float o[4];
+                    for (int e = 0; e < 4; e++) o[e] = v[e] * gelu_erf(gt[e]);   // fp32 through the gate: one rounding, at the store
+                    *reinterpret_cast<uint2*>(row + j * 32) = pack4<T>(o[0], o[1], o[2], o[3]);
+                }
+            } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) o[e] = v[e] * gelu_erf(gt[e]);   // fp32 through the gate: one rounding, at the store
-                        *reinterpret_cast<uint2*>(row + j * 32) = pack4<T>(o[0], o[1], o[2], o[3]);
-                    }
-                } else {
-#pragma unroll
-                    for (int mi = 0; mi < MB; mi++) {
-                        f4v v = acc[mi][ni];
-                        if (scaled) v *= rscale[ni];
-                        *reinterpret_cast<uint2*>(row + mi * 32) = pack4<T>(v[0], v[1], v[2], v[3]);
-                    }
+                for (int mi = 0; mi < MB; mi++) {
+                    f4v v = acc[mi][ni];
+                    if (scaled) v *= rscale[ni];
+                    *reinterpret_cast<uint2*>(row + mi * 32) = pack4<T>(v[0], v[1], v[2], v[3]);
                 }
             }
-            // read back row-contiguous: chunk c of the wave's [32 tokens][NOCT chunks] block -> token c / NOCT, chunk c % NOCT.
-            // In groups of <= 5 sweeps: a group's residual pieces are fetched together first (unconditional, clamped addresses),
-            // so their latency is exposed once per group -- and 20 registers hold them, not 40 next to the live accumulators
-            constexpr int GRP = NIT > 5 ? (NIT + 1) / 2 : NIT;
+            // read back row-contiguous: chunk c of the wave's [16 tokens][NOCT chunks] block -> token c / NOCT, chunk c % NOCT.
+            // The residual pieces of a block are fetched together first (unconditional, clamped addresses): their latency is exposed once.
+            uint4 rr[NIT];
+            if (rb) {
 #pragma unroll
-            for (int i0 = 0; i0 < NIT; i0 += GRP) {
-                uint4 rr[GRP];
-                if (rb) {
-#pragma unroll
-                    for (int i = 0; i < GRP; i++) {
-                        if (i0 + i >= NIT) break;
-                        const int c = (i0 + i) * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
-                        int m = mrow + tok, col = wcol + oc * 8;
-                        m = m < a.M ? m : a.M - 1;
-                        col = col < ncols ? col : 0;
-                        rr[i] = *reinterpret_cast<const uint4*>(rb + (size_t)m * a.ldr + col);
-                    }
+                for (int i = 0; i < NIT; i++) {
+                    const int c = i * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
+                    int m = mrow + (tok < 16 ? tok : 15), col = wcol + oc * 8;
+                    m = m < a.M ? m : a.M - 1;
+                    col = col < ncols ? col : 0;
+                    rr[i] = *reinterpret_cast<const uint4*>(rb + (size_t)m * a.ldr + col);
                 }
+            }
 #pragma unroll
-                for (int i = 0; i < GRP; i++) {
-                    if (i0 + i >= NIT) break;
-                    const int c = (i0 + i) * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
-                    uint4 w = *reinterpret_cast<const uint4*>(ep + tok * EP_PITCH + oc * 16);
-                    const int m = mrow + tok, col = wcol + oc * 8;
-                    if (rb) {
-                        const uint4 r = rr[i];
-                        const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
-                        unsigned oo[4];
+            for (int i = 0; i < NIT; i++) {
+                const int c = i * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
+                const bool live = (NOCT * 16) % 64 == 0 || tok < 16;
+                uint4 w = *reinterpret_cast<const uint4*>(ep + (live ? tok : 0) * EP_PITCH + oc * 16);
+                const int m = mrow + tok, col = wcol + oc * 8;
+                if (rb) {
+                    const uint4 r = rr[i];
+                    const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
+                    unsigned oo[4];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {   // the 16-bit sum of the ROUNDED product and the residual, as the separate ops
-                            const T2 x2 = __builtin_bit_cast(T2, wi[q]), r2 = __builtin_bit_cast(T2, ri[q]);
-                            oo[q] = Tr<T>::pack2((float)x2[0] + (float)r2[0], (float)x2[1] + (float)r2[1]);
-                        }
-                        w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                    for (int q = 0; q < 4; q++) {   // the 16-bit sum of the ROUNDED product and the residual, as the separate ops
+                        const T2 x2 = __builtin_bit_cast(T2, wi[q]), r2 = __builtin_bit_cast(T2, ri[q]);
+                        oo[q] = Tr<T>::pack2((float)x2[0] + (float)r2[0], (float)x2[1] + (float)r2[1]);
                     }
-#if GVD_GEMM_DBG & 16
-                    if (m < a.M && col < ncols && w.x == 0x12345678u) *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
-#else
+                    w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                }
+                if (live && m < a.M && col < ncols) {
 #if GVD_GEMM_NT_STORE
-                    if (m < a.M && col < ncols) {
-                        typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                        __builtin_nontemporal_store(u4v{ w.x, w.y, w.z, w.w }, reinterpret_cast<u4v*>(yb + (size_t)m * a.ldy + col));
-                    }
+                    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(u4v{ w.x, w.y, w.z, w.w }, reinterpret_cast<u4v*>(yb + (size_t)m * a.ldy + col));
 #else
-                    if (m < a.M && col < ncols) *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
-#endif
+                    *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
 #endif
                 }
             }
@@ -664,8 +741,12 @@ template <typename T, int MI, int WM, int BK, bool GEGLU>
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t stream)
 {
     constexpr int BN = WM * MI * 32;
-    constexpr int stage = (BN + BM) * BK * 2, ep = WM * WN * 32 * (MI * 64 + 16);
-    constexpr int smem = stage + (stage > ep ? stage : ep);   // two K stages; the epilogue staging overlays the second
+    constexpr int stage = (BN + BM) * BK * 2, epw = 16 * (MI * 64 + 16);
+    // 8-wave (ring) form: four K slots, the epilogue staging from slot 3 on, the initialisation vectors behind it; 4-wave form: two K
+    // stages, the staging (and the vectors) overlaying the second
+    constexpr int smem = WM == 2 ? 3 * stage + WM * WN * epw + WM * WN * MI * 64 * 4 : stage + (stage > WM * WN * epw ? stage : WM * WN * epw);
+    static_assert(WM != 2 || 3 * stage + WM * WN * epw >= 4 * stage, "the staging area covers slot 3");
+    static_assert(smem <= 160 * 1024, "LDS");
     auto kern = k_gemm_nt<T, MI, WM, BK, GEGLU>;
     static bool attr_done[64] = {};
     static int cus[64] = {};
@@ -688,8 +769,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t stream)
 // Workgroup form: 1 = 8 waves, 320 / 256-channel tiles, K-step 64, one per CU (the faster main loop); 0 = 4 waves, 160 / 128-channel
 // tiles, K-step 32, two per CU -- taken when the 8-wave form would leave CUs without a tile (small M x N: the 9 x 16 level, the
 // context projections, the wide attention's P V product).  GVD_GEMM_VARIANT = 0 / 1 forces one form (A/B runs).
-int gemm_variant(long long M, int N, int batch)
+int gemm_variant(long long M, int N, int batch, int K = 32)
 {
+    if (K & 63) return 0;   // (the ring form reads whole 32-channel half-tiles, two per trip of its loop)
     static const int forced = [] { const char* e = getenv("GVD_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
     if (forced == 0 || forced == 1) return forced;
     const int w5 = (N + 319) / 320 * 320, w4 = (N + 255) / 256 * 256;
@@ -701,12 +783,12 @@ int gemm_variant(long long M, int N, int batch)
 
 extern "C" {
 
-static int tile_n(long long M, int N, int batch)
+static int tile_n(long long M, int N, int batch, int K = 32)
 {
     // 5-block (160 / 320-channel) or 4-block (128 / 256) tiles: the one whose launch is shorter under the simple model
     // rounds-of-resident-workgroups x tile width (padding of N and a mostly empty last round both cost); ties go to the wider tile
     static const int forced = [] { const char* e = getenv("GVD_GEMM_BLOCKS"); return e ? atoi(e) : 0; }();
-    const int v = gemm_variant(M, N, batch), big = v == 1 ? 2 : 1, resident = v == 1 ? 256 : 512;
+    const int v = gemm_variant(M, N, batch, K), big = v == 1 ? 2 : 1, resident = v == 1 ? 256 : 512;
     const int w5 = 160 * big, w4 = 128 * big;
     if (forced == 4 || forced == 5) return forced == 5 ? w5 : w4;
     const long long mt = (M + BM - 1) / BM * batch;
@@ -750,7 +832,7 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
         if (es != hipSuccess) return fail(-2, "launch k_gemm_skinny", es);
         return 0;
     }
-    const int bn = tile_n(M, N, batch);
+    const int bn = tile_n(M, N, batch, K);
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + bn - 1) / bn; a.mgroups = (a.tiles_m + 7) / 8;
     {   // channel tiles whose W rows (bn x K x 2 bytes each) share an XCD's L2 with the token panels in flight
         static const long long budget = [] { const char* e = getenv("GVD_GEMM_L2_BYTES"); return e ? atoll(e) : (3LL << 19); }();
@@ -766,8 +848,8 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
     (is_bf16 ? (geglu ? launch_gemm<__bf16, MI_, WM_, BK_, true>(a, stream) : launch_gemm<__bf16, MI_, WM_, BK_, false>(a, stream))      \
              : (geglu ? launch_gemm<_Float16, MI_, WM_, BK_, true>(a, stream) : launch_gemm<_Float16, MI_, WM_, BK_, false>(a, stream)))
     switch (bn) {
-    case 320: e = GVD_GEMM_GO(5, 2, 64); break;
-    case 256: e = GVD_GEMM_GO(4, 2, 64); break;
+    case 320: e = GVD_GEMM_GO(5, 2, 32); break;
+    case 256: e = GVD_GEMM_GO(4, 2, 32); break;
     case 160: e = GVD_GEMM_GO(5, 1, 32); break;
     default: e = GVD_GEMM_GO(4, 1, 32); break;
     }

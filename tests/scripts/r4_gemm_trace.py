@@ -11,7 +11,7 @@ from lvdm_amd import gemm, ops
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 print("lib", sys.argv[1])
-for (M, N, K) in [(230400, 2560, 320), (230400, 320, 320), (57600, 5120, 640)]:
+for (M, N, K) in [(230400, 2560, 320), (230400, 320, 320), (57600, 5120, 640), (14400, 10240, 1280)]:
     x = torch.randn(M, K, device=dev, generator=g).half()
     w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).half()
     b = torch.randn(N, device=dev, generator=g)
