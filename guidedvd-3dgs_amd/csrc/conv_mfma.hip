@@ -58,6 +58,43 @@ __device__ unsigned long long g_ctrace[2048 * 6];
 #define GVD_CSTAMP(i) do { } while (0)
 #endif
 
+
+#ifndef GVD_CONV_RDAHEAD
+#define GVD_CONV_RDAHEAD 2   // A fragments read ahead of their MFMAs, in steps of NI MFMAs (0: the compiler's own order, for A/B builds)
+#endif
+// sched_group_barrier takes literal sizes: one instantiation per (reads, MFMAs) group
+template <int N> __device__ __forceinline__ void sgb_read()
+{
+    if constexpr (N == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    else if constexpr (N == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    else if constexpr (N == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    else if constexpr (N == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    else if constexpr (N == 5) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+    else if constexpr (N == 6) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    else if constexpr (N == 7) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+    else if constexpr (N == 8) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    else static_assert(N == 0, "add a case");
+}
+template <int N> __device__ __forceinline__ void sgb_mfma()
+{
+    if constexpr (N == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    else if constexpr (N == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    else if constexpr (N == 4) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    else static_assert(N == 0, "add a case");
+}
+// the order of the read-ahead block of the K loop below: NI + RD reads, then per (ks, mi) [its read(s)] [NI MFMAs]
+template <int MI, int NI, int RD, int KS = 0, int M = 0> __device__ __forceinline__ void conv_sched()
+{
+    if constexpr (KS == 0 && M == 0) sgb_read<NI + RD>();
+    if constexpr (KS < 2) {
+        if constexpr (M + RD < MI) sgb_read<1>();
+        else if constexpr (KS == 0) sgb_read<(M + RD - MI == 0 ? NI : 0) + 1>();
+        sgb_mfma<NI>();
+        if constexpr (M + 1 < MI) conv_sched<MI, NI, RD, KS, M + 1>();
+        else conv_sched<MI, NI, RD, KS + 1, 0>();
+    }
+}
+
 struct ConvArgs {
     const void* x;        // input activations
     const void* w;        // packed weights
@@ -401,6 +438,35 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                 else if (SPATIAL) { const int dy = tap / 3, dx = tap - 3 * dy; shift = dy * G_::PITCH + dx * PIX_BYTES; }
                 else shift = tap * PB * PIX_BYTES;
                 const unsigned char* pb = pbuf + pcur * PBYTES + shift;
+                if constexpr (GVD_CONV_RDAHEAD > 0 && MI <= 4) {   // (the 5-block tiles sit at the register cap: any pinned read-ahead spills them)
+                    // operand fragments read AHEAD of the MFMAs that use them, in an order pinned for the machine scheduler (left alone it sinks
+                    // every read to right in front of its first use: the LDS latency in front of every group of MFMAs -- gemm_mfma.hip)
+                    vec8 af[2][MI], bf[2][NI];
+                    auto rd_a = [&](int ks, int mi) { af[ks][mi] = *reinterpret_cast<const vec8*>(wb + a_off[ks] + mi * 2048); };
+                    auto rd_b = [&](int ks, int ni) { bf[ks][ni] = *reinterpret_cast<const vec8*>(pb + b_off[ni] + ks * 32); };
+                    constexpr int RD = GVD_CONV_RDAHEAD < MI ? GVD_CONV_RDAHEAD : (MI > 1 ? MI - 1 : 1);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) rd_b(0, ni);
+#pragma unroll
+                    for (int d = 0; d < RD; d++) rd_a(0, d);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                        for (int mi = 0; mi < MI; mi++) {
+                            if (mi + RD < MI) rd_a(ks, mi + RD);
+                            else if (ks == 0) {
+                                const int d = mi + RD - MI;
+                                if (d == 0) {
+#pragma unroll
+                                    for (int ni = 0; ni < NI; ni++) rd_b(1, ni);
+                                }
+                                rd_a(1, d);
+                            }
+#pragma unroll
+                            for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[ks][mi], bf[ks][ni], acc[mi][ni]);
+                        }
+                    conv_sched<MI, NI, RD>();
+                } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
                     vec8 af[MI], bf[NI];
@@ -412,6 +478,7 @@ __global__ void __launch_bounds__(256, MODE == 3 ? 1 : 2) k_conv_mfma(const Conv
                     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                         for (int ni = 0; ni < NI; ni++) acc[mi][ni] = Tr<T>::mfma(af[mi], bf[ni], acc[mi][ni]);
+                }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 store_w(wcur ^ 1);

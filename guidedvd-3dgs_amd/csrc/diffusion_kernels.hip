@@ -989,24 +989,7 @@ __global__ void __launch_bounds__(256) k_layer_norm(const T* __restrict__ x, T* 
 // the shorter Abramowitz-Stegun form in gemm_mfma.hip's fused epilogue does not give; these row kernels sit at the HBM rate either
 // way).  Phi = 1 - erfc/2 for g >= 0, erfc/2 for g < 0: no cancellation.  The two row kernels were VALU-bound with erff + expf
 // (197 us for the 717 MB of a level-0 gate gradient: 3.6 TB/s); they now move their bytes at 5.5-5.8 TB/s.
-__device__ __forceinline__ void gelu_cdf_exp(float g, float& cdf, float& e)
-{
-    const float z = fabsf(g) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.f));
-    float c = fmaf(t, 0.17087277f, -0.82215223f);
-    c = fmaf(t, c, 1.48851587f);
-    c = fmaf(t, c, -1.13520398f);
-    c = fmaf(t, c, 0.27886807f);
-    c = fmaf(t, c, -0.18628806f);
-    c = fmaf(t, c, 0.09678418f);
-    c = fmaf(t, c, 0.37409196f);
-    c = fmaf(t, c, 1.00002368f);
-    c = fmaf(t, c, -1.26551223f);
-    const float mz2 = (-0.5f * 1.4426950408889634f) * (g * g);   // -z^2 log2(e)
-    e = __builtin_amdgcn_exp2f(mz2);
-    const float half_erfc = (0.5f * t) * __builtin_amdgcn_exp2f(fmaf(c, 1.4426950408889634f, mz2));
-    cdf = g >= 0.f ? 1.f - half_erfc : half_erfc;
-}
+// (gelu_cdf_exp: diffusion_common.h -- shared with the GEMM's fused gate epilogues)
 
 // GEGLU gate (attention.py:415-423): y[m, c] = h[m, c] * gelu(h[m, C + c]) for h = proj(x) of width 2C; exact (erf) GELU.
 template <typename T>

@@ -51,7 +51,9 @@ struct GemmArgs {
     const float2* row_stats;               // [batch][M] (mean, rstd) or nullptr
     const float* col_sum;                  // [N] s[n] (with row_stats)
     const void* res; long long ldr, sr;    // residual rows (layout of y) or nullptr
-    int geglu;                             // W rows in [16 value | 16 gate] blocks (gvd_diffusion.h); y has N / 2 columns
+    int geglu;                             // gate mode (gvd_diffusion.h): 0 none, 1 gate (y has N / 2 columns), 2 gate + the pre-activation to `aux`,
+                                           // 3 gate backward (the product is d/d(gated output); `aux` = the saved pre-activation, y = its gradient, 2 N columns)
+    const void* aux; long long ldaux, saux;   // [.., M, N] (mode 2, written) / [.., M, 2 N] (mode 3, read), columns in the kernel's [16 value | 16 gate] order
 };
 
 #ifndef GVD_GEMM_RDAHEAD
@@ -107,9 +109,10 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { ret
 // wave continues across it without a gap.  The DMA instructions are hand-written (hipcc counts a builtin LDS-DMA as a pending LDS write and
 // drains it -- vmcnt(0) -- in front of the next LDS read it cannot tell apart) and issued between the MFMA steps; the three half-tiles that
 // open the NEXT tile go out before this tile's epilogue, whose staging lives in slot 3 and the space behind it.
-template <typename T, int MI, int WM, int BK, bool GEGLU>
+template <typename T, int MI, int WM, int BK, int GM>
 __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
 {
+    constexpr bool GEGLU = GM == 1;   // the inference gate: fp32 through the gate, y only.  Modes 2 / 3 stage the plain (rounded) tile and gate in the read-back
     typedef typename Tr<T>::vec8 vec8;
     typedef T T2 __attribute__((ext_vector_type(2)));
     constexpr bool RING = WM == 2;
@@ -497,8 +500,22 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
             }
             // read back row-contiguous: chunk c of the wave's [16 tokens][NOCT chunks] block -> token c / NOCT, chunk c % NOCT.
             // The residual pieces of a block are fetched together first (unconditional, clamped addresses): their latency is exposed once.
-            uint4 rr[NIT];
-            if (rb) {
+            uint4 rr[NIT], rg[GM == 3 ? NIT : 1];
+            if (GM == 3) {
+                // gate backward: the tile is d/d(gated output) for outputs col .. col + 7; value and gate of those outputs sit in the saved
+                // pre-activation's [16 value | 16 gate] blocks at (col >> 4) * 32 + (col & 8) and + 16
+                const T* __restrict__ hb = (const T*)a.aux + (size_t)tb * a.saux;
+#pragma unroll
+                for (int i = 0; i < NIT; i++) {
+                    const int c = i * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
+                    int m = mrow + (tok < 16 ? tok : 15), col = wcol + oc * 8;
+                    m = m < a.M ? m : a.M - 1;
+                    col = col < ncols ? col : 0;
+                    const T* hp = hb + (size_t)m * a.ldaux + ((col >> 4) * 32 + (col & 8));
+                    rr[i] = *reinterpret_cast<const uint4*>(hp);
+                    rg[i] = *reinterpret_cast<const uint4*>(hp + 16);
+                }
+            } else if (rb) {
 #pragma unroll
                 for (int i = 0; i < NIT; i++) {
                     const int c = i * 64 + lane, tok = c / NOCT, oc = c - tok * NOCT;
@@ -514,6 +531,26 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
                 const bool live = (NOCT * 16) % 64 == 0 || tok < 16;
                 uint4 w = *reinterpret_cast<const uint4*>(ep + (live ? tok : 0) * EP_PITCH + oc * 16);
                 const int m = mrow + tok, col = wcol + oc * 8;
+                if (GM == 3) {
+                    // attention.py:415-423 backward, as k_geglu_bwd evaluates it on the ROUNDED operands: d value = dy gelu(g), d gate = dy value gelu'(g)
+                    const vec8 dyv = __builtin_bit_cast(vec8, w), av = __builtin_bit_cast(vec8, rr[i]), gv = __builtin_bit_cast(vec8, rg[i]);
+                    vec8 ra, rgt;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const float gf = (float)gv[k], df = (float)dyv[k];
+                        float cdf, e;
+                        gelu_cdf_exp(gf, cdf, e);
+                        const float pdf = 0.3989422804014327f * e;
+                        ra[k] = (T)(df * gf * cdf);
+                        rgt[k] = (T)(df * (float)av[k] * fmaf(gf, pdf, cdf));
+                    }
+                    if (live && m < a.M && col < ncols) {
+                        T* dp = yb + (size_t)m * a.ldy + ((col >> 4) * 32 + (col & 8));
+                        *reinterpret_cast<vec8*>(dp) = ra;
+                        *reinterpret_cast<vec8*>(dp + 16) = rgt;
+                    }
+                    continue;
+                }
                 if (rb) {
                     const uint4 r = rr[i];
                     const unsigned wi[4] = { w.x, w.y, w.z, w.w }, ri[4] = { r.x, r.y, r.z, r.w };
@@ -526,12 +563,37 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_gemm_nt(const GemmArgs a)
                     w = make_uint4(oo[0], oo[1], oo[2], oo[3]);
                 }
                 if (live && m < a.M && col < ncols) {
+                    T* dst = GM == 2 ? (T*)a.aux + (size_t)tb * a.saux + (size_t)m * a.ldaux + col : yb + (size_t)m * a.ldy + col;   // (mode 2: the pre-activation)
 #if GVD_GEMM_NT_STORE
                     typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(u4v{ w.x, w.y, w.z, w.w }, reinterpret_cast<u4v*>(yb + (size_t)m * a.ldy + col));
+                    __builtin_nontemporal_store(u4v{ w.x, w.y, w.z, w.w }, reinterpret_cast<u4v*>(dst));
 #else
-                    *reinterpret_cast<uint4*>(yb + (size_t)m * a.ldy + col) = w;
+                    *reinterpret_cast<uint4*>(dst) = w;
 #endif
+                }
+            }
+            if (GM == 2) {
+                // the gate on the staged, ROUNDED pre-activation (what k_geglu reads back from memory on the unfused path: bit-identical):
+                // output chunk oc2 = 8 outputs 16 j + 8 half .. of this wave: values at bytes 64 j + 16 half of the token row, gates 32 further
+                constexpr int NOCT2 = MI * 2, NIT2 = (NOCT2 * 16 + 63) / 64;
+                const int wcol2 = (tn0 >> 1) + wm * MI * 16, ncols2 = a.N >> 1;
+#pragma unroll
+                for (int i = 0; i < NIT2; i++) {
+                    const int c = i * 64 + lane, tok = c / NOCT2, oc = c - tok * NOCT2;
+                    const bool live = (NOCT2 * 16) % 64 == 0 || tok < 16;
+                    const unsigned char* sp = ep + (live ? tok : 0) * EP_PITCH + (oc >> 1) * 64 + (oc & 1) * 16;
+                    const vec8 av = *reinterpret_cast<const vec8*>(sp), gv = *reinterpret_cast<const vec8*>(sp + 32);
+                    vec8 r;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const float gf = (float)gv[k];
+                        float cdf, e;
+                        gelu_cdf_exp(gf, cdf, e);
+                        const T ge = (T)(gf * cdf);               // torch: gelu in fp32, rounded, then the product (two separate ops)
+                        r[k] = (T)((float)av[k] * (float)ge);
+                    }
+                    const int m = mrow + tok, col = wcol2 + oc * 8;
+                    if (live && m < a.M && col < ncols2) *reinterpret_cast<vec8*>(yb + (size_t)m * a.ldy + col) = r;
                 }
             }
         }
@@ -737,7 +799,7 @@ __global__ void __launch_bounds__(256) k_attn_ds(T* __restrict__ s, T* __restric
     }
 }
 
-template <typename T, int MI, int WM, int BK, bool GEGLU>
+template <typename T, int MI, int WM, int BK, int GM>
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t stream)
 {
     constexpr int BN = WM * MI * 32;
@@ -747,8 +809,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t stream)
     constexpr int smem = WM == 2 ? 3 * stage + WM * WN * epw + WM * WN * MI * 64 * 4 : stage + (stage > WM * WN * epw ? stage : WM * WN * epw);
     static_assert(WM != 2 || 3 * stage + WM * WN * epw >= 4 * stage, "the staging area covers slot 3");
     static_assert(smem <= 160 * 1024, "LDS");
-    auto kern = k_gemm_nt<T, MI, WM, BK, GEGLU>;
-    static bool attr_done[64] = {};
+    auto kern = k_gemm_nt<T, MI, WM, BK, GM>;
+    static bool attr_done[64] = {};   // (per instantiation)
     static int cus[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -800,26 +862,31 @@ int gvd_gemm_tile_n(int M, int N, int batch) { return tile_n(M, N, batch); }
 
 int gvd_gemm_geglu_layout(void) { return 1; }   // 1: [16 values | 16 gates] in natural order (16 x 16 x 32 MFMA blocks); see gvd_diffusion.h
 
-int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
-                void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
-                const float* row_stats, const float* col_sum, const void* residual, long long ldr, long long stride_r,
-                int geglu, int is_bf16, void* stream_)
+static int gemm_nt_impl(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
+                        void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
+                        const float* row_stats, const float* col_sum, const void* residual, long long ldr, long long stride_r,
+                        int geglu, const void* aux, long long ldaux, long long stride_aux, int is_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (geglu < 0 || geglu > 3) return fail(-1, "gvd_gemm_nt: gate mode is 0 .. 3");
+    if (geglu >= 2 && (!aux || (ldaux & 7) || (stride_aux & 7) || ((uintptr_t)aux & 15) || residual))
+        return fail(-1, "gvd_gemm_nt_gate: modes 2 / 3 need the pre-activation tensor (aligned, strides multiples of 8) and take no residual");
+    if (geglu == 3 && (N & 15)) return fail(-1, "gvd_gemm_nt_gate: mode 3 needs N % 16 == 0");
     if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return fail(-1, "gvd_gemm_nt: bad arguments");
     if ((K & 7) || (ldx & 7) || (ldw & 7) || (ldy & 7) || (stride_x & 7) || (stride_w & 7) || (stride_y & 7) ||
         (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)residual) & 15))
         return fail(-1, "gvd_gemm_nt: K, row and batch strides must be multiples of 8 elements and tensors 16-byte aligned");
-    if (geglu ? (N & 31) : (N & 7)) return fail(-1, "gvd_gemm_nt: N must be a multiple of 8 (32 with the GEGLU epilogue)");
+    if ((geglu == 1 || geglu == 2) ? (N & 31) : (N & 7)) return fail(-1, "gvd_gemm_nt: N must be a multiple of 8 (32 with the GEGLU epilogue)");
     if ((row_stats == nullptr) != (col_sum == nullptr)) return fail(-1, "gvd_gemm_nt: the LayerNorm fold needs row_stats AND col_sum");
     if (residual && ((ldr & 7) || (stride_r & 7))) return fail(-1, "gvd_gemm_nt: residual strides must be multiples of 8");
     GemmArgs a{};
     a.x = x; a.w = w; a.y = y; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.sx = stride_x; a.sw = stride_w; a.sy = stride_y;
     a.M = M; a.N = N; a.K = K; a.batch = batch; a.alpha = alpha; a.bias = bias;
     a.row_stats = reinterpret_cast<const float2*>(row_stats); a.col_sum = col_sum;
-    a.res = residual; a.ldr = ldr; a.sr = stride_r; a.geglu = geglu ? 1 : 0;
+    a.res = residual; a.ldr = ldr; a.sr = stride_r; a.geglu = geglu;
+    a.aux = aux; a.ldaux = ldaux; a.saux = stride_aux;
     static const bool no_skinny = [] { const char* e = getenv("GVD_GEMM_NO_SKINNY"); return e && e[0] != '0'; }();   // (A/B switch)
-    if (M <= 256 && batch == 1 && !row_stats && !residual && !geglu && !no_skinny) {
+    if (M <= 256 && batch == 1 && !row_stats && !residual && !geglu && !no_skinny) {   // (geglu: any gate mode)
         // skinny: a wave per (32 channels, quarter of K); y = alpha x w^T + bias
         const int tb = (M + 31) / 32;
         const dim3 grid((unsigned)((N + 31) / 32), tb > 4 ? 2u : 1u);
@@ -844,9 +911,10 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
     }
     if ((long long)a.mgroups * 8 * a.tiles_n * batch >= (1LL << 31)) return fail(-1, "gvd_gemm_nt: grid too large");
     hipError_t e;
-#define GVD_GEMM_GO(MI_, WM_, BK_)                                                                                                  \
-    (is_bf16 ? (geglu ? launch_gemm<__bf16, MI_, WM_, BK_, true>(a, stream) : launch_gemm<__bf16, MI_, WM_, BK_, false>(a, stream))      \
-             : (geglu ? launch_gemm<_Float16, MI_, WM_, BK_, true>(a, stream) : launch_gemm<_Float16, MI_, WM_, BK_, false>(a, stream)))
+#define GVD_GEMM_GM(T_, MI_, WM_, BK_)                                                                                              \
+    (geglu == 0 ? launch_gemm<T_, MI_, WM_, BK_, 0>(a, stream) : geglu == 1 ? launch_gemm<T_, MI_, WM_, BK_, 1>(a, stream)              \
+     : geglu == 2 ? launch_gemm<T_, MI_, WM_, BK_, 2>(a, stream) : launch_gemm<T_, MI_, WM_, BK_, 3>(a, stream))
+#define GVD_GEMM_GO(MI_, WM_, BK_) (is_bf16 ? GVD_GEMM_GM(__bf16, MI_, WM_, BK_) : GVD_GEMM_GM(_Float16, MI_, WM_, BK_))
     switch (bn) {
     case 320: e = GVD_GEMM_GO(5, 2, 32); break;
     case 256: e = GVD_GEMM_GO(4, 2, 32); break;
@@ -854,8 +922,28 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
     default: e = GVD_GEMM_GO(4, 1, 32); break;
     }
 #undef GVD_GEMM_GO
+#undef GVD_GEMM_GM
     if (e != hipSuccess) return fail(-2, "launch k_gemm_nt", e);
     return 0;
+}
+
+int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
+                void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
+                const float* row_stats, const float* col_sum, const void* residual, long long ldr, long long stride_r,
+                int geglu, int is_bf16, void* stream)
+{
+    return gemm_nt_impl(x, ldx, stride_x, w, ldw, stride_w, y, ldy, stride_y, M, N, K, batch, alpha, bias, row_stats, col_sum, residual, ldr, stride_r,
+                        geglu ? 1 : 0, nullptr, 0, 0, is_bf16, stream);
+}
+
+int gvd_gemm_nt_gate(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
+                     void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
+                     const float* row_stats, const float* col_sum, int mode, void* aux, long long ldaux, long long stride_aux,
+                     int is_bf16, void* stream)
+{
+    if (mode != 2 && mode != 3) return fail(-1, "gvd_gemm_nt_gate: mode is 2 (gate + pre-activation) or 3 (gate backward)");
+    return gemm_nt_impl(x, ldx, stride_x, w, ldw, stride_w, y, ldy, stride_y, M, N, K, batch, alpha, bias, row_stats, col_sum, nullptr, 0, 0,
+                        mode, aux, ldaux, stride_aux, is_bf16, stream);
 }
 
 int gvd_row_stats(const void* x, long long ldx, float* stats, long long M, int C, float eps, int is_bf16, void* stream_)

@@ -270,6 +270,19 @@ int gvd_gemm_nt(const void* x, long long ldx, long long stride_x, const void* w,
 
 /* Channel-tile width (320 / 256: 8-wave workgroups; 160 / 128: 4-wave workgroups for problems that would under-fill the chip)
  * gvd_gemm_nt uses for an M x N problem with `batch` batches. */
+/* The GEGLU feed-forward of the guided sampler's differentiable U-Net evaluation (attention.py:415-450 under autograd with frozen weights)
+ * without its two gate row kernels -- the same product and LayerNorm fold / bias as gvd_gemm_nt (no residual), W rows in the gate order above:
+ *   mode 2 (forward)   y [.., M, N / 2] = value * gelu(gate), evaluated on the ROUNDED projection exactly as gvd_geglu evaluates it on the tensor
+ *                      it reads back, and aux [.., M, N] = that projection (columns stay in the kernel's [16 value | 16 gate] block order: only
+ *                      mode 3 reads it);
+ *   mode 3 (backward)  the product is d(loss)/d(gated output) [.., M, N] (x = the gradient behind the output projection, w = that projection's
+ *                      transposed weight); aux [.., M, 2 N] is the tensor mode 2 saved; y [.., M, 2 N] = d(loss)/d(projection) in the same block
+ *                      order (d value = dy gelu(gate), d gate = dy value gelu'(gate), as gvd_geglu_bwd).  N % 16 == 0. */
+int gvd_gemm_nt_gate(const void* x, long long ldx, long long stride_x, const void* w, long long ldw, long long stride_w,
+                     void* y, long long ldy, long long stride_y, int M, int N, int K, int batch, float alpha, const float* bias,
+                     const float* row_stats, const float* col_sum, int mode, void* aux, long long ldaux, long long stride_aux,
+                     int is_bf16, void* stream);
+
 int gvd_gemm_tile_n(int M, int N, int batch);
 int gvd_gemm_geglu_layout(void);
 

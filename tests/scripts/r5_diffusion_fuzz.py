@@ -42,8 +42,9 @@ for it in range(120):
     if geglu:
         # gemm_nt's GEGLU epilogue expects W rows in blocks of [16 value | 16 gate] rows, half-row c holding output u(c) of the block
         # (gemm._geglu_perm / include/gvd_diffusion.h): the random W here IS such an image, so the reference is un-permuted instead
+        # (round 6: the 16 x 16 x 32 MFMA kernels take each half in natural order -- gvd_gemm_geglu_layout() == 1)
         c = torch.arange(16, device=dev)
-        u = 8 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3)
+        u = c if ops.lib().gvd_gemm_geglu_layout() == 1 else 8 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3)
         r4 = ref.reshape(*ref.shape[:-1], N // 32, 2, 16)
         prod = r4[..., 0, :] * F.gelu(r4[..., 1, :])
         out = torch.empty_like(prod)
