@@ -14,6 +14,7 @@ with the reference's torch ops (F.layer_norm, F.linear, gelu).  fp32 device tens
 usual one-time RuntimeWarning.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -31,6 +32,10 @@ def _lib():
         L.gvd_gemm_nt.argtypes = [_P, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_float, _P, _P, _P, _P, _LL, _LL, ctypes.c_int, ctypes.c_int, _P]
         L.gvd_gemm_nt.restype = ctypes.c_int
+        if hasattr(L, "gvd_gemm_nt_gate"):
+            L.gvd_gemm_nt_gate.argtypes = [_P, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_float, _P, _P, _P, ctypes.c_int, _P, _LL, _LL, ctypes.c_int, _P]
+            L.gvd_gemm_nt_gate.restype = ctypes.c_int
         L.gvd_row_stats.argtypes = [_P, _LL, _P, _LL, ctypes.c_int, ctypes.c_float, ctypes.c_int, _P]
         L.gvd_row_stats.restype = ctypes.c_int
         _SIG = True
@@ -253,6 +258,103 @@ class _FusedLinearFn(torch.autograd.Function):
         if in_to is not None and in_to.put(dh):
             dh = None
         return (dh, g_res, None, None, None) + (None,) * (2 * len(weights))
+
+
+def _gate_gemm(x2, w, y, aux, mode, *, bias=None, row_stats=None, col_sum=None):
+    """gvd_gemm_nt_gate on 2-D row tensors: mode 2 -- y [M, N / 2] = gate(x2 w^T ...), aux [M, N] = the projection (kernel block order);
+    mode 3 -- the product is d/d(gated output) [M, N], aux [M, 2 N] the saved projection, y [M, 2 N] its gradient."""
+    M, K = x2.shape
+    N = w.shape[0]
+    p = lambda t: _P(None if t is None else t.data_ptr())
+    with ops._on(x2.device):
+        rc = _lib().gvd_gemm_nt_gate(p(x2), x2.stride(0) if M > 1 else K, 0, p(w), w.stride(0), 0, p(y), y.stride(0) if M > 1 else y.shape[1], 0,
+                                     M, N, K, 1, 1.0, p(bias), p(row_stats), p(col_sum), int(mode), p(aux), aux.stride(0) if M > 1 else aux.shape[1], 0,
+                                     1 if x2.dtype == torch.bfloat16 else 0, _P(ops._stream()))
+    ops._check(rc)
+    return y
+
+
+def _transposed_gate_order(weight, dtype):
+    """[K, 2C] image of a GEGLU projection [2C, K] for the input-gradient GEMM behind the fused gate backward: columns in the kernel's
+    [16 value | 16 gate] block order (the order gvd_gemm_nt_gate's mode 3 writes d/d(projection) in).  Cached on the weight."""
+    key = (_tag(weight), dtype)
+    cache = getattr(weight, "_gvd_gemm_tg", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            W = weight.detach().reshape(weight.shape[0], -1).to(dtype)
+            Wt = W[_geglu_perm(W.shape[0], W.device)].t().contiguous()
+        cache = (key, Wt)
+        try:
+            weight._gvd_gemm_tg = cache
+        except AttributeError:
+            pass
+    return cache[1]
+
+
+class _FeedForwardFn(torch.autograd.Function):
+    """The transformer block's feed-forward under autograd with frozen weights (attention.py:415-450, :241-244; the guided sampler's
+    differentiable U-Net evaluation) as FOUR GEMM launches and no gate row kernel:
+        forward    g = geglu(LayerNorm(x) W1^T + b1)   one launch: LayerNorm fold, gate, and the projection saved for the backward (mode 2)
+                   y = g W2^T + b2 [+ x]               one launch (residual in the epilogue)
+        backward   dh = gate'(gy W2)                   one launch: the gate's backward in the epilogue of its producer (mode 3)
+                   dx = LayerNorm'(dh W1) [+ gy]       one launch + the LayerNorm row kernel (which adds the residual branch's gradient)
+    The unfused pair wrote the projection, read it for the gate (k_geglu), and in the backward wrote d/d(gated) and read it again next to the
+    projection (k_geglu_bwd): 4.5 + 2.7 ms of a 220 ms guided step at 320x448.  Same operand roundings as the unfused kernels."""
+
+    @staticmethod
+    def forward(ctx, x2, ln_w, ln_b, cfg, w1, b1, w2, b2):
+        ln, res_is_x = cfg
+        Wd, c, s = _prepared([w1], [b1], ln, True, x2.dtype)
+        st = None if ln is None else row_stats(x2, ln.eps)
+        M, C2 = x2.shape[0], Wd.shape[0]
+        h = torch.empty((M, C2), dtype=x2.dtype, device=x2.device)
+        g = torch.empty((M, C2 // 2), dtype=x2.dtype, device=x2.device)
+        _gate_gemm(x2, Wd, g, h, 2, bias=c, row_stats=st, col_sum=s)
+        W2d, c2, _ = _prepared([w2], [b2], None, False, x2.dtype)
+        y = gemm_nt(g, W2d, bias=c2, residual=x2 if res_is_x else None)
+        ctx.save_for_backward(x2, h)
+        ctx.cfg = (ln, res_is_x, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ln, res_is_x, w1, w2 = ctx.cfg
+        x2, h = ctx.saved_tensors
+        gy = gy if gy.stride(-1) == 1 else gy.contiguous()
+        Wt2 = _transposed([w2], gy.dtype)                            # [C, dim]: d/d(gated) = gy W2
+        dh = torch.empty_like(h)
+        _gate_gemm(gy, Wt2, dh, h, 3)
+        Wt1 = _transposed_gate_order(w1, gy.dtype)                   # [dim, 2C], columns in dh's block order
+        extra = gy if res_is_x else None
+        if ln is None:
+            dx = gemm_nt(dh, Wt1, residual=extra)
+        else:
+            dxn = gemm_nt(dh, Wt1)
+            dx = torch.empty_like(dxn)
+            C = dxn.shape[-1]
+            x2c = x2 if x2.is_contiguous() else x2.contiguous()
+            ex = None if extra is None else (extra if extra.is_contiguous() else extra.contiguous())
+            with ops._on(dxn.device):
+                ops._check(ops.lib().gvd_layer_norm_bwd_add(_P(x2c.data_ptr()), _P(dxn.data_ptr()), _P(ln.weight.data_ptr()),
+                                                            _P(None if ex is None else ex.data_ptr()), _P(dx.data_ptr()),
+                                                            _LL(dxn.shape[0]), C, ctypes.c_float(ln.eps),
+                                                            1 if dxn.dtype == torch.bfloat16 else 0, _P(ops._stream())))
+        return dx, None, None, None, None, None, None, None
+
+
+def feed_forward(x, w1, b1, w2, b2, *, ln=None, residual=None):
+    """y = geglu(LayerNorm?(x) w1^T + b1) w2^T + b2 [+ residual] (attention.py:415-450).  Under autograd with frozen weights and the fused
+    kernels available this is _FeedForwardFn (no gate row kernels); otherwise the two `linear` calls it stands for."""
+    fused = (torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+             and not any(t is not None and t.requires_grad for t in (w1, b1, w2, b2))
+             and x.shape[-1] % 8 == 0 and w1.shape[0] % 32 == 0 and w2.shape[0] % 8 == 0 and w1.shape[0] == 2 * w2.shape[1]
+             and (ln is None or _ln_kernel_ok(x, ln)) and (residual is None or residual is x)
+             and hasattr(ops.lib(), "gvd_gemm_nt_gate") and os.environ.get("GVD_NO_FUSED_FF") is None)
+    if not fused:
+        return None
+    x2 = _rows(x)
+    y = _FeedForwardFn.apply(x2, None if ln is None else ln.weight, None if ln is None else ln.bias, (ln, residual is x), w1, b1, w2, b2)
+    return y.reshape(*x.shape[:-1], y.shape[-1])
 
 
 def _rows(x):

@@ -198,6 +198,12 @@ class FeedForward(nn.Module):
 
     def forward(self, x, norm=None, residual=None):
         """norm: the LayerNorm in front (folded into the projection); residual: the block's `+ x` (second GEMM's epilogue)."""
+        drop = self.net[1]
+        if not (drop.training and drop.p > 0):
+            # guided sampler (autograd, frozen weights): projection + gate + output projection and their backward without the gate row kernels
+            y = gemm.feed_forward(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=norm, residual=residual)
+            if y is not None:
+                return y
         cell = _cell(x) if residual is x else None
         h = self.net[1](self.net[0](x, norm=norm, grad_add=cell))
         return gemm.linear(h, self.net[2].weight, self.net[2].bias, residual=residual, res_grad_to=cell)

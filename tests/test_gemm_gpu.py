@@ -232,3 +232,53 @@ def test_fused_forms_under_autograd_match_fp32():
     (g_r,) = torch.autograd.grad([qkv_r, y_r], [xf], [probe_q.float(), probe_y.float()])
     assert _rel(qkv.detach(), qkv_r.detach()) < 2.5e-3 and _rel(y.detach(), y_r.detach()) < 3e-3
     assert _rel(gx, g_r) < 6e-3, _rel(gx, g_r)
+
+
+@pytest.mark.parametrize("C,M,with_ln,res", [(320, 1100, True, True), (640, 777, True, True), (128, 300, False, True), (320, 513, True, False)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_feed_forward_equals_the_unfused_pair(C, M, with_ln, res, dtype, monkeypatch):
+    """attention.py:415-450 under autograd (guided sampler): `gemm.feed_forward` -- gate and the saved projection in the producing GEMM's
+    epilogue, the gate's backward in the epilogue of ITS producer (gvd_gemm_nt_gate modes 2 / 3) -- against the two `linear` calls with the
+    gate row kernels between them.  The forward is bit-identical (same operand roundings); the input gradient differs only by the
+    accumulation order of the last product (its K runs over the kernel's [16 value | 16 gate] block order), and both sit at the 16-bit
+    rounding level from the fp32 form."""
+    from lvdm_amd import gemm
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ln = None
+    if with_ln:
+        ln = torch.nn.LayerNorm(C).to(DEV)
+        with torch.no_grad():
+            ln.weight.copy_(1 + 0.3 * torch.randn(C, device=DEV, generator=g))
+            ln.bias.copy_(0.2 * torch.randn(C, device=DEV, generator=g))
+        ln.to(dtype).requires_grad_(False)
+    p1 = torch.nn.Linear(C, 8 * C).to(DEV).to(dtype).requires_grad_(False)
+    p2 = torch.nn.Linear(4 * C, C).to(DEV).to(dtype).requires_grad_(False)
+    x0 = _mk(g, 2, M, C, dtype=dtype)
+    probe = _mk(g, 2, M, C, dtype=dtype)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("GVD_NO_FUSED_FF", raising=False)
+        else:
+            monkeypatch.setenv("GVD_NO_FUSED_FF", "1")
+        x = x0.clone().requires_grad_(True)
+        y = gemm.feed_forward(x, p1.weight, p1.bias, p2.weight, p2.bias, ln=ln, residual=x if res else None)
+        if not fused:
+            assert y is None
+            h = gemm.linear(x, p1.weight, p1.bias, ln=ln, geglu=True)
+            y = gemm.linear(h, p2.weight, p2.bias, residual=x if res else None)
+        (gx,) = torch.autograd.grad(y, x, probe)
+        return y.detach(), gx
+
+    y_f, g_f = run(True)
+    y_u, g_u = run(False)
+    assert torch.equal(y_f, y_u)
+    tol = 3e-3 if dtype == torch.float16 else 2.5e-2
+    assert _rel(g_f, g_u.float()) < tol, _rel(g_f, g_u.float())
+    xf = x0.float().requires_grad_(True)
+    hn = xf if ln is None else F.layer_norm(xf, (C,), ln.weight.float(), ln.bias.float(), ln.eps)
+    a, gate = F.linear(hn, p1.weight.float(), p1.bias.float()).chunk(2, dim=-1)
+    y_r = F.linear(a * F.gelu(gate), p2.weight.float(), p2.bias.float()) + (xf if res else 0)
+    (g_r,) = torch.autograd.grad(y_r, xf, probe.float())
+    assert _rel(y_f, y_r.detach()) < (3e-3 if dtype == torch.float16 else 2.5e-2)
+    assert _rel(g_f, g_r) < (6e-3 if dtype == torch.float16 else 4e-2), _rel(g_f, g_r)
