@@ -24,6 +24,11 @@ namespace gvd {
 
 constexpr int kNV = 10;  // reduced values per (Gaussian, tile)
 
+#ifndef GVD_BWD_MERGE
+#define GVD_BWD_MERGE 0   // 1: two list entries in one serial step when no pixel is active in both.  Built, bit-identical, and SLOWER: k_render_bwd 103.3 -> 110.9 us
+                          // (profiles/r06_bwd_merge_ab.txt: the wave-uniform test and the per-lane selects cost more than the 9.5 % of steps they remove)
+#endif
+
 // experiments (tests/scripts/r5_bwd_trace.py): per-workgroup stamps of k_render_bwd -- s_memrealtime at entry / exit, XCC + HW ids,
 // the tile's walk length, and each wave's s_memtime cycles inside the walk.  Compiled only with -DGVD_RBWD_TRACE.
 #ifdef GVD_RBWD_TRACE
@@ -248,9 +253,10 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
         const float G##J = __expf(pw##J);                                                         \
         const float alpha##J = fminf(0.99f, con##J.w * G##J);                                     \
         const bool act##J = (ord##J < last_contributor) && !(pw##J > 0.0f) && !(alpha##J < 1.0f / 255.0f);  \
-        /* wave-level "any lane active": the AND of the three compares' lane masks */             \
-        const bool any##J = (__builtin_amdgcn_ballot_w64(ord##J < last_contributor) &             \
-                             __builtin_amdgcn_ballot_w64(!(pw##J > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha##J < 1.0f / 255.0f))) != 0ull;
+        /* the wave's active lanes: the AND of the three compares' lane masks */                  \
+        const unsigned long long msk##J = __builtin_amdgcn_ballot_w64(ord##J < last_contributor) &  \
+                             __builtin_amdgcn_ballot_w64(!(pw##J > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha##J < 1.0f / 255.0f)); \
+        const bool any##J = msk##J != 0ull;
 // The serial part and the entry's row of the strip.  Inactive lanes run with alpha = G = 0: then Tn == T, every accum_rec' equals the
 // value the next active entry would have formed (fmaf(1, acc, 0 * c) == acc bit-exactly) and q = w = 0.
 #define GVD_BWD_SERIAL(J, SL)                                                                     \
@@ -288,6 +294,55 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
                 row[lane] = make_float2(gm * d_, wgt);                                            \
                 if (lane == 0) row[64] = make_float2(__uint_as_float(SL), 0.f);                   \
                 rows++;                                                                           \
+            }                                                                                     \
+            lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
+        }
+// TWO ENTRIES IN ONE SERIAL STEP (round 6; GVD_BWD_MERGE).  When no pixel of the quadrant is active in BOTH entries of a pair, every lane
+// has at most one of them to walk: it picks its own (alpha, G, colour) and the pair costs one pass through the serial block instead of two.
+// Bit-identical to the two steps: an inactive step multiplies T by exactly 1 and leaves, through (last_alpha, last colour), the same
+// pending update of the accum_rec recurrences that the next walked entry applies -- here it simply stays pending one entry longer
+// (fmaf(1 - a, acc, a c) is evaluated once, on the same operands).  The lane writes its (q, w) into its entry's row of the strip and
+// zeros into the other one.  Measured on the C2 views: tests/scripts/lane_stats.py counts 9.5 % of the walked entries as removable this
+// way (windows of 2; 16 % for windows of 4, 22 % of 8 -- at the price of per-lane entry queues).
+#define GVD_BWD_MERGED(SL)                                                                        \
+        {                                                                                         \
+            const float4 c = s_cd[act0 ? (SL) : (SL) + 1u];                                       \
+            const float am = act0 ? alpha0 : (act1 ? alpha1 : 0.f);                               \
+            const float gm = act0 ? G0 : (act1 ? G1 : 0.f);                                       \
+            const float one_m_a = 1.f - am;                                                       \
+            const float rinv = GVD_BWD_RCP(one_m_a);                                              \
+            T = T * rinv;                                                                         \
+            const float wgt = am * T; (void)wgt; (void)gm;                                        \
+            const float oml = 1.f - last_alpha;                                                   \
+            acc0 = fmaf(oml, acc0, last_alpha * lc0);                                             \
+            acc1 = fmaf(oml, acc1, last_alpha * lc1);                                             \
+            acc2 = fmaf(oml, acc2, last_alpha * lc2);                                             \
+            if (DA) {                                                                             \
+                acc_d = fmaf(oml, acc_d, last_alpha * last_depth);                                \
+                acc_a = fmaf(oml, acc_a, last_alpha);                                             \
+            }                                                                                     \
+            if (!LIGHT) {                                                                         \
+                float d_ = (c.x - acc0) * dLp0;                                                   \
+                d_ = fmaf(c.y - acc1, dLp1, d_);                                                  \
+                d_ = fmaf(c.z - acc2, dLp2, d_);                                                  \
+                if (DA) {                                                                         \
+                    d_ = fmaf(c.w - acc_d, dLd, d_);                                              \
+                    d_ = fmaf(1.f - acc_a, dLa, d_);                                              \
+                }                                                                                 \
+                d_ *= T;                                                                          \
+                if (BG) {                                                                         \
+                    float qb = nTf * rinv;                                                        \
+                    qb = fmaf(fmaf(-one_m_a, qb, nTf), rinv, qb);                                 \
+                    d_ = fmaf(qb, bg_dot, d_);                                                    \
+                }                                                                                 \
+                const uint32_t mine = act0 ? rows : rows + 1u, other = act0 ? rows + 1u : rows;   \
+                s_qw[mine][lane] = make_float2(gm * d_, wgt);                                     \
+                s_qw[other][lane] = make_float2(0.f, 0.f);                                        \
+                if (lane == 0) {                                                                  \
+                    s_qw[rows][64] = make_float2(__uint_as_float(SL), 0.f);                       \
+                    s_qw[rows + 1u][64] = make_float2(__uint_as_float((SL) + 1u), 0.f);           \
+                }                                                                                 \
+                rows += 2;                                                                        \
             }                                                                                     \
             lc0 = c.x; lc1 = c.y; lc2 = c.z; last_depth = c.w; last_alpha = am;                   \
         }
@@ -343,8 +398,14 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
             for (; j + 2 <= n; j += 2) {
                 GVD_BWD_GEOM(0, j)
                 GVD_BWD_GEOM(1, j + 1)
-                if (any0) GVD_BWD_SERIAL(0, j)
-                if (any1) GVD_BWD_SERIAL(1, j + 1)
+#if GVD_BWD_MERGE
+                if (any0 && any1 && !(msk0 & msk1)) GVD_BWD_MERGED(j)
+                else
+#endif
+                {
+                    if (any0) GVD_BWD_SERIAL(0, j)
+                    if (any1) GVD_BWD_SERIAL(1, j + 1)
+                }
                 if (rows >= (uint32_t)kRows - 1u) { flush(rows); rows = 0; }
             }
             if (j < n) {
@@ -356,6 +417,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a)
         if (has_bg) walk(std::true_type{});
         else walk(std::false_type{});
 #undef GVD_BWD_SERIAL
+#undef GVD_BWD_MERGED
 #undef GVD_BWD_GEOM
 #undef GVD_BWD_RCP
 #ifdef GVD_RBWD_TRACE

@@ -33,6 +33,8 @@ steps = {16: 0, 8: 0, 4: 0, 2: 0}
 rect84 = rect48 = bbox4 = bbox4q = 0
 steps_8x8 = steps_pair84 = steps_pair48 = steps_quad44 = 0   # wave steps: one list per quadrant / max over its 2 halves / its 4 blocks
 fwd_live = 0
+comp_steps = {2: 0, 4: 0, 8: 0, 16: 0}   # round 6: wave steps if every pixel lane walked ITS OWN active entries of a window of k kept entries
+chain_bound = 0                          # ... and of the whole list (the busiest pixel's chain: the floor of any lane-compacting scheme)
 yy, xx = torch.meshgrid(torch.arange(16, device=dev), torch.arange(16, device=dev), indexing="ij")
 for tile in range(gx * gy):
     r0, r1 = ranges[tile]
@@ -64,6 +66,17 @@ for tile in range(gx * gy):
     h48 = A.reshape(n, 2, 8, 2, 2, 4).any(dim=5).any(dim=2).sum(dim=0)                   # [qy, qx, half]: 4 wide x 8 high halves
     b44 = A.reshape(n, 2, 2, 4, 2, 2, 4).any(dim=6).any(dim=3).sum(dim=0)                # [qy, sy, qx, sx]
     steps_8x8 += int(q88.sum())
+    Aq = A.reshape(n, 2, 8, 2, 8).permute(1, 3, 0, 2, 4).reshape(4, n, 64)                # [quadrant, entry, pixel]
+    for qd in range(4):
+        Ak = Aq[qd][Aq[qd].any(dim=1)]                                                    # the entries the quadrant's wave walks
+        nk = Ak.shape[0]
+        if nk == 0:
+            continue
+        chain_bound += int(Ak.sum(dim=0).max())
+        for kk in comp_steps:
+            pad = (-nk) % kk
+            Ap = torch.cat([Ak, torch.zeros(pad, 64, dtype=Ak.dtype, device=dev)]) if pad else Ak
+            comp_steps[kk] += int(Ap.reshape(-1, kk, 64).sum(dim=1).max(dim=1).values.sum())
     steps_pair84 += int(h84.max(dim=1).values.sum())
     steps_pair48 += int(h48.max(dim=2).values.sum())
     steps_quad44 += int(b44.permute(0, 2, 1, 3).reshape(2, 2, 4).max(dim=2).values.sum())
@@ -92,5 +105,8 @@ print(f"R={R}  list pairs (R*256)={tot_pairs/1e6:.1f} M   active pairs={act_pair
 print(f"  perfect 8x4: {rect84/1e6:.3f} M  4x8: {rect48/1e6:.3f} M   bbox 4x4: {bbox4/1e6:.3f} M   bbox & exact-8x8: {bbox4q/1e6:.3f} M")
 print(f"  WAVE steps with perfect culls: one list per 8x8 quadrant {steps_8x8/1e6:.3f} M | two 8x4 halves, max {steps_pair84/1e6:.3f} M | "
       f"two 4x8 halves, max {steps_pair48/1e6:.3f} M | four 4x4 blocks, max {steps_quad44/1e6:.3f} M")
+print("  serial steps of a quadrant wave if each pixel lane walked only ITS active entries inside windows of k kept entries (max over the 64 lanes per window): "
+      + " | ".join(f"k={kk}: {v/1e6:.3f} M ({v/steps_8x8:.3f} of the {steps_8x8/1e6:.3f} M entry steps)" for kk, v in comp_steps.items())
+      + f" | whole list (busiest pixel's chain): {chain_bound/1e6:.3f} M ({chain_bound/steps_8x8:.3f})")
 for bs, s in steps.items():
     print(f"  perfect cull at {bs}x{bs}: {s/1e6:.3f} M (entry, block) steps = {s*bs*bs/1e6:.1f} M lane slots, useful {act_pairs/(s*bs*bs):.3f}")
