@@ -37,6 +37,15 @@ for _p in (ROOT, os.path.join(ROOT, "guidedvd-3dgs_amd")):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one -> (path, 'profiles/<name>'); the line quotes which file it read."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not c:
+        return None, None
+    return c[-1], "profiles/" + os.path.basename(c[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +386,35 @@ def raster_run(args, dev, rank, world):
                 except Exception:
                     pass
 
+        # Two more HBM figures next to the dominant kernel's (verdict r5 item 7c): the WHOLE step against SURVEY 8(d)'s byte model
+        # (SURVEY.md:438, with the measured R), and k_gather_bwd -- the one kernel of the step that is bandwidth-bound -- against its own bytes.
+        roofline_step = roofline_gather = None
+        if kern:
+            Msh = (args.sh_degree + 1) ** 2 if args.sh_degree < 3 else 16
+            Msh = 16   # the SH tensor is stored (and its gradient written) at 16 coefficients whatever the active degree
+            ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+            bit = max(1, (ntiles - 1).bit_length())
+            fwd_b = P * (12 + 12 + 16 + 4 + 12 * Msh) + P * 79 + P * 8 + R_mean * 12 + R_mean * 24 * ((32 + bit + 7) // 8) + R_mean * 8 + R_mean * 28 + HW * 24
+            bwd_b = R_mean * (28 + 16) + HW * (20 + 4 + 4) + P * (12 + 4 + 16 + 4 + 12) + P * (79 + 12 * Msh + 12 * Msh + 12 + 12 + 16 + 24)
+            step_s = elapsed / args.steps
+            roofline_step = dict(bound="hbm", what="whole step (all launches, forward + backward) against SURVEY.md section 8(d)'s byte model with the measured R; "
+                                 "the model prices the reference's global radix sort (24 B x 6 passes per instance) that this design does in LDS",
+                                 achieved=round((fwd_b + bwd_b) / step_s / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round((fwd_b + bwd_b) / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                 alg_bytes_fwd=int(fwd_b), alg_bytes_bwd=int(bwd_b), ms_per_step=round(1e3 * step_s, 4))
+            if "gather_bwd" in kern:
+                gb = P * (12 + 4 + 16 + 4 + 12) + P * (79 + 12 * Msh + 12 * Msh + 12 + 12 + 16 + 24)
+                tr = None
+                try:
+                    tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("gather_bwd")
+                except Exception:
+                    pass
+                ga = gb / (kern["gather_bwd"]["avg_us"] * 1e-6) / 1e9
+                roofline_gather = dict(bound="hbm", kernel="gather_bwd", achieved=round(ga, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ga / HBM_PEAK_GBS, 4),
+                                       alg_bytes=int(gb), avg_us=round(kern["gather_bwd"]["avg_us"], 2), traffic=tr,
+                                       traffic_from=None if tr is None else "profiles/pmc_traffic.json (committed counter pass; NOT observed in this run)",
+                                       what="per Gaussian: the 48 B of summed pixel-side gradients in, geometry state 79 B + SH 192 B in, dSH 192 B + 64 B of parameter gradients out "
+                                            "(SURVEY 8(d), rows A14 / A15); the per-(instance, quadrant) sub-records it also reads are this design's own traffic and count only in `traffic`")
+
         # SURVEY 8(d) asks for two more points on the same scene: SH degree 0, and all three pixel gradients non-zero
         # (colour + depth + alpha).  Short side runs (not the headline value), single rank.
         variants = None
@@ -443,6 +481,8 @@ def raster_run(args, dev, rank, world):
                         "`sustained` = the same loop over a >= 1 s window, the steadier figure",
             "two_view_step": two_view,
             "roofline": roofline,
+            "roofline_step": roofline_step,
+            "roofline_gather_bwd": roofline_gather,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "variants": variants,
             "cpu_baseline": cpu_baseline,
@@ -816,7 +856,11 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         a.record()
         o = orig_conv(xx, wpk, Cout, mode, N, H, W, Cin, **kw)
         b.record()
-        ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * (3 if mode == mconv.TEMPORAL else 9), ("conv", mode, N, H, W, Cin, Cout, int(kw.get("upsample", 0) or 0))))
+        # nearest-x2 + 3x3 runs as four 2x2 phase convolutions (mode UP2): 4 tap evaluations per OUTPUT pixel are executed where the reference's
+        # operator (upsample, then 3x3) counts 9 -- `frac` is on executed flops, the reference-operator count rides along as e[4]
+        taps = 3 if mode == mconv.TEMPORAL else (4 if mode == mconv.UP2 else 9)
+        ev_conv.append((a, b, 2.0 * N * H * W * Cin * Cout * taps, ("conv", mode, N, H, W, Cin, Cout, int(kw.get("upsample", 0) or 0)),
+                        2.0 * N * H * W * Cin * Cout * (3 if mode == mconv.TEMPORAL else 9)))
         return o
 
     def timed_split(xx, wpk, Cout, mode, N, H, W, Cin, ksplit, **kw):      # split-K slices + their sum: one convolution
@@ -876,6 +920,12 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
     mconv._split_conv, mconv._sheet_conv = timed_split, timed_sheet
     xi = x
+    if n_inst:   # one untimed EAGER step first: the graph-replayed timed region never asked the caching allocator for the eager path's
+        #          buffers, and the first instrumented launch of a shape then timed a hipMalloc of its ~1 GB output inside its event pair
+        #          (the 6149 us / 157 TFLOP/s 230400 x 4096 x 512 row of profiles/r05_ddim_by_shape.json: verdict r5 item 7a)
+        one(warm + steps + n_inst + 1, x)   # (graph_apply is already off; its event pairs are dropped below)
+        torch.cuda.synchronize()
+        del ev_attn[:], ev_conv[:], ev_gemm[:]
     smi = _SmiSampler(dev.index or 0) if (n_inst and rank == 0) else None   # (outside the headline region: a host thread polling rocm-smi)
     t1 = time.perf_counter()
     try:
@@ -926,9 +976,15 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         if not ms:
             return None
         ach = fl / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "launches": len(evs), "ms_per_step": round(ms / n_inst, 2),
-                "alg_tflop_per_step": round(fl / n_inst / 1e12, 2)}
+        r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
+             "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "launches": len(evs), "ms_per_step": round(ms / n_inst, 2),
+             "alg_tflop_per_step": round(fl / n_inst / 1e12, 2)}
+        ref_fl = sum((e[4] if len(e) > 4 and isinstance(e[3], tuple) else e[2]) for e in evs)
+        if ref_fl != fl:   # the phase convolutions execute 16 of the reference operator's 36 taps per input pixel
+            r["flops"] = "executed (nearest-x2 + 3x3 as four 2x2 phase convolutions: 4 taps per output pixel)"
+            r["reference_operator_tflop_per_step"] = round(ref_fl / n_inst / 1e12, 2)
+            r["achieved_on_reference_operator_flops"] = round(ref_fl / (ms * 1e-3) / 1e12, 2)
+        return r
 
     r_conv = roof(ev_conv, "k_conv_mfma (3x3 / upsample / temporal implicit-GEMM convolutions, fused GroupNorm+SiLU prologue)")
     r_attn = roof(ev_attn, "k_attn_fwd (all spatial / cross / temporal attention launches)")
@@ -951,7 +1007,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     # in this run, and only quoted at the resolution those passes ran at
     if (args.ddim_height, args.ddim_width) == (576, 1024) and not guided:
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_mfma_pmc.json")) as fh:
+            pmc_path, pmc_name = newest_profile("mfma_pmc.json")
+            with open(pmc_path) as fh:
                 pmc_all = json.load(fh)
             for r, prefix, what in ((r_attn, "attn i4ELi2", "level-0 self-attention forward, 25 frames x 5 heads x 9216 tokens (0.59 GB of q, k, v, out)"),
                                     (r_gemm, "gemm L0 ff-in", "level-0 feed-forward in, 230400 x 2560 x 320 with LayerNorm fold + GEGLU (0.15 GB in, 0.59 GB out)"),
@@ -959,10 +1016,10 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
                 row = next((v for k, v in pmc_all.items() if k.startswith(prefix)), None)
                 if r and row and row.get("launches"):
                     r["traffic"] = int(row["traffic_bytes"] / row["launches"])
-                    r["traffic_of"] = (what + "; profiles/r04_mfma_pmc.json, NOT observed in this run.  FETCH_SIZE doubled (the guide's gfx950 correction for "
+                    r["traffic_of"] = (what + "; " + pmc_name + ", NOT observed in this run.  FETCH_SIZE doubled (the guide's gfx950 correction for "
                                        "16-byte-per-lane reads), WRITE_SIZE raw -- uncalibrated per the guide, and on these kernels' 16-byte stores it reports about a "
                                        "third of the known output bytes (attention out 147 MB -> 51 MB, GEMM out 590 -> 197, convolution out 295 -> 117)")
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, TypeError):
             pass
     # Bandwidth-bound Linear shapes (arithmetic intensity under the 2.5 PFLOP/s : 8 TB/s ridge of 312 flop/byte) get an HBM roofline
     # object of their own -- the MFMA fraction of such a launch says nothing: algorithmic bytes (X, W, Y and the residual, 16 bit) over
@@ -985,11 +1042,11 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         shp, n_, ms_, byt = best
         ach = byt * n_ / (ms_ * 1e-3) / 1e9
         traffic, t_from = None, None
-        pmc = os.path.join(ROOT, "profiles", "r04_mfma_pmc.json")
-        if os.path.exists(pmc) and shp[1:5] == (1, 230400, 320, 320) and shp[7]:
+        pmc, pmc_name = newest_profile("mfma_pmc.json")
+        if pmc and shp[1:5] == (1, 230400, 320, 320) and shp[7]:
             try:
                 traffic = json.load(open(pmc)).get("gemm L0 out-proj 230400x320x320 +residual", {}).get("traffic_bytes")
-                t_from = "profiles/r04_mfma_pmc.json (FETCH_SIZE x 2 + WRITE_SIZE of a separate rocprofv3 --pmc pass of this shape; NOT observed in this run)"
+                t_from = pmc_name + " (FETCH_SIZE x 2 + WRITE_SIZE of a separate rocprofv3 --pmc pass of this shape; NOT observed in this run)"
             except Exception:
                 traffic = None
         r_hbm = {"bound": "hbm", "kernel": f"k_gemm_nt {shp[2]} x {shp[3]} x {shp[4]}" + (" + residual" if shp[7] else ""), "achieved": round(ach, 1),
@@ -1003,14 +1060,14 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         byt = sum(e[4] for e in ta)
         ach = byt / (ms_ * 1e-3) / 1e9
         traffic, t_from = None, None
-        pmc = os.path.join(ROOT, "profiles", "r04_mfma_pmc.json")
-        if os.path.exists(pmc) and (args.ddim_height, args.ddim_width, T) == (576, 1024, 25):
+        pmc, pmc_name = newest_profile("mfma_pmc.json")
+        if pmc and (args.ddim_height, args.ddim_width, T) == (576, 1024, 25):
             try:
                 pj = json.load(open(pmc))
                 key = [k_ for k_ in pj if k_.startswith("attn short") or k_.startswith("attn i1ELi1E")]
                 if key:
                     traffic = pj[key[0]].get("traffic_bytes")
-                    t_from = "profiles/r04_mfma_pmc.json: per LAUNCH of the level-0 shape (25 frames x 9216 pixels x 320 channels; 590 MB algorithmic), separate rocprofv3 --pmc passes; NOT observed in this run"
+                    t_from = pmc_name + ": per LAUNCH of the level-0 shape (25 frames x 9216 pixels x 320 channels; 590 MB algorithmic), separate rocprofv3 --pmc passes; NOT observed in this run"
             except Exception:
                 traffic = None
         r_hbm_attn = {"bound": "hbm", "kernel": "k_attn_short_fwd (temporal self-attention: a wave per (pixel, head), the frames of a pixel read in place)", "achieved": round(ach, 1),
@@ -1136,7 +1193,9 @@ def ddim_cpu_leg(unet, T, unet_tflop, guided):
     fwd_equiv = 2.0 if not guided else 4.0  # guided: 2 fwd + 2 dgrad (VAE part not included in this estimate)
     return dict(value=round(tfps / (fwd_equiv * unet_tflop), 6), unit="steps/s", cores=ncores, host_cores=host_cores, kind="port",
                 sample=f"one fp32 U-Net forward, T={T}, latent {hs}x{ws}, 333 context tokens: {tf_small:.3f} TFLOP in {el:.1f} s "
-                       f"= {tfps:.3f} TFLOP/s on {ncores} threads; value = that rate / ({fwd_equiv:.0f} x {unet_tflop} TFLOP per step)")
+                       f"= {tfps:.3f} TFLOP/s on {ncores} threads; value = that rate / ({fwd_equiv:.0f} x {unet_tflop} TFLOP per step).  "
+                       f"Core counts of the two legs of this line: this leg {ncores} threads (the operator graph measured SLOWER on all {host_cores}: 468 s for the "
+                       f"25-frame forward), the raster leg all {host_cores} (its OpenMP oracle scales)")
 
 
 def cpu_leg(sc, args, np):
@@ -1159,7 +1218,8 @@ def cpu_leg(sc, args, np):
         if el > args.cpu_seconds or n >= 24:
             break
     return dict(value=round(n / el, 4), unit="iters/s", cores=ncores, host_cores=ncores, kind="port",
-                sample=f"{n} fwd+bwd iterations of the same workload (OpenMP, {ncores} threads, incl. Python/ctypes marshalling)")
+                sample=f"{n} fwd+bwd iterations of the same workload (OpenMP, {ncores} threads, incl. Python/ctypes marshalling).  Core counts of the two legs "
+                       f"of the default line: this leg all {ncores} host threads, the diffusion leg min({ncores}, 32) (its torch-CPU operator graph is slower beyond that)")
 
 
 if __name__ == "__main__":
