@@ -18,6 +18,18 @@
 #include "raster_kernels.h"
 #include "raster_layout.h"
 
+
+// spin-wait hint of the host's architecture (the ticket wait below): x86 `pause`, AArch64 `yield`, a compiler barrier elsewhere
+static inline void gvd_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -143,18 +155,25 @@ void spec_update(int P, int W, int H, uint32_t R, uint32_t max_list)
 }
 // Capacity whose binning layout occupies exactly `bytes` (bin_bytes is strictly increasing in the capacity: the last
 // sub-array, the 48-byte partial records, ends the chunk unrounded).  Returns false if no capacity matches.
-bool capacity_of_bytes(size_t bytes, uint32_t* cap_out)
+bool capacity_of_bytes(size_t bytes, uint32_t* cap_out, bool* compact_out = nullptr)
 {
-    uint32_t lo = 0, hi = 0xfffffff0u;
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (gvd::make_layout(0, 16, 16, mid).bin_bytes < bytes) lo = mid + 1; else hi = mid;
+    // two forms: the full layout, and the compact one of a forward run under gvd_raster_expect_backward(0) (no partial records; full
+    // sizes are multiples of 64, compact ones 2 mod 4: the size alone names the form).  keys / point_list / bucket / qmask sit at the same
+    // offsets in both.
+    for (int compact = 0; compact < 2; ++compact) {
+        uint32_t lo = 0, hi = 0xfffffff0u;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (gvd::make_layout(0, 16, 16, mid, !compact).bin_bytes < bytes) lo = mid + 1; else hi = mid;
+        }
+        if (gvd::make_layout(0, 16, 16, lo, !compact).bin_bytes != bytes) continue;
+        // capacities 0 and 1 share one layout (every sub-array holds at least one element): report 1, or a chunk that holds exactly one
+        // instance would come back as "smaller than num_rendered requires" (found by tests/scripts/r5_raster_stress.py: P = 1, R = 1)
+        *cap_out = lo ? lo : 1u;
+        if (compact_out) *compact_out = compact != 0;
+        return true;
     }
-    if (gvd::make_layout(0, 16, 16, lo).bin_bytes != bytes) return false;
-    // capacities 0 and 1 share one layout (every sub-array holds at least one element): report 1, or a chunk that holds exactly one
-    // instance would come back as "smaller than num_rendered requires" (found by tests/scripts/r5_raster_stress.py: P = 1, R = 1)
-    *cap_out = lo ? lo : 1u;
-    return true;
+    return false;
 }
 inline int sort_class_of(uint32_t max_list) { return max_list > 16384 ? 2 : (max_list > 2048 ? 1 : 0); }
 
@@ -307,6 +326,7 @@ const char* gvd_version(void) { return "gvd-raster 0.1 (gfx950)"; }
 size_t gvd_raster_geometry_bytes(int P, int width, int height) { return gvd::make_layout(P, width, height, 0).geom_bytes; }
 size_t gvd_raster_image_bytes(int width, int height) { return gvd::make_layout(0, width, height, 0).img_bytes; }
 size_t gvd_raster_binning_bytes(uint32_t num_rendered) { return gvd::make_layout(0, 16, 16, num_rendered).bin_bytes; }
+size_t gvd_raster_binning_bytes_no_backward(uint32_t num_rendered) { return gvd::make_layout(0, 16, 16, num_rendered, false).bin_bytes; }
 
 void gvd_raster_chunk_layout(int P, int width, int height, uint32_t num_rendered, gvd_chunk_layout* o)
 {
@@ -363,7 +383,7 @@ int gvd_raster_forward(
         {
             const uint32_t cap = hint.r_max + hint.r_max / 8 + 4096;
             const int class_spec = sort_class_of(hint.list_max + hint.list_max / 4);
-            gvd::Layout Ls = gvd::make_layout(P, width, height, cap);
+            gvd::Layout Ls = gvd::make_layout(P, width, height, cap, t_expect_backward != 0);
             char* bin_s = binning_alloc(binning_user, Ls.bin_bytes);
             if (!bin_s) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
             bin_s = align_up(bin_s);
@@ -380,7 +400,7 @@ int gvd_raster_forward(
             {
                 unsigned long long spins = 0;
                 while (mirror[2] != ticket) {
-                    __builtin_ia32_pause();
+                    gvd_cpu_relax();
                     if ((++spins & 0xfffffull) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {   // ~every few ms: the stream died or drained
                         if (mirror[2] == ticket) break;
                         HIP_TRY(hipStreamSynchronize(stream));
@@ -404,7 +424,7 @@ int gvd_raster_forward(
     const uint32_t max_list = mirror[1];
     if (R > 0x7fffffffu) return fail(GVD_ERR_OVERFLOW, "num_rendered exceeds int32");
     spec_update(P, width, height, R, max_list);
-    L = gvd::make_layout(P, width, height, R);
+    L = gvd::make_layout(P, width, height, R, t_expect_backward != 0);   // (no backward expected: no partial records in the chunk)
     char* bin = binning_alloc(binning_user, L.bin_bytes);
     if (!bin) return fail(GVD_ERR_ALLOC, "binning allocator returned NULL");
     bin = align_up(bin);
@@ -471,7 +491,9 @@ int gvd_raster_backward_conf(
     // layout capacity of this chunk: num_rendered itself, unless the forward laid it out speculatively -- then its size says
     uint32_t cap = (uint32_t)R;
     if (binning_chunk_bytes) {
-        if (!capacity_of_bytes(binning_chunk_bytes, &cap)) return fail(GVD_ERR_INVALID, "binning_chunk_bytes is not the size of a binning chunk");
+        bool compact = false;
+        if (!capacity_of_bytes(binning_chunk_bytes, &cap, &compact)) return fail(GVD_ERR_INVALID, "binning_chunk_bytes is not the size of a binning chunk");
+        if (compact) return fail(GVD_ERR_INVALID, "this binning chunk was laid out without the backward's partial records: its forward ran under gvd_raster_expect_backward(0)");
         if (cap < (uint32_t)R) return fail(GVD_ERR_INVALID, "binning chunk is smaller than num_rendered requires");
     }
     const Layout L = make_layout(P, width, height, cap);

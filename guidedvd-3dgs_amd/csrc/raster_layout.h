@@ -36,7 +36,12 @@ inline size_t carve(size_t& cur, size_t bytes)
     return off;
 }
 
-inline Layout make_layout(int P, int W, int H, uint32_t R)
+// `with_partials` = false: the binning chunk of a forward that no backward will follow (gvd_raster_expect_backward(0), allocator-callback
+// entry point only): the flag words and the 4 x 48-byte sub-records per instance -- 196 of the chunk's 224 bytes per instance, times the
+// speculative capacity's 12.5 % + 4096 of headroom -- are not laid out at all (advisor finding, round 5: ~2.2 GB at 10 M instances held
+// per render in flight on a GPU shared with the diffusion model).  Such a chunk's size is not the size of any full layout (see below), so a
+// backward handed it is refused by its size check instead of reading past the end.
+inline Layout make_layout(int P, int W, int H, uint32_t R, bool with_partials = true)
 {
     Layout L{};
     L.P = P; L.W = W; L.H = H;
@@ -77,9 +82,14 @@ inline Layout make_layout(int P, int W, int H, uint32_t R)
     L.point_list = carve(c, Rz * 4);
     L.bucket = carve(c, Rz * 8);
     L.qmask = carve(c, Rz * 4);                           // 4 byte planes (quadrant) x list entry: the forward's conservative cull bit
-    L.pflags = carve(c, Rz * 4);                          // byte q: quadrant q of the instance wrote its sub-record
-    L.partials = carve(c, Rz * 4 * kPartialStride * 4);
-    L.bin_bytes = c + kAlign;
+    if (with_partials) {
+        L.pflags = carve(c, Rz * 4);                      // byte q: quadrant q of the instance wrote its sub-record
+        L.partials = carve(c, Rz * 4 * kPartialStride * 4);
+        L.bin_bytes = c + kAlign;
+    } else {
+        L.pflags = L.partials = 0;                        // never dereferenced: the forward passes pflags = nullptr to k_scatter
+        L.bin_bytes = c + kAlign + 2;                     // + 2: full layouts are multiples of 64 bytes, these are 2 mod 4 -- the size alone names the form
+    }
     return L;
 }
 

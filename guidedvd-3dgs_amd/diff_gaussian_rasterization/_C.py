@@ -63,6 +63,8 @@ def lib():
         L.gvd_raster_binning_capacity.argtypes = [ctypes.c_size_t]
         L.gvd_raster_set_speculation.argtypes = [_I]
         L.gvd_raster_expect_backward.argtypes = [_I]
+        L.gvd_raster_binning_bytes_no_backward.restype = ctypes.c_size_t
+        L.gvd_raster_binning_bytes_no_backward.argtypes = [ctypes.c_uint32]
         L.gvd_raster_set_backward_split.argtypes = [_I]
         # this binding hands the binning chunk's size to backward, so the forward may lay it out speculatively (gvd_raster.h)
         L.gvd_raster_set_speculation(1)
@@ -396,6 +398,8 @@ def chunk_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):
     cap = L.gvd_raster_binning_capacity(binningBuffer.numel()) if binningBuffer.numel() else int(R)
     if cap == 0xffffffff:
         raise RuntimeError("binningBuffer does not have the size of a binning chunk")
+    if cap < int(R):
+        raise RuntimeError("binningBuffer is smaller than num_rendered requires")
     L.gvd_raster_chunk_layout(P, W, H, cap, ctypes.byref(lay))
 
     def view(buf, off, nbytes, dtype):

@@ -48,20 +48,28 @@ class GraphedApplyModel:
     def __init__(self, model, warmup=2):
         self.model, self.warmup = model, warmup
         self._graphs = {}
-        self._params = None      # (parameter, version at capture): a graph holds the ADDRESSES of the packed weight images of its capture
+        self._state = None       # what the captures saw: (id, data_ptr, version) of every parameter and buffer of the model
+
+    def _model_state(self):
+        """A graph holds the ADDRESSES of the packed weight images of its capture, and those are rebuilt on the next eager call when a
+        parameter changes.  Three things move them without telling anyone: an in-place checkpoint load (a version bump per parameter), a
+        `.data` re-assignment (`module.half()`, `.to()`, a re-layout: new data_ptr, version may not move), and a replaced Parameter / buffer
+        object (new id).  All three are in this signature, for parameters AND buffers; ~1 400 attribute reads per call, on a host that runs
+        ahead of the replayed graph anyway."""
+        m = self.model
+        if not hasattr(m, "parameters"):
+            return ()
+        ts = list(m.parameters()) + (list(m.buffers()) if hasattr(m, "buffers") else [])
+        return tuple((id(t), t.data_ptr(), t._version) for t in ts)
 
     def _weights_changed(self):
-        """A checkpoint loaded in place after a capture (load_state_dict: a version bump per parameter) re-packs the weight images at new
-        addresses on the next eager call -- a captured graph would keep replaying the old (freed) ones.  ~700 attribute reads per call."""
-        if self._params is None:
-            return False
-        return any(p._version != v for p, v in self._params)
+        return self._state is not None and self._state != self._model_state()
 
     @torch.no_grad()
     def apply(self, x, t, cond, **kw):
         if self._weights_changed():
             self._graphs.clear()
-            self._params = None
+            self._state = None
         key = (_sig(x), _sig(t), _sig(cond), _sig(kw))
         ent = self._graphs.get(key)
         if ent is None:
@@ -86,7 +94,5 @@ class GraphedApplyModel:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.model.apply_model(sx, st, sc, **skw)
-        if self._params is None:
-            ps = list(self.model.parameters()) if hasattr(self.model, "parameters") else []
-            self._params = [(p, p._version) for p in ps]
+        self._state = self._model_state()   # (a change between two captures would have cleared the cache in apply() first)
         return sx, st, sc, skw, graph, out

@@ -225,6 +225,17 @@ class DDIMSampler(object):
                              temperature=float(temperature))
 
 
+def guidance_gradient_scale(G):
+    """The power of two (a 0-d fp32 tensor on G's device, no host sync) that brings G's largest entry into [2^-5, 2^-4).  Formed in fp32
+    whatever G's dtype (1e-30 and 2^95 do not exist in fp16), held to fp32's exponents, and exactly 1 when G is all zero
+    (no valid mask pixel: rho = 0 in the update, as in the reference) or not finite (left to surface where the reference would show it)."""
+    gmax = G.detach().float().abs().amax()
+    ok = torch.isfinite(gmax) & (gmax > 0)
+    expo = -5.0 - torch.floor(torch.log2(torch.where(ok, gmax, torch.ones_like(gmax))))
+    lim = 126.0   # (the product is formed in fp32 by the caller, then cast back: a 16-bit G may need more than 2^15)
+    return torch.where(ok, torch.exp2(expo.clamp(-lim, lim)), torch.ones_like(gmax))
+
+
 class DDIMSamplerGuidance(DDIMSampler):
     """ddim_guidance.py: the guided step differentiates pred_x0 w.r.t. x_t through BOTH U-Net evaluations
     and back-propagates the per-frame decoder-space loss gradient (Algorithm 1, L11-L13 of the paper)."""
@@ -241,24 +252,28 @@ class DDIMSamplerGuidance(DDIMSampler):
     scale_guidance_gradient = True
 
     def _decode_group(self, n_frames, h, w, device):
-        """Chosen ONCE per (frames, latent size, device) and kept on the sampler: the grouping decides launch shapes and the order
-        of the GroupNorm statistics' fp64 atomics, so it must not follow the allocator's state from step to step (same seed, same
-        grouping, same result), and a driver memory query per guided step is a host stall.  The 4 GB per frame at 72x128 latents
-        are the saved decoder activations of the ViewCrafter KL-VAE (ch 128, ch_mult [1, 2, 4, 4], 2 blocks per level, fp16,
-        measured); they scale with the pixel count."""
+        """Frames per decoder pass.  The grouping decides launch shapes and the summation order of the decoder's backward, so it should not
+        follow the allocator's state from step to step.  Two cases: when the fixed budget cap (`decode_budget_gb`) decides, the group is
+        chosen ONCE per (frames, latent size, device) and kept -- same seed, same grouping, same result, no memory query per step.  When
+        the device's FREE memory decided (a co-resident 3DGS side: BASELINE configs[3]), the first choice is kept too, but every step asks
+        the driver again (one hipMemGetInfo, ~20 us) and the group may only SHRINK -- when the other tenant has grown (densification) --
+        never grow back: run-to-run reproducible as long as memory pressure does not rise mid-run, and safe when it does (advisor
+        findings, rounds 4 and 5).  `sampler.decode_group = n` pins it outright.  The 4 GB per frame at 72x128 latents are the saved decoder
+        activations of the ViewCrafter KL-VAE (ch 128, ch_mult [1, 2, 4, 4], 2 blocks per level, fp16, measured); they scale with the
+        pixel count."""
         fixed = getattr(self, "decode_group", None)
         if fixed:
             return max(1, int(fixed))
         key = (int(n_frames), int(h), int(w), str(device), float(self.decode_budget_gb))
         cache = self.__dict__.setdefault("_decode_group_cache", {})
-        if key not in cache:
-            group, by_cap = self._choose_decode_group(n_frames, h, w, device)
-            if not by_cap:
-                # free memory, not the fixed cap, decided: that figure goes stale when the 3DGS side grows (densification) or
-                # another allocation lands -- do not keep it (advisor finding, round 4); the next step asks again
-                return group
-            cache[key] = group
-        return cache[key]
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = self._choose_decode_group(n_frames, h, w, device)
+        elif not ent[1]:
+            again = self._choose_decode_group(n_frames, h, w, device)
+            if again[0] < ent[0]:
+                ent = cache[key] = (again[0], False)
+        return ent[0]
 
     def _choose_decode_group(self, n_frames, h, w, device):
         """(frames per decoder pass, True when the fixed budget cap -- not the device's free memory -- set it)."""
@@ -377,8 +392,7 @@ class DDIMSamplerGuidance(DDIMSampler):
                 # rho = rms(correction) s 0.2 w / rms(gx): invariant under any rescaling of G.  So G is scaled by a power of two
                 # (exact in binary floating point) to a largest entry in [2^-5, 2^-4) -- chosen on the device, no host sync; the
                 # same number on every rank (G is the gathered tensor).
-                gmax = G.abs().amax().clamp_min(1e-30)
-                G = G * torch.exp2(-4.0 - torch.floor(torch.log2(gmax)) - 1.0)
+                G = (G.float() * guidance_gradient_scale(G)).to(G.dtype)
             if plan is None:
                 (gx,) = torch.autograd.grad(pred_x0, x, grad_outputs=G)
             else:

@@ -126,6 +126,23 @@ def test_binning_capacity_inverts_binning_bytes_and_never_reports_less_than_it_h
         assert L.gvd_raster_binning_capacity(b + 4) == 0xffffffff
 
 
+def test_no_backward_chunk_is_an_eighth_of_the_size_and_never_passes_for_a_full_one(capi):
+    """The binning chunk of a forward run under gvd_raster_expect_backward(0) carries no partial records (advisor finding, round 5: 224 bytes
+    per instance held per render in flight).  Its size is never the size of a full layout -- the backward tells the two apart by size alone
+    and refuses the compact one."""
+    L = capi.lib()
+    for r in list(range(0, 70)) + [100, 1000, 4095, 4096, 4097, 436438, 436439, 5_000_000, 10_000_000]:
+        full, compact = L.gvd_raster_binning_bytes(r), L.gvd_raster_binning_bytes_no_backward(r)
+        assert compact < full
+        assert full % 64 == 0 and compact % 4 == 2        # the size alone names the form
+        assert L.gvd_raster_binning_capacity(compact) == max(r, 1)   # (keys / point_list / bucket / qmask sit at the same offsets in both forms)
+        if r >= 1000:
+            assert compact < 0.14 * full, (r, compact, full)
+    assert L.gvd_raster_binning_bytes_no_backward(10_000_000) < 300e6 < 2.2e9 < L.gvd_raster_binning_bytes(10_000_000)
+    sizes = [L.gvd_raster_binning_bytes_no_backward(r) for r in range(1, 3000)]
+    assert all(b > a for a, b in zip(sizes, sizes[1:]))   # strictly increasing: the size names the capacity
+
+
 def test_compiled_operator_loads_and_fails_loudly_without_a_device(capi):
     """lib/_gvd_raster_torch.so (csrc/raster_torch_ext.cpp, built by __graft_entry__.build_raster_torch_ext) imports, resolves its C-ABI
     entry points from libgvd_raster.so and refuses CPU tensors with the binding's message -- no silent fallback."""

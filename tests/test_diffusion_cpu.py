@@ -408,3 +408,75 @@ def test_loss_guidance_frames_loss_equals_the_per_frame_calls():
         assert torch.allclose(tot2, total, rtol=1e-6) and num2.tolist() == numels
         assert torch.allclose(g_fast, g_loop, rtol=1e-6, atol=1e-7)
     assert LossGuidance(ddim_steps=50, recur_steps=1, ssim_guidance=True).frames_loss(D, 0, F_) is None
+
+
+def test_guidance_gradient_scale_is_a_safe_power_of_two():
+    """The guided sampler's pre-scaling of d(loss)/d(pred_x0) (samplers.guidance_gradient_scale; advisor finding, round 5): an exact power of
+    two that puts the largest entry into [2^-5, 2^-4) for fp32 AND 16-bit gradients, and exactly 1 for an all-zero gradient (no valid mask
+    pixel -- the reference then gets rho = 0, not NaN) or a non-finite one."""
+    from lvdm_amd.samplers import guidance_gradient_scale
+    g = torch.Generator().manual_seed(3)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        for mag in (1e-7, 3e-4, 1.0, 40.0):
+            G = (torch.randn(2, 4, 5, 6, 7, generator=g) * mag).to(dt)
+            sc = guidance_gradient_scale(G)
+            assert sc.dtype == torch.float32 and float(torch.log2(sc)) == round(float(torch.log2(sc)))
+            top = float((G.float() * sc).to(dt).float().abs().max())
+            assert 2.0 ** -5 <= top < 2.0 ** -4, (dt, mag, top)
+        Z = torch.zeros(2, 3, dtype=dt)
+        assert float(guidance_gradient_scale(Z)) == 1.0 and not torch.isnan((Z.float() * guidance_gradient_scale(Z)).to(dt)).any()
+        assert float(guidance_gradient_scale(torch.tensor([1.0, float("inf")], dtype=dt))) == 1.0
+    tiny = torch.full((4,), 2.0 ** -140)           # fp32 subnormal: the exponent is held to fp32's range, the product stays finite
+    assert torch.isfinite(tiny * guidance_gradient_scale(tiny)).all()
+
+
+def test_graph_cache_notices_every_way_a_weight_can_move():
+    """graphs.GraphedApplyModel keys its captured hipGraphs on (id, data_ptr, version) of every parameter AND buffer (advisor finding, round 5:
+    only Parameter._version was tracked): an in-place load, a `.data` re-assignment (module.half() / .to()), a replaced Parameter object and a
+    changed buffer must each invalidate the captures; nothing else may.  Host logic only -- the capture itself is a GPU test."""
+    from lvdm_amd.graphs import GraphedApplyModel
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    gm = GraphedApplyModel(m)
+    assert not gm._weights_changed()                       # nothing captured yet
+    gm._state = gm._model_state()
+    assert not gm._weights_changed()
+    m(torch.randn(3, 4)).sum().backward()                  # gradients do not move weights ... but BatchNorm's running statistics did
+    assert gm._weights_changed()
+    m.eval()
+    gm._state = gm._model_state()
+    m(torch.randn(3, 4))
+    assert not gm._weights_changed()
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})      # in-place copy_: version bump
+    assert gm._weights_changed()
+    gm._state = gm._model_state()
+    m[0].weight.data = m[0].weight.data.clone()            # .data re-assignment: same object, new storage
+    assert gm._weights_changed()
+    gm._state = gm._model_state()
+    m[0].weight = torch.nn.Parameter(m[0].weight.detach().clone())            # replaced Parameter object
+    assert gm._weights_changed()
+    gm._state = gm._model_state()
+    m[1].running_mean.add_(1.0)                            # a buffer changed after the capture
+    assert gm._weights_changed()
+
+
+def test_decode_group_is_kept_and_only_shrinks():
+    """DDIMSamplerGuidance._decode_group (advisor finding, round 5): the frames-per-decoder-pass choice is kept per (frames, size, device);
+    when free memory (not the budget cap) decided it, later steps may shrink it, never grow it back."""
+    from lvdm_amd.samplers import DDIMSamplerGuidance
+    s = DDIMSamplerGuidance.__new__(DDIMSamplerGuidance)
+    s.decode_budget_gb = 100.0
+    answers = iter([(13, False), (25, False), (7, False), (9, True)])
+    calls = []
+    s._choose_decode_group = lambda n, h, w, d: (calls.append(1), next(answers))[1]
+    dev = torch.device("cpu")
+    assert s._decode_group(25, 72, 128, dev) == 13      # first choice, by free memory
+    assert s._decode_group(25, 72, 128, dev) == 13      # more memory later: does not grow
+    assert s._decode_group(25, 72, 128, dev) == 7       # less: shrinks
+    assert s._decode_group(25, 72, 128, dev) == 7 and len(calls) == 4
+    s2 = DDIMSamplerGuidance.__new__(DDIMSamplerGuidance)
+    s2.decode_budget_gb = 100.0
+    n = []
+    s2._choose_decode_group = lambda *a: (n.append(1), (25, True))[1]
+    assert [s2._decode_group(25, 40, 56, dev) for _ in range(3)] == [25, 25, 25] and len(n) == 1   # cap decided: asked once
+    s2.decode_group = 5
+    assert s2._decode_group(25, 40, 56, dev) == 5

@@ -587,6 +587,46 @@ def test_colour_only_backward_equals_zero_depth_and_alpha_gradients():
         assert torch.equal(a, b)
 
 
+def test_no_backward_forward_lays_out_a_compact_chunk_that_the_backward_refuses():
+    """gvd_raster_expect_backward(0) (advisor finding, round 5): the forward of a no-grad render asks its binning allocator for the layout WITHOUT
+    the backward's partial records (28 instead of 224 bytes per instance), renders the same bits, and a backward handed that chunk fails loudly
+    instead of reading records that were never laid out."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    sc = syn.scene_c2(P=30000, W=320, H=240)
+    cam = sc["cameras"][1]
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    E = torch.Tensor([])
+    W, H = cam["image_width"], cam["image_height"]
+    bg, m3, op, scl, rot, sh = t(sc["bg"]), t(sc["means3D"]), t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"]), t(sc["shs"])
+    vm, pm, cp = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["campos"])
+    fwd = lambda eb: _C.rasterize_gaussians(bg, m3, E, op, scl, rot, 1.0, E, vm, pm, cam["tanfovx"], cam["tanfovy"], H, W, sh, sc["sh_degree"], cp,
+                                            False, False, expect_backward=eb)
+    L = _C.lib()
+    for _ in range(3):      # exact path first, then the speculative one (the capacity then exceeds num_rendered)
+        full, lean = fwd(True), fwd(False)
+        assert full[0] == lean[0] > 1000
+        for a, b in zip(full[1:5], lean[1:5]):
+            assert torch.equal(a, b)
+        nf, nl = full[6].numel(), lean[6].numel()
+        assert nf % 64 == 0 and nl % 4 == 2 and nl < 0.2 * nf
+        cap = L.gvd_raster_binning_capacity(nl)
+        assert cap >= lean[0] and nl == L.gvd_raster_binning_bytes_no_backward(cap)
+        vf, vl = (_C.chunk_views(m3.shape[0], W, H, o[0], o[5], o[6], o[7]) for o in (full, lean))
+        R = full[0]
+        assert torch.equal(vf["point_list"][:R], vl["point_list"][:R]) and torch.equal(vf["ranges"], vl["ranges"])
+    gC = torch.ones(3, H, W, device=dev)
+    R, color, depth, alpha, radii, gb, bb, ib = lean
+    with pytest.raises(RuntimeError, match="without the backward's partial records"):
+        _C.rasterize_gaussians_backward(bg, m3, radii, E, scl, rot, 1.0, E, vm, pm, cam["tanfovx"], cam["tanfovy"], gC, None, None, sh,
+                                        sc["sh_degree"], cp, gb, R, bb, ib, alpha, False)
+    R, color, depth, alpha, radii, gb, bb, ib = full     # ... and the full chunk of the same render still differentiates
+    g = _C.rasterize_gaussians_backward(bg, m3, radii, E, scl, rot, 1.0, E, vm, pm, cam["tanfovx"], cam["tanfovy"], gC, None, None, sh,
+                                        sc["sh_degree"], cp, gb, R, bb, ib, alpha, False)
+    assert float(g[3].abs().max()) > 0
+
+
 def test_compiled_operator_equals_the_python_operator():
     """`rasterize_gaussians` runs the compiled torch::autograd::Function of lib/_gvd_raster_torch.so (csrc/raster_torch_ext.cpp); the
     Python `_RasterizeGaussians` over the ctypes entry points is the same operator (and carries debug dumps and the capacity mode).
