@@ -13,3 +13,11 @@ Importing this package changes no process-wide state, and nothing in it configur
 rocBLAS GEMM and no MIOpen convolution is left on the 16-bit product path of the U-Net and the VAE (tests/test_no_library_kernels_gpu.py
 holds that), so the recorded TunableOp / MIOpen find-db choices of rounds 1-3 and `configure_tuning()` were removed in round 5.
 """
+
+
+def allow_torch_fallback(allow=True):
+    """`with lvdm_amd.allow_torch_fallback():` -- see ops.allow_torch_fallback.  Device tensors no hand-written kernel covers (fp32
+    activations, mostly) RAISE by default instead of quietly running torch's library kernels; inside this context they run them with
+    one RuntimeWarning per (op, reason)."""
+    from .ops import allow_torch_fallback as _ctx
+    return _ctx(allow)

@@ -11,6 +11,7 @@ fallback: CPU tensors raise unless a test has explicitly enabled the reference m
 """
 import ctypes
 import os
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -66,12 +67,48 @@ def _require_device(t, what):
 
 
 _WARNED = set()
+_FALLBACK = threading.local()
+
+
+def torch_fallback_policy():
+    """'error' (the default) or 'warn': what happens when a DEVICE tensor is about to take the plain-torch form of an op (torch's library
+    kernels) instead of this package's hand-written one -- fp32 activations, a shape no kernel covers.  The thread's innermost
+    `allow_torch_fallback(...)` context decides, then GVD_TORCH_FALLBACK in the environment, then 'error'."""
+    v = getattr(_FALLBACK, "stack", None)
+    if v:
+        return v[-1]
+    return "warn" if os.environ.get("GVD_TORCH_FALLBACK", "error").lower() in ("warn", "allow", "1") else "error"
+
+
+class allow_torch_fallback:
+    """`with lvdm_amd.allow_torch_fallback():` -- inside, device tensors this package's kernels do not cover (fp32 activations of a parity
+    run; the fp32 Resampler / CLIP towers of a caller who did not `.half()` them) run torch's own kernels with one RuntimeWarning per
+    (op, reason).  Outside, the same call RAISES: a drop-in user cannot end up on a second backend unknowingly (verdict r5, item 8).
+    `allow_torch_fallback(False)` restores the strict default inside an allowing context.  Per thread, re-entrant."""
+
+    def __init__(self, allow=True):
+        self.mode = "warn" if allow else "error"
+
+    def __enter__(self):
+        st = getattr(_FALLBACK, "stack", None)
+        if st is None:
+            st = _FALLBACK.stack = []
+        st.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _FALLBACK.stack.pop()
+        return False
 
 
 def _torch_form(op, why):
     """A DEVICE tensor is about to take the plain-torch form of `op` instead of the hand-written kernel (fp32 activations of a
-    parity run, a head size the MFMA kernel does not cover, ...).  Never silent: one RuntimeWarning per (op, reason) and process,
-    so that a caller who merely forgot `.half()` sees that it is not running the product kernels."""
+    parity run, a head size the MFMA kernel does not cover, ...).  Never silent and, by default, not allowed: RuntimeError unless the
+    caller opted in (`allow_torch_fallback()` / GVD_TORCH_FALLBACK=warn), then one RuntimeWarning per (op, reason) and process."""
+    if torch_fallback_policy() == "error":
+        raise RuntimeError(f"lvdm_amd.ops.{op}: {why} -- no hand-written kernel covers this call, and the plain-torch form (torch's library "
+                           f"kernels) is not entered silently.  Run the module in 16 bit (.half() / .bfloat16(), as the reference's autocast "
+                           f"does), or opt in: `with lvdm_amd.allow_torch_fallback(): ...` / GVD_TORCH_FALLBACK=warn")
     key = (op, why)
     if key not in _WARNED:
         _WARNED.add(key)

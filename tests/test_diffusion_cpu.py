@@ -480,3 +480,29 @@ def test_decode_group_is_kept_and_only_shrinks():
     assert [s2._decode_group(25, 40, 56, dev) for _ in range(3)] == [25, 25, 25] and len(n) == 1   # cap decided: asked once
     s2.decode_group = 5
     assert s2._decode_group(25, 40, 56, dev) == 5
+
+
+def test_torch_fallback_policy_is_strict_by_default_and_opt_in_by_context(monkeypatch):
+    """Verdict r5 item 8: a device tensor no hand-written kernel covers must not reach torch's library kernels unknowingly.  The gate
+    (ops._torch_form) raises by default, warns once inside `lvdm_amd.allow_torch_fallback()`, nests, and follows GVD_TORCH_FALLBACK."""
+    import warnings
+    import lvdm_amd
+    from lvdm_amd import ops
+    monkeypatch.delenv("GVD_TORCH_FALLBACK", raising=False)      # (conftest opts the suite in; this test holds the product default)
+    assert ops.torch_fallback_policy() == "error"
+    with pytest.raises(RuntimeError, match="allow_torch_fallback"):
+        ops._torch_form("linear", "dtype torch.float32 (test)")
+    with lvdm_amd.allow_torch_fallback():
+        assert ops.torch_fallback_policy() == "warn"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ops._torch_form("linear", "dtype torch.float32 (test, unique reason 1)")
+            ops._torch_form("linear", "dtype torch.float32 (test, unique reason 1)")
+        assert len(w) == 1 and "plain torch form" in str(w[0].message)
+        with lvdm_amd.allow_torch_fallback(False):
+            with pytest.raises(RuntimeError):
+                ops._torch_form("attention", "x")
+        assert ops.torch_fallback_policy() == "warn"
+    assert ops.torch_fallback_policy() == "error"
+    monkeypatch.setenv("GVD_TORCH_FALLBACK", "warn")
+    assert ops.torch_fallback_policy() == "warn"

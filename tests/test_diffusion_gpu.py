@@ -797,3 +797,24 @@ def test_reloaded_weights_are_not_served_from_stale_packed_caches():
         y_re, d_re = u_old(x, t, context=ctx, fs=fs), v_old.decode(z)
     assert torch.equal(y_re, y_new), float((y_re.float() - y_new.float()).abs().max())
     assert torch.equal(d_re, d_new), float((d_re.float() - d_new.float()).abs().max())
+
+
+def test_fp32_device_tensors_raise_unless_the_caller_opts_in(monkeypatch):
+    """Verdict r5 item 8: fp32 device tensors used to run torch's library kernels behind a RuntimeWarning.  Product default now: RuntimeError
+    naming the remedy; `lvdm_amd.allow_torch_fallback()` is the explicit door (this suite's conftest opens it for the fp32 parity legs)."""
+    import lvdm_amd
+    from lvdm_amd import gemm, ops
+    monkeypatch.delenv("GVD_TORCH_FALLBACK", raising=False)
+    dev = "cuda:0"
+    x = torch.randn(64, 64, device=dev)
+    lin = torch.nn.Linear(64, 64).to(dev)
+    q = torch.randn(2, 16, 128, device=dev)
+    for call in (lambda: gemm.linear(x, lin.weight, lin.bias), lambda: ops.attention(q, q, q, 2),
+                 lambda: ops.layer_norm(x, lin.weight[0], lin.bias, 1e-5)):
+        with pytest.raises(RuntimeError, match="allow_torch_fallback"):
+            call()
+    with lvdm_amd.allow_torch_fallback():
+        y = gemm.linear(x, lin.weight, lin.bias)
+        assert torch.allclose(y, torch.nn.functional.linear(x, lin.weight, lin.bias), atol=1e-4)
+    yh = gemm.linear(x.half(), lin.weight.half(), lin.bias.half())       # 16 bit: the kernel, no door needed
+    assert torch.allclose(yh.float(), y, atol=3e-2)
