@@ -14,9 +14,31 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 # spawns; tests/test_diffusion_gpu.py::test_fp32_device_tensors_raise_unless_the_caller_opts_in holds the default.
 os.environ.setdefault("GVD_TORCH_FALLBACK", "warn")
 
+_GUARD = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # GVD_GUARD_ALLOC=1: the whole pytest process runs under the red-zone guard allocator (tests/guard/guard_allocator.cpp, verdict r5 item 6);
+    # written red zones fail the session at its end.  Only for test files that neither capture hipGraphs nor read allocator statistics
+    # (tests/scripts/r6_guard_all.sh names them).
+    global _GUARD
+    if os.environ.get("GVD_GUARD_ALLOC") == "1":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "scripts"))
+        import r6_guard_run
+        _GUARD = r6_guard_run.install()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _GUARD is not None:
+        import gc
+        import torch
+        gc.collect()
+        torch.cuda.synchronize()
+        v = _GUARD.gvd_guard_check_all()
+        print(f"\n[gvd_guard] pytest session: {_GUARD.gvd_guard_allocs()} allocations, {_GUARD.gvd_guard_frees()} freed and checked, violations: {v}")
+        if v and session.exitstatus == 0:
+            session.exitstatus = 1
 
 
 @pytest.fixture(scope="session")
