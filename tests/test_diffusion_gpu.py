@@ -807,7 +807,7 @@ def test_fp32_device_tensors_raise_unless_the_caller_opts_in(monkeypatch):
     monkeypatch.delenv("GVD_TORCH_FALLBACK", raising=False)
     dev = "cuda:0"
     x = torch.randn(64, 64, device=dev)
-    lin = torch.nn.Linear(64, 64).to(dev)
+    lin = torch.nn.Linear(64, 64).to(dev).requires_grad_(False)
     q = torch.randn(2, 16, 128, device=dev)
     for call in (lambda: gemm.linear(x, lin.weight, lin.bias), lambda: ops.attention(q, q, q, 2),
                  lambda: ops.layer_norm(x, lin.weight[0], lin.bias, 1e-5)):
@@ -816,5 +816,6 @@ def test_fp32_device_tensors_raise_unless_the_caller_opts_in(monkeypatch):
     with lvdm_amd.allow_torch_fallback():
         y = gemm.linear(x, lin.weight, lin.bias)
         assert torch.allclose(y, torch.nn.functional.linear(x, lin.weight, lin.bias), atol=1e-4)
-    yh = gemm.linear(x.half(), lin.weight.half(), lin.bias.half())       # 16 bit: the kernel, no door needed
+    with torch.no_grad():
+        yh = gemm.linear(x.half(), lin.weight.detach().half(), lin.bias.detach().half())       # 16 bit: the kernel, no door needed
     assert torch.allclose(yh.float(), y, atol=3e-2)
