@@ -13,7 +13,7 @@ plug in unchanged.
 """
 import torch
 
-from .samplers import DDIMSampler, DDIMSamplerGuidance
+from .samplers import DDIMSampler, DDIMSamplerGuidance, DDIMSamplerMultiCond
 
 
 def get_latent_z(model, videos):
@@ -29,9 +29,10 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
                            multiple_cond_cfg=False, timestep_spacing='uniform', guidance_rescale=0.0,
                            condition_index=None, loss_guidance_fn=None, no_guidance=False, **kwargs):
     """Same signature and return ([batch, n_samples, c, t, h, w]) as diffusion_utils.py:118-223."""
-    if multiple_cond_cfg:
-        raise NotImplementedError("multiple_cond_cfg (DDIMSampler_multicond) is not used by the guidedvd drivers")
-    sampler = DDIMSampler(model) if no_guidance else DDIMSamplerGuidance(model)
+    if multiple_cond_cfg:     # diffusion_utils.py:123-125: the three-way sampler replaces BOTH the plain and the guided one
+        sampler = DDIMSamplerMultiCond(model)
+    else:
+        sampler = DDIMSampler(model) if no_guidance else DDIMSamplerGuidance(model)
     batch_size = noise_shape[0]
     fs = torch.tensor([fs] * batch_size, dtype=torch.long, device=model.device)
     if not text_input:
@@ -62,7 +63,15 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
         uc = {"c_crossattn": [torch.cat([uc_emb, uc_img_emb], dim=1)]}
         if hybrid:
             uc["c_concat"] = [img_cat_cond]
-    kwargs.update({"unconditional_conditioning_img_nonetext": None})
+    if multiple_cond_cfg and cfg_img != 1.0:    # one more unconditional: image = yes, text = "" (diffusion_utils.py:176-183)
+        if uc is None:
+            raise ValueError("multiple_cond_cfg needs unconditional_guidance_scale != 1.0 (the reference reads uc_emb here)")
+        uc_2 = {"c_crossattn": [torch.cat([uc_emb, img_emb], dim=1)]}
+        if hybrid:
+            uc_2["c_concat"] = [img_cat_cond]
+        kwargs.update({"unconditional_conditioning_img_nonetext": uc_2})
+    else:
+        kwargs.update({"unconditional_conditioning_img_nonetext": None})
     if loss_guidance_fn is not None:
         kwargs.update({"loss_guidance_fn": loss_guidance_fn})
 

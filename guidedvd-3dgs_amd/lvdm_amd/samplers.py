@@ -215,14 +215,65 @@ class DDIMSampler(object):
         else:
             e_cond = m.apply_model(x, t, c, **kwargs)
             e_uncond = m.apply_model(x, t, unconditional_conditioning, **kwargs)
+        return self._finish_step(x, e_cond, e_uncond, index, unconditional_guidance_scale, guidance_rescale, temperature, noise)
+
+    def _finish_step(self, x, e_cond, e_uncond, index, cfg_scale, guidance_rescale, temperature, noise):
+        """CFG combine, guidance rescale, v -> (eps, x0), dynamic rescale, x_{t-1}: the one fused update (ops.ddim_step; ddim.py:225-280)."""
         k = self._step_constants(index)
         if noise is None:
             noise = self._randn(x.shape, x.device)
         return ops.ddim_step(x.float(), e_cond.float(), None if e_uncond is None else e_uncond.float(), noise,
-                             cfg_scale=float(unconditional_guidance_scale), guidance_rescale=float(guidance_rescale),
+                             cfg_scale=float(cfg_scale), guidance_rescale=float(guidance_rescale),
                              sqrt_ac_t=k["sqrt_ac_t"], sqrt_1mac_t=k["sqrt_1mac_t"], sqrt_a_prev=k["sqrt_a_prev"],
                              dir_coef=k["dir_coef"], sigma_t=k["sigma_t"], x0_rescale=k["x0_rescale"],
                              temperature=float(temperature))
+
+
+class DDIMSamplerMultiCond(DDIMSampler):
+    """The three-way classifier-free guidance of lvdm/models/samplers/ddim_multiplecond.py:210-286 (text x image), the sampler
+    utils_vc/diffusion_utils.py:123-125 picks when `multiple_cond_cfg` is set: per step THREE U-Net evaluations -- full condition c,
+    unconditional uc (text "", image zero) and `unconditional_conditioning_img_nonetext` (text "", image kept; built at
+    diffusion_utils.py:177-181) -- combined as
+
+        v = e_uc + cfg_img (e_img - e_uc) + s (e_c - e_img),          cfg_img defaulting to s                      (:220-221, :234)
+
+    then the plain step's rescale / v-parameterisation / update (:235-286, the same lines as ddim.py).  The combination is handed to the
+    fused update in its two-way form: v = B + s (e_c - B) with B = (e_uc + cfg_img (e_img - e_uc) - s e_img) / (1 - s), formed in fp32
+    -- algebraically the same line, one elementwise expression instead of a second update kernel (the rescale's statistics are those of v
+    and e_c in both forms).  With CFG off (uc None or s == 1) it is the plain sampler, as in the reference.  Golden:
+    tests/golden/make_golden_multicond.py (the reference's own class on the duck model)."""
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        """As the plain sampler's, except for one table the reference fixed there and not here: the dynamic-rescale factor of the LAST
+        step (index 0) is `ddim_scale_arr[0] / ddim_scale_arr[0]` = 1 in ddim_multiplecond.py:33, where ddim.py:33-35 ("fix a bug") divides
+        `scale_arr[0]` by it.  Kept as the reference has it -- the golden pins it (tests/golden/make_golden_multicond.py, index 0)."""
+        super().make_schedule(ddim_num_steps, ddim_discretize, ddim_eta, verbose)
+        if self.model.use_dynamic_rescale:
+            self.ddim_scale_arr_prev = torch.cat([self.ddim_scale_arr[0:1], self.ddim_scale_arr[:-1]])
+
+    def p_sample_ddim(self, x, c, t, index, temperature=1., unconditional_guidance_scale=1., unconditional_conditioning=None,
+                      guidance_rescale=0.0, noise=None, cfg_img=None, **kwargs):
+        if self.model.parameterization != "v":
+            raise NotImplementedError("ViewCrafter is v-parameterised")
+        uc_img = kwargs.pop("unconditional_conditioning_img_nonetext", None)
+        s = float(unconditional_guidance_scale)
+        if unconditional_conditioning is None or s == 1.:
+            return super().p_sample_ddim(x, c, t, index, temperature=temperature, unconditional_guidance_scale=s,
+                                         unconditional_conditioning=unconditional_conditioning, guidance_rescale=guidance_rescale,
+                                         noise=noise, **kwargs)
+        if uc_img is None:   # (the reference evaluates apply_model(x, t, None) here and fails inside the U-Net)
+            raise ValueError("multiple-condition CFG needs kwargs['unconditional_conditioning_img_nonetext'] "
+                             "(diffusion_utils.py:177-181 builds it when cfg_img != 1.0)")
+        if getattr(self, "parallel", None) is not None:
+            raise NotImplementedError("the multi-GPU plan partitions a CFG PAIR; the three-way sampler runs on one rank")
+        ci = s if cfg_img is None else float(cfg_img)
+        m = self.model
+        with torch.no_grad():
+            e_c = m.apply_model(x, t, c, **kwargs).float()
+            e_uc = m.apply_model(x, t, unconditional_conditioning, **kwargs).float()
+            e_img = m.apply_model(x, t, uc_img, **kwargs).float()
+            base = (e_uc + ci * (e_img - e_uc) - s * e_img) / (1.0 - s)
+        return self._finish_step(x, e_c, base, index, s, guidance_rescale, temperature, noise)
 
 
 def guidance_gradient_scale(G):

@@ -11,12 +11,18 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 VC = "/root/reference/third_party/ViewCrafter"
-sys.path.insert(0, VC)
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, VC)
+# The reference FIRST, before guidedvd-3dgs_amd/ is importable at all: that directory also holds an `lvdm` -- the drop-in that shadows the
+# reference's in production, and does so from ANY position of sys.path, because the reference's lvdm/ has no __init__.py (a namespace
+# package loses to a regular one).  With the old import order the reference's image_guided_synthesis would drive THIS repository's
+# samplers.  (pipeline_ref.npz was generated before the drop-in existed; regenerated with this order in round 6: bit-identical.)
+from utils_vc import diffusion_utils as du  # the reference
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "guidedvd-3dgs_amd"))
-
-from utils_vc import diffusion_utils as du  # the reference
+import inspect
+for _cls in (du.DDIMSampler, du.DDIMSamplerGuidance, du.DDIMSampler_multicond):
+    assert inspect.getsourcefile(_cls).startswith("/root/reference/"), inspect.getsourcefile(_cls)
 from lvdm_amd import ops
 from lvdm_amd.guidance import LossGuidance
 from lvdm_amd.schedule import DiffusionSchedule
