@@ -101,6 +101,28 @@ class allow_torch_fallback:
         return False
 
 
+def checkpoint_dtype_tower(forward):
+    """Decorator for the forward of the ONCE-PER-VIDEO conditioning modules that use this package's operators (the Resampler and the
+    image projection; the CLIP towers of clip.py are plain torch modules throughout and never reach the gate).  The reference runs them in the
+    checkpoint's fp32 under autocast and never `.half()`s them; a drop-in user does not either, and the reference's own
+    utils_vc/diffusion_utils.py:140-160 calls them directly -- there is no place for the user to opt in.  So these two modules are the NAMED exception
+    to the strict default: with fp32 parameters on a device they run torch's kernels (one RuntimeWarning per (op, reason)); in 16 bit
+    they run this package's kernels like everything else.  An explicit `allow_torch_fallback(False)` around the call still wins.  The hot loop -- U-Net,
+    VAE, samplers -- never passes through here."""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(self, *args, **kwargs):
+        if getattr(_FALLBACK, "stack", None):          # the caller stated a policy: keep it
+            return forward(self, *args, **kwargs)
+        p = next(self.parameters(), None)
+        if p is not None and p.is_cuda and p.dtype == torch.float32:
+            with allow_torch_fallback():
+                return forward(self, *args, **kwargs)
+        return forward(self, *args, **kwargs)
+    return wrapped
+
+
 def _torch_form(op, why):
     """A DEVICE tensor is about to take the plain-torch form of `op` instead of the hand-written kernel (fp32 activations of a
     parity run, a head size the MFMA kernel does not cover, ...).  Never silent and, by default, not allowed: RuntimeError unless the

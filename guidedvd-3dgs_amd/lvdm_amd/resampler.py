@@ -39,6 +39,7 @@ class ImageProjModel(nn.Module):
         self.add_module("proj", _linear(clip_embeddings_dim, clip_extra_context_tokens * cross_attention_dim))
         self.add_module("norm", _LayerNorm(cross_attention_dim))
 
+    @ops.checkpoint_dtype_tower
     def forward(self, image_embeds):
         wide = gemm.linear(image_embeds.to(self.proj.weight.dtype), self.proj.weight, self.proj.bias)
         return self.norm(wide.view(-1, self.clip_extra_context_tokens, self.cross_attention_dim))
@@ -87,6 +88,7 @@ class Resampler(nn.Module):
         for _ in range(depth):
             self.layers.append(nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads), FeedForward(dim, ff_mult)]))
 
+    @ops.checkpoint_dtype_tower
     def forward(self, x):
         tokens = gemm.linear(x, self.proj_in.weight, self.proj_in.bias)
         state = self.latents.expand(tokens.shape[0], -1, -1).to(tokens.dtype)

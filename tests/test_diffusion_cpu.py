@@ -584,3 +584,34 @@ def test_pipeline_entry_with_multiple_cond_cfg_matches_the_reference():
     np.testing.assert_allclose(got.detach().numpy(), ref, rtol=0, atol=5e-5)
     plain = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_ref.npz"))["plain_video"]
     assert np.abs(ref - plain).max() > 1e-2          # the third evaluation matters: not the two-way video
+
+
+def test_once_per_video_towers_are_the_named_exception_to_the_strict_default(monkeypatch):
+    """ops.checkpoint_dtype_tower (Resampler / ImageProjModel forward): with fp32 parameters on a device the module opens the torch-fallback door itself
+    -- the reference's diffusion_utils.py calls these modules directly, a drop-in user has no place to opt in -- unless the caller stated a policy.
+    Host logic only: a stand-in module whose forward reports the policy it runs under (is_cuda / dtype are what the decorator reads)."""
+    from lvdm_amd import ops
+    monkeypatch.delenv("GVD_TORCH_FALLBACK", raising=False)
+
+    class P:   # what next(self.parameters()) hands the decorator
+        def __init__(self, cuda, dtype):
+            self.is_cuda, self.dtype = cuda, dtype
+
+    class Tower:
+        def __init__(self, cuda, dtype):
+            self.p = P(cuda, dtype)
+
+        def parameters(self):
+            return iter([self.p])
+
+        @ops.checkpoint_dtype_tower
+        def forward(self):
+            return ops.torch_fallback_policy()
+
+    assert Tower(True, torch.float32).forward() == "warn"          # fp32 on a device: the named exception
+    assert Tower(True, torch.float16).forward() == "error"         # 16 bit: this package's kernels, strict
+    assert Tower(False, torch.float32).forward() == "error"        # CPU tensors raise elsewhere (no CPU path)
+    with ops.allow_torch_fallback(False):
+        assert Tower(True, torch.float32).forward() == "error"     # an explicit policy of the caller wins
+    from lvdm_amd import resampler
+    assert resampler.Resampler.forward.__wrapped__ is not None and resampler.ImageProjModel.forward.__wrapped__ is not None
