@@ -14,7 +14,7 @@ from math import exp
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_loss.so")
+_LIB_PATH = os.environ.get("GVD_LOSS_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libgvd_loss.so")  # env: A/B and sanitizer builds
 _LIB = None
 
 

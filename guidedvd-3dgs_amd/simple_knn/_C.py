@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgvd_knn.so")
+_LIB_PATH = os.environ.get("GVD_KNN_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libgvd_knn.so")  # env: A/B and sanitizer builds
 _LIB = None
 
 

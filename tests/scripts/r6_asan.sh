@@ -3,6 +3,10 @@
 # enabled on the box (HSA_XNACK=1 and a kernel driver that allows it), (b) the host ASan runtime preloaded into the un-instrumented python, and
 # (c) for device-side reports the instrumented runtime libraries of /opt/rocm/lib/asan, which this image does NOT ship (ls below).  Whatever the box
 # says is logged verbatim; the red-zone guard allocator (r6_guard_all.sh) is the pass that does not depend on any of this.
+# libgvd_diffusion is NOT built here: under -fsanitize=address hipcc rejects the hand-written LDS-DMA block of gemm_mfma.hip (the inline asm at
+# :257-265, `global_load_lds_dwordx4 %2, %5` with SGPR-constrained operands: "invalid operand for instruction", 135 times, after 24 min 41 s of
+# compilation at -O1 in the build container; the same file builds for gfx950:xnack+ WITHOUT the sanitizer in 21 s) -- the instrumentation moves the
+# operands out of the scalar registers the instruction needs.  The diffusion kernels' memory safety rests on the guard allocator.
 set -u
 R=$PWD
 A=$R/guidedvd-3dgs_amd/lib/asan
@@ -23,5 +27,7 @@ export HSA_XNACK=1 ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_erro
 echo "== asan: rocminfo xnack: $(/opt/rocm/bin/rocminfo 2>/dev/null | grep -i -m2 'xnack' | tr '\n' ' ')"
 echo "== asan: raster tests (ctypes carrier; the compiled operator is not instrumented)"
 LD_PRELOAD=$RT GVD_RASTER_LIB=$A/libgvd_raster.so GVD_RASTER_NO_EXT=1 timeout 900 python -m pytest tests/test_raster_gpu.py -m gpu -q -x 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm ver\|^Hostname\|^Librccl\|amdgpu.ids' | tail -12
+echo "== asan: knn + loss tests"
+LD_PRELOAD=$RT GVD_KNN_LIB=$A/libgvd_knn.so GVD_LOSS_LIB=$A/libgvd_loss.so timeout 900 python -m pytest tests/test_knn.py tests/test_fused_loss.py -m gpu -q -x 2>&1 | tail -4
 echo "== asan: raster stress"
 LD_PRELOAD=$RT GVD_RASTER_LIB=$A/libgvd_raster.so GVD_RASTER_NO_EXT=1 timeout 900 python tests/scripts/r5_raster_stress.py 2>&1 | tail -6

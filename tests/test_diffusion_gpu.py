@@ -181,6 +181,29 @@ def test_plain_sampler_on_device_uses_fused_step():
         np.testing.assert_allclose(xp.cpu().numpy(), ref, rtol=5e-5, atol=5e-6 * np.abs(ref).max())
 
 
+def test_multicond_sampler_on_device_uses_fused_step():
+    """The three-way (text x image) CFG of DDIMSamplerMultiCond on the device: the combination is handed to the fused update kernel in its two-way
+    form; against the reference's own ddim_multiplecond.py golden (tests/golden/make_golden_multicond.py)."""
+    from test_diffusion_cpu import MC, _Duck, _duck_inputs
+    from lvdm_amd.samplers import DDIMSamplerMultiCond
+    duck = _Duck().to(DEV)
+    s = DDIMSamplerMultiCond(duck)
+    s.make_schedule(50, "uniform_trailing", 1.0)
+    x, cond, uc = _duck_inputs()
+    x = x.to(DEV)
+    cond = {"c_crossattn": [cond["c_crossattn"][0].to(DEV)]}
+    uc = {"c_crossattn": [uc["c_crossattn"][0].to(DEV)]}
+    uc_img = {"c_crossattn": [torch.tensor(MC["mc_uc_img"], device=DEV)]}
+    for index in (49, 30, 0):
+        for tag, cfg_img, resc in (("a", 3.0, 0.7), ("b", None, 0.7), ("c", 1.5, 0.0)):
+            t = torch.full((1,), int(s.ddim_timesteps[index]), dtype=torch.long, device=DEV)
+            xp, p0 = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc, cfg_img=cfg_img,
+                                     guidance_rescale=resc, noise=torch.tensor(G["step_noise0"], device=DEV),
+                                     unconditional_conditioning_img_nonetext=uc_img)
+            ref = MC[f"mc{index}{tag}_xprev"]
+            np.testing.assert_allclose(xp.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape,cl", [((3, 320, 40, 56), False), ((2, 640, 5, 7), False), ((1, 320, 25, 12, 16), False),
                                       ((1, 25, 192, 320), True), ((2, 7, 35, 1280), True), ((1, 4, 600, 64), True)])
