@@ -1,4 +1,4 @@
-// gemm_mfma.hip -- hand-written gfx950 NT GEMM  Y[M, N] = X[M, K] . W[N, K]^T  on MFMA 32x32x16 with the transformer-side
+// gemm_mfma.hip -- hand-written gfx950 NT GEMM  Y[M, N] = X[M, K] . W[N, K]^T  on MFMA 16x16x32 with the transformer-side
 // epilogues of the ViewCrafter U-Net fused in (C-ABI: include/gvd_diffusion.h, gvd_gemm_nt / gvd_row_stats).
 //
 // Replaces (reference lines, all nn.Linear / 1x1 convolutions on token rows; hipBLASLt through F.linear until round 2):
@@ -11,22 +11,23 @@
 //
 // Layout: X rows = tokens (row stride ldx), W rows = output channels (row stride ldw), both K-contiguous 16-bit; Y rows = tokens.
 //
-// Design (one workgroup = 512 threads = 8 waves, one workgroup per CU):
-//   * Tile: BN = 320 (or 256) output channels x 256 tokens, K in steps of 64.  Waves 2 (channels) x 4 (tokens); a wave owns
-//     160 (128) channels x 64 tokens = 5 (4) x 2 MFMA 32x32 blocks: 10 (8) MFMAs per 7 (6) operand reads, 160 (128) accumulator
-//     registers.  MFMA roles as in conv_mfma.hip: A = W rows (channels), B = X rows (tokens): a lane ends with 4 consecutive
-//     channels of ONE token per register quad, so the epilogue writes channel-contiguous rows.
-//   * Staging is LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass): the LDS image of a stage is
-//     [BN + 256 rows][128 B], filled linearly (wave base + lane x 16 B); the bank-conflict-free layout for the ds_read_b128
-//     operand reads (16-lane groups {0-3,12-15,20-27} ...) is an XOR of the 16-byte slot with ((row >> 1) & 7), applied to the
-//     per-lane GLOBAL address (inside the row's own 128-byte line, so coalescing is untouched) and to the read address.
-//   * Two LDS stages (2 x 72 KiB): the DMA of K-tile t+1 is in flight under the 40 MFMAs of tile t; one barrier per K-tile.
-//   * PERSISTENT workgroups (one per CU) walk their tiles; the first K-tile of the NEXT tile is issued before the epilogue of
-//     the current one, so its HBM / L2 latency hides under the epilogue's stores (with K = 320 a tile is only 5 K-steps long).
-//   * Epilogue: scale, the LAYERNORM FOLD, bias in fp32 registers; GEGLU gate; 16-bit rounding; the two wave halves, which hold
-//     channels 8 rg + [0, 4) and 8 rg + [4, 8) of a token, exchange 8-byte halves with v_permlane32_swap to own whole octets;
-//     a wave-private transposition through LDS (no barriers); residual; 16-byte stores in which 20 consecutive lanes cover
-//     320 contiguous bytes of one token row.
+// Design as of round 6 (one workgroup = 512 threads = 8 waves, one workgroup per CU; a 4-wave form with two workgroups per CU for narrow N):
+//   * Tile: BN = 320 (or 256) output channels x 256 tokens.  Waves 2 (channels) x 4 (tokens); a wave owns 160 (128) channels x 64 tokens as
+//     MFMA 16x16x32 blocks (round 6: more flops per watt than 32x32x16 on the power-capped board, tests/scripts/r6_mfma_power.hip; the
+//     32x32x16 form of rounds 3-5 is gone from k_gemm_nt; k_gemm_skinny keeps it).  MFMA roles as in conv_mfma.hip: A = W rows (channels), B = X rows (tokens): a lane ends with 4
+//     consecutive channels of ONE token per register quad, so the epilogue writes channel-contiguous rows.
+//   * Staging is LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), filled linearly (wave base + lane x 16 B); the
+//     bank-conflict-free layout for the ds_read_b128 operand reads is an XOR of the 16-byte slot with row bits, applied to the per-lane GLOBAL
+//     address (inside the row's own line, so coalescing is untouched) and to the read address.
+//   * K loop (8-wave form): a RING of four 32-channel slots, the DMA of half-tile h + 3 issued by hand-written asm between the MFMA steps of
+//     h, counted vmcnt waits, the fragments that open h + 1 read across the barrier -- see the comment above k_gemm_nt.  (Rounds 3-5: two
+//     64-channel stages, one barrier per K-tile, ~500 of 2750 cycles per K-tile without an MFMA in flight.)  Operand fragments are read two
+//     MFMA steps ahead of their use, pinned with sched_group_barrier (GVD_GEMM_RDAHEAD).
+//   * PERSISTENT workgroups (one per CU) walk their tiles; the three half-tiles that open the NEXT tile are issued before the epilogue of the
+//     current one, so their HBM / L2 latency hides under the epilogue's stores (with K = 320 a tile is only ten half-tiles long).
+//   * Epilogue, in 16-token passes: scale, the LAYERNORM FOLD, bias in fp32 registers; the GEGLU gate (modes of GemmArgs::geglu: inference
+//     gate; gate + saved pre-activation for autograd; the gate's BACKWARD on an incoming gradient -- round 6, gvd_gemm_nt_gate); 16-bit
+//     rounding; a wave-private transposition through LDS (no barriers); residual; 16-byte non-temporal stores, row-contiguous.
 //   * LayerNorm fold: LN(x) W^T = rstd (x W'^T - mean s) + c with W' = W gamma (per input channel), s[n] = sum_k W'[n, k],
 //     c[n] = sum_k beta[k] W[n, k] + bias[n]: the GEMM runs on the raw tokens and the normalisation is two per-row scalars
 //     (gvd_row_stats) and two per-column vectors in the epilogue -- no normalised tensor is ever written or read.
