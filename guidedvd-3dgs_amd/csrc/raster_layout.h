@@ -37,7 +37,7 @@ inline size_t carve(size_t& cur, size_t bytes)
 }
 
 // `with_partials` = false: the binning chunk of a forward that no backward will follow (gvd_raster_expect_backward(0), allocator-callback
-// entry point only): the flag words and the 4 x 48-byte sub-records per instance -- 196 of the chunk's 224 bytes per instance, times the
+// entry point only): the flag words and the 4 x 48-byte sub-records per instance -- 196 of the chunk's 220 bytes per instance, times the
 // speculative capacity's 12.5 % + 4096 of headroom -- are not laid out at all (advisor finding, round 5: ~2.2 GB at 10 M instances held
 // per render in flight on a GPU shared with the diffusion model).  Such a chunk's size is not the size of any full layout (see below), so a
 // backward handed it is refused by its size check instead of reading past the end.

@@ -102,7 +102,7 @@ void gvd_raster_set_speculation(int on);
  * gvd_raster_backward(_conf) therefore requires the binning chunk as the forward left it -- bytes may be copied / offloaded /
  * restored, but not modified.  A caller that will NOT run a backward on the chunks of its next forwards (no-grad / evaluation
  * renders) may say so with gvd_raster_expect_backward(0): the clearing stores are skipped, gvd_raster_forward lays the binning chunk
- * out WITHOUT the partial records (gvd_raster_binning_bytes_no_backward: an eighth of the size), and a backward on such a chunk is refused
+ * out WITHOUT the partial records (gvd_raster_binning_bytes_no_backward: a ninth of the size), and a backward on such a chunk is refused
  * when binning_chunk_bytes is given, undefined otherwise.  Per host thread, sticky until changed; default 1 (the reference's contract: any forward may be followed by a
  * backward). */
 void gvd_raster_expect_backward(int yes);
@@ -242,7 +242,7 @@ size_t gvd_raster_geometry_bytes(int P, int width, int height);
 size_t gvd_raster_image_bytes(int width, int height);
 size_t gvd_raster_binning_bytes(uint32_t num_rendered);
 /* MI355X addition: what gvd_raster_forward asks its binning allocator for under gvd_raster_expect_backward(0) -- the chunk WITHOUT the
- * backward's flag words and 4 x 48-byte partial records per instance (28 instead of 224 bytes per instance).  gvd_raster_backward(_conf)
+ * backward's flag words and 4 x 48-byte partial records per instance (24 instead of 220 bytes per instance).  gvd_raster_backward(_conf)
  * refuses such a chunk (GVD_ERR_INVALID) when it is told the chunk's size.  gvd_raster_forward_capped always uses the full layout. */
 size_t gvd_raster_binning_bytes_no_backward(uint32_t num_rendered);
 

@@ -126,8 +126,8 @@ def test_binning_capacity_inverts_binning_bytes_and_never_reports_less_than_it_h
         assert L.gvd_raster_binning_capacity(b + 4) == 0xffffffff
 
 
-def test_no_backward_chunk_is_an_eighth_of_the_size_and_never_passes_for_a_full_one(capi):
-    """The binning chunk of a forward run under gvd_raster_expect_backward(0) carries no partial records (advisor finding, round 5: 224 bytes
+def test_no_backward_chunk_is_a_ninth_of_the_size_and_never_passes_for_a_full_one(capi):
+    """The binning chunk of a forward run under gvd_raster_expect_backward(0) carries no partial records (advisor finding, round 5: 220 bytes
     per instance held per render in flight).  Its size is never the size of a full layout -- the backward tells the two apart by size alone
     and refuses the compact one."""
     L = capi.lib()

@@ -589,7 +589,7 @@ def test_colour_only_backward_equals_zero_depth_and_alpha_gradients():
 
 def test_no_backward_forward_lays_out_a_compact_chunk_that_the_backward_refuses():
     """gvd_raster_expect_backward(0) (advisor finding, round 5): the forward of a no-grad render asks its binning allocator for the layout WITHOUT
-    the backward's partial records (28 instead of 224 bytes per instance), renders the same bits, and a backward handed that chunk fails loudly
+    the backward's partial records (24 instead of 220 bytes per instance), renders the same bits, and a backward handed that chunk fails loudly
     instead of reading records that were never laid out."""
     import torch
     from diff_gaussian_rasterization import _C
