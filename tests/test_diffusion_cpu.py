@@ -615,3 +615,24 @@ def test_once_per_video_towers_are_the_named_exception_to_the_strict_default(mon
         assert Tower(True, torch.float32).forward() == "error"     # an explicit policy of the caller wins
     from lvdm_amd import resampler
     assert resampler.Resampler.forward.__wrapped__ is not None and resampler.ImageProjModel.forward.__wrapped__ is not None
+
+
+def test_geglu_row_order_is_the_kernels_block_order():
+    """gemm._geglu_perm: the row order in which the GEGLU projection's weight is handed to the MFMA GEMM so that a lane of the 16x16x32 accumulator
+    layout owns value AND gate of the same outputs (include/gvd_diffusion.h: gvd_gemm_geglu_layout() == 1).  Per block of 32 tile rows: rows 0-15 the
+    VALUES of 16 consecutive outputs, rows 16-31 their GATES, each half in natural order.  The fused feed-forward's backward
+    (gemm._transposed_gate_order) relies on the same order for the columns of d/d(projection).  Host logic; the library only answers the layout query."""
+    from lvdm_amd import gemm, ops
+    L = ops.lib()
+    assert hasattr(L, "gvd_gemm_geglu_layout") and L.gvd_gemm_geglu_layout() == 1
+    for n in (16, 320, 1280):
+        perm = gemm._geglu_perm(2 * n, torch.device("cpu"))
+        assert sorted(perm.tolist()) == list(range(2 * n))
+        blocks = perm.view(n // 16, 32)
+        for b in (0, n // 16 - 1):
+            assert blocks[b, :16].tolist() == list(range(16 * b, 16 * b + 16))
+            assert blocks[b, 16:].tolist() == list(range(n + 16 * b, n + 16 * b + 16))
+    w = torch.nn.Parameter(torch.arange(64 * 8, dtype=torch.float32).view(64, 8))      # a [2C = 64, K = 8] projection
+    Wt = gemm._transposed_gate_order(w, torch.float32)
+    assert Wt.shape == (8, 64) and torch.equal(Wt[:, :16], w[:16].t()) and torch.equal(Wt[:, 16:32], w[32:48].t())
+    assert gemm._transposed_gate_order(w, torch.float32) is Wt                          # cached on the weight
