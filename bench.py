@@ -46,6 +46,68 @@ def newest_profile(suffix):
     return c[-1], "profiles/" + os.path.basename(c[-1])
 
 
+def raster_byte_model(P, W, H, R):
+    """SURVEY.md section 8(d) (SURVEY.md:438) with the measured instance count R and M = 16 SH coefficients (the tensor is stored, and its gradient
+    written, at 16 whatever the active degree): algorithmic bytes of one view's forward, backward, and of the per-Gaussian backward alone."""
+    M = 16
+    HW = W * H
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    bit = max(1, (ntiles - 1).bit_length())                 # getHigherMsb(#tiles), rasterizer_impl.cu:35-50
+    fwd = P * (12 + 12 + 16 + 4 + 12 * M) + P * 79 + P * 8 + R * 12 + R * 24 * ((32 + bit + 7) // 8) + R * 8 + R * 28 + HW * 24
+    per_gaussian = P * (12 + 4 + 16 + 4 + 12) + P * (79 + 12 * M + 12 * M + 12 + 12 + 16 + 24)
+    bwd = R * (28 + 16) + HW * (20 + 4 + 4) + per_gaussian
+    return fwd, bwd, per_gaussian
+
+
+def raster_hbm_rooflines(P, W, H, R_mean, step_s, kern):
+    """Two HBM figures next to the dominant kernel's (verdict r5 item 7c): the WHOLE step against SURVEY 8(d)'s byte model, and k_gather_bwd -- the
+    one kernel of the step that is bandwidth-bound -- against its own bytes.  -> (roofline_step, roofline_gather_bwd), either None when unmeasured."""
+    if not kern or not step_s:
+        return None, None
+    fwd_b, bwd_b, gb = raster_byte_model(P, W, H, R_mean)
+    ach = (fwd_b + bwd_b) / step_s / 1e9
+    step = dict(bound="hbm", what="whole step (all launches, forward + backward) against SURVEY.md section 8(d)'s byte model with the measured R; "
+                "the model prices the reference's global radix sort (24 B x 6 passes per instance) that this design does in LDS",
+                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                alg_bytes_fwd=int(fwd_b), alg_bytes_bwd=int(bwd_b), ms_per_step=round(1e3 * step_s, 4))
+    gather = None
+    if "gather_bwd" in kern and kern["gather_bwd"].get("avg_us"):
+        tr = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                tr = json.load(fh).get("gather_bwd")
+        except (OSError, ValueError):
+            pass
+        us = kern["gather_bwd"]["avg_us"]
+        ga = gb / (us * 1e-6) / 1e9
+        gather = dict(bound="hbm", kernel="gather_bwd", achieved=round(ga, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ga / HBM_PEAK_GBS, 4),
+                      alg_bytes=int(gb), avg_us=round(us, 2), traffic=tr,
+                      traffic_from=None if tr is None else "profiles/pmc_traffic.json (committed counter pass; NOT observed in this run)",
+                      what="per Gaussian: the 48 B of summed pixel-side gradients in, geometry state 79 B + SH 192 B in, dSH 192 B + 64 B of parameter gradients out "
+                           "(SURVEY 8(d), rows A14 / A15); the per-(instance, quadrant) sub-records it also reads are this design's own traffic and count only in `traffic`")
+    return step, gather
+
+
+def mfma_family_roofline(evs, name, n_inst, peak_tflops=2500.0):
+    """Roofline object of one MFMA kernel family from its event pairs of the instrumented pass: evs = [(start, end, executed flops, key[, reference-
+    operator flops])].  `frac` is on EXECUTED flops; where a family executes fewer than the reference operator counts (nearest-x2 + 3x3 as four 2x2
+    phase convolutions: 16 of 36 taps per input pixel) the reference-operator figures ride along."""
+    ms = sum(e[0].elapsed_time(e[1]) for e in evs)
+    fl = sum(e[2] for e in evs)
+    if not ms or not n_inst:
+        return None
+    ach = fl / (ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+         "frac": round(ach / peak_tflops, 4), "traffic": None, "launches": len(evs), "ms_per_step": round(ms / n_inst, 2),
+         "alg_tflop_per_step": round(fl / n_inst / 1e12, 2)}
+    ref_fl = sum((e[4] if len(e) > 4 and isinstance(e[3], tuple) else e[2]) for e in evs)
+    if ref_fl != fl:
+        r["flops"] = "executed (nearest-x2 + 3x3 as four 2x2 phase convolutions: 4 taps per output pixel)"
+        r["reference_operator_tflop_per_step"] = round(ref_fl / n_inst / 1e12, 2)
+        r["achieved_on_reference_operator_flops"] = round(ref_fl / (ms * 1e-3) / 1e12, 2)
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,32 +454,7 @@ def raster_run(args, dev, rank, world):
 
         # Two more HBM figures next to the dominant kernel's (verdict r5 item 7c): the WHOLE step against SURVEY 8(d)'s byte model
         # (SURVEY.md:438, with the measured R), and k_gather_bwd -- the one kernel of the step that is bandwidth-bound -- against its own bytes.
-        roofline_step = roofline_gather = None
-        if kern:
-            Msh = (args.sh_degree + 1) ** 2 if args.sh_degree < 3 else 16
-            Msh = 16   # the SH tensor is stored (and its gradient written) at 16 coefficients whatever the active degree
-            ntiles = ((W + 15) // 16) * ((H + 15) // 16)
-            bit = max(1, (ntiles - 1).bit_length())
-            fwd_b = P * (12 + 12 + 16 + 4 + 12 * Msh) + P * 79 + P * 8 + R_mean * 12 + R_mean * 24 * ((32 + bit + 7) // 8) + R_mean * 8 + R_mean * 28 + HW * 24
-            bwd_b = R_mean * (28 + 16) + HW * (20 + 4 + 4) + P * (12 + 4 + 16 + 4 + 12) + P * (79 + 12 * Msh + 12 * Msh + 12 + 12 + 16 + 24)
-            step_s = elapsed / args.steps
-            roofline_step = dict(bound="hbm", what="whole step (all launches, forward + backward) against SURVEY.md section 8(d)'s byte model with the measured R; "
-                                 "the model prices the reference's global radix sort (24 B x 6 passes per instance) that this design does in LDS",
-                                 achieved=round((fwd_b + bwd_b) / step_s / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round((fwd_b + bwd_b) / step_s / 1e9 / HBM_PEAK_GBS, 4),
-                                 alg_bytes_fwd=int(fwd_b), alg_bytes_bwd=int(bwd_b), ms_per_step=round(1e3 * step_s, 4))
-            if "gather_bwd" in kern:
-                gb = P * (12 + 4 + 16 + 4 + 12) + P * (79 + 12 * Msh + 12 * Msh + 12 + 12 + 16 + 24)
-                tr = None
-                try:
-                    tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("gather_bwd")
-                except Exception:
-                    pass
-                ga = gb / (kern["gather_bwd"]["avg_us"] * 1e-6) / 1e9
-                roofline_gather = dict(bound="hbm", kernel="gather_bwd", achieved=round(ga, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ga / HBM_PEAK_GBS, 4),
-                                       alg_bytes=int(gb), avg_us=round(kern["gather_bwd"]["avg_us"], 2), traffic=tr,
-                                       traffic_from=None if tr is None else "profiles/pmc_traffic.json (committed counter pass; NOT observed in this run)",
-                                       what="per Gaussian: the 48 B of summed pixel-side gradients in, geometry state 79 B + SH 192 B in, dSH 192 B + 64 B of parameter gradients out "
-                                            "(SURVEY 8(d), rows A14 / A15); the per-(instance, quadrant) sub-records it also reads are this design's own traffic and count only in `traffic`")
+        roofline_step, roofline_gather = raster_hbm_rooflines(P, W, H, R_mean, elapsed / args.steps, kern)
 
         # SURVEY 8(d) asks for two more points on the same scene: SH degree 0, and all three pixel gradients non-zero
         # (colour + depth + alpha).  Short side runs (not the headline value), single rank.
@@ -974,21 +1011,7 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
             return None
     MFMA_PEAK = 2500.0  # TFLOP/s dense f16/bf16 (MI355X_MICROARCH.md)
 
-    def roof(evs, name):
-        ms = sum(e[0].elapsed_time(e[1]) for e in evs)
-        fl = sum(e[2] for e in evs)
-        if not ms:
-            return None
-        ach = fl / (ms * 1e-3) / 1e12
-        r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
-             "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "launches": len(evs), "ms_per_step": round(ms / n_inst, 2),
-             "alg_tflop_per_step": round(fl / n_inst / 1e12, 2)}
-        ref_fl = sum((e[4] if len(e) > 4 and isinstance(e[3], tuple) else e[2]) for e in evs)
-        if ref_fl != fl:   # the phase convolutions execute 16 of the reference operator's 36 taps per input pixel
-            r["flops"] = "executed (nearest-x2 + 3x3 as four 2x2 phase convolutions: 4 taps per output pixel)"
-            r["reference_operator_tflop_per_step"] = round(ref_fl / n_inst / 1e12, 2)
-            r["achieved_on_reference_operator_flops"] = round(ref_fl / (ms * 1e-3) / 1e12, 2)
-        return r
+    roof = lambda evs, name: mfma_family_roofline(evs, name, n_inst, MFMA_PEAK)
 
     r_conv = roof(ev_conv, "k_conv_mfma (3x3 / upsample / temporal implicit-GEMM convolutions, fused GroupNorm+SiLU prologue)")
     r_attn = roof(ev_attn, "k_attn_fwd (all spatial / cross / temporal attention launches)")
