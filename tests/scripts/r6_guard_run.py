@@ -78,4 +78,8 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    code = main()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code or 0)     # no interpreter finalisation: the tensors still alive would be freed -- through this allocator's device synchronise and
+    #                         red-zone copies -- while the HIP runtime is being torn down; every live block was checked by gvd_guard_check_all() above
