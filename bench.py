@@ -940,6 +940,17 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
                         ("gemm", bt, xx.shape[-2], ww.shape[-2], xx.shape[-1], bool(kw.get("geglu")), kw.get("row_stats") is not None, kw.get("residual") is not None)))
         return o
 
+    orig_gate = getattr(mgemm, "_gate_gemm", None)
+
+    def timed_gate(x2, w, y, aux, mode, **kw):    # the guided step's feed-forward GEMMs with the gate (forward, mode 2) / its backward (mode 3) in the epilogue
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        o = orig_gate(x2, w, y, aux, mode, **kw)
+        b.record()
+        ev_gemm.append((a, b, 2.0 * x2.shape[0] * w.shape[0] * x2.shape[1],
+                        ("gemm", 1, x2.shape[0], w.shape[0], x2.shape[1], f"gate mode {int(mode)}", kw.get("row_stats") is not None, False)))
+        return o
+
     # ---- timed region: the product path, nothing else on the stream (no per-kernel event pairs) ----
     mark = (lambda tag: ops.lib().gvd_profile_marker(tag, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))) if os.environ.get("GVD_BENCH_MARKERS") else (lambda tag: None)
     mark(0)   # (profiling runs only: tests/scripts/prof_summary.py counts the launches between the two markers)
@@ -960,6 +971,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
     sampler.graph_apply = False
     ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = timed_attn, timed_conv, timed_gemm
     mconv._split_conv, mconv._sheet_conv = timed_split, timed_sheet
+    if orig_gate is not None:
+        mgemm._gate_gemm = timed_gate
     xi = x
     if n_inst:   # one untimed EAGER step first: the graph-replayed timed region never asked the caching allocator for the eager path's
         #          buffers, and the first instrumented launch of a shape then timed a hipMalloc of its ~1 GB output inside its event pair
@@ -978,6 +991,8 @@ def ddim_run(args, dev, rank, world, guided, steps, warm, cpu_leg_wanted, cache=
         clock = smi.stop() if smi else None
         ops._hip_attention_fwd, mconv._launch, mgemm.gemm_nt = orig_attn, orig_conv, orig_gemm
         mconv._split_conv, mconv._sheet_conv = orig_split, orig_sheet
+        if orig_gate is not None:
+            mgemm._gate_gemm = orig_gate
         sampler.graph_apply = graph_was
     assert torch.isfinite(xi).all()
     if os.environ.get("GVD_BENCH_TORCH_PROFILE"):   # dev: where do the step's copy / fill / add / cat launches come from?  (op, first package frame) table
