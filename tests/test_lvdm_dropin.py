@@ -245,3 +245,51 @@ def test_dropin_plumbing_on_the_device_agrees_with_the_packages_own_cpu_form():
     # (one evaluation agrees to 1.3e-3 forward / 1.6e-3 input gradient -- tests/scripts/r3_pair_probe.py: rounding level, the batch-2
     #  launches tile differently -- and three guided steps at CFG 7.5 amplify that like they amplify the fp16-vs-fp32 difference above)
     assert float((out - out_seq).abs().max() / out_seq.abs().max()) < 5e-2
+
+
+def test_latent_diffusion_matches_the_references_own_classes():
+    """SURVEY rows B5 / B13 glue against lvdm/models/ddpm3d.py::LatentDiffusion + autoencoder.py::AutoencoderKL THEMSELVES
+    (tests/golden/make_golden_latent_diffusion.py imports them with a two-name placeholder for pytorch_lightning; until round 6 the comparison was key
+    counts and shapes).  The drop-in built from the same configuration has the SAME state-dict keys and shapes -- so name-derived weights land
+    identically -- the same schedule buffers, and reproduces apply_model with hybrid conditioning, the v-parameterisation helpers, q_sample, decode
+    (per frame and batched) with its input gradient, and encode (posterior sample, same generator order)."""
+    from latent_diffusion_cfg import LD_KW, UNET, VAE
+    from fill_by_name import fill_by_name
+    from lvdm.models.ddpm3d import LatentDiffusion
+    from lvdm_amd import ops
+    R = np.load(os.path.join(HERE, "golden", "latent_diffusion_ref.npz"), allow_pickle=False)
+    ld = LatentDiffusion(first_stage_config=VAE, cond_stage_config={"target": "torch.nn.Identity"}, unet_config=UNET, **LD_KW).eval()
+    sd = ld.state_dict()
+    assert sorted(sd) == list(R["keys"])
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(R["shapes"])
+    for k in sd:
+        if not k.startswith(("model.", "first_stage_model.")):
+            np.testing.assert_allclose(sd[k].numpy(), R["buf_" + k], rtol=1e-6, atol=1e-12, err_msg=k)
+    fill_by_name(ld.model)
+    fill_by_name(ld.first_stage_model)
+    t = lambda k: torch.tensor(R[k])
+    x, tt, fs = t("x"), torch.tensor([400]), torch.tensor([10])
+    cond = {"c_crossattn": [t("c_text"), t("c_img")], "c_concat": [t("c_concat")]}
+    ops.use_reference_math(True)
+    try:
+        with torch.no_grad():
+            v = ld.apply_model(x, tt, cond, fs=fs)
+            np.testing.assert_allclose(v.numpy(), R["v"], rtol=2e-4, atol=2e-5 * np.abs(R["v"]).max())
+            vr = t("v")
+            np.testing.assert_allclose(ld.predict_start_from_z_and_v(x, tt, vr).numpy(), R["x0_from_v"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(ld.predict_eps_from_z_and_v(x, tt, vr).numpy(), R["eps_from_v"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(ld.q_sample(x, tt, noise=t("q_noise")).numpy(), R["q_sample"], rtol=1e-5, atol=1e-6)
+        z = t("z")
+        for tag, pf in (("perframe", True), ("batched", False)):
+            ld.perframe_ae = pf
+            with torch.no_grad():
+                img = ld.decode_first_stage(z)
+            np.testing.assert_allclose(img.numpy(), R[f"decode_{tag}"], rtol=2e-4, atol=2e-5 * np.abs(R[f"decode_{tag}"]).max())
+            zr = z.clone().requires_grad_(True)
+            (gz,) = torch.autograd.grad(ld.differentiable_decode_first_stage(zr), zr, t("decode_gi"))
+            np.testing.assert_allclose(gz.numpy(), R[f"decode_grad_{tag}"], rtol=5e-4, atol=5e-5 * np.abs(R[f"decode_grad_{tag}"]).max())
+            torch.manual_seed(5)
+            enc = ld.encode_first_stage(t("video"))
+            np.testing.assert_allclose(enc.numpy(), R[f"encode_{tag}"], rtol=2e-4, atol=2e-5 * np.abs(R[f"encode_{tag}"]).max())
+    finally:
+        ops.use_reference_math(False)
