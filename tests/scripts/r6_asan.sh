@@ -10,6 +10,8 @@
 # attention_backward.hip and conv_mfma.hip instrumented (conv_mfma.hip alone takes ~20 min: build it in the build container -- the .so travels
 # to the GPU box with the snapshot, lib/asan/ is git-ignored, not gpurun-ignored), gemm_mfma.hip plain.  The GEMM's memory safety rests on the
 # red-zone guard allocator alone.
+# (The build container's copies live outside the tree -- 86 MB would otherwise travel with every gpurun call; before the call that runs this script:
+#  cp -r /tmp/asan/libs guidedvd-3dgs_amd/lib/asan.  Without them everything but conv_mfma.hip is rebuilt on the box in ~2 min and the convolution leg is skipped.)
 set -u
 R=$PWD
 A=$R/guidedvd-3dgs_amd/lib/asan
@@ -23,8 +25,9 @@ echo "== asan: build"
 [ -f $A/libgvd_knn.so ] || $HIPCC $SAN -shared -ffp-contract=off -o $A/libgvd_knn.so $C/knn.hip 2>&1 | tail -3
 [ -f $A/libgvd_loss.so ] || $HIPCC $SAN -shared -o $A/libgvd_loss.so $C/ssim.hip 2>&1 | tail -3
 if [ ! -f $A/libgvd_diffusion.so ]; then
-  for f in diffusion_kernels attention_backward conv_mfma; do $HIPCC $SAN -fno-honor-nans -c -o $A/$f.asan.o $C/$f.hip 2>&1 | grep "error" | head -3; done
+  for f in diffusion_kernels attention_backward ${ASAN_BUILD_CONV:+conv_mfma}; do $HIPCC $SAN -fno-honor-nans -c -o $A/$f.asan.o $C/$f.hip 2>&1 | grep "error" | head -3; done
   $HIPCC --offload-arch=gfx950:xnack+ -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed -fno-honor-nans -c -o $A/gemm_mfma.plain.o $C/gemm_mfma.hip 2>&1 | grep "error" | head -3
+  [ -f $A/conv_mfma.asan.o ] || $HIPCC --offload-arch=gfx950:xnack+ -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed -fno-honor-nans -c -o $A/conv_mfma.asan.o $C/conv_mfma.hip 2>&1 | grep error | head -3   # (plain unless ASAN_BUILD_CONV=1: 20 min under the sanitizer)
   $HIPCC --offload-arch=gfx950:xnack+ -fsanitize=address -shared-libsan -shared -fPIC -o $A/libgvd_diffusion.so $A/diffusion_kernels.asan.o $A/attention_backward.asan.o $A/conv_mfma.asan.o $A/gemm_mfma.plain.o 2>&1 | tail -3
 fi
 ls -la $A
