@@ -89,6 +89,33 @@ def main():
                               unconditional_conditioning=uc, eta=1.0, cfg_img=2.5, x_T=xT, timestep_spacing="uniform_trailing",
                               guidance_rescale=0.7, unconditional_conditioning_img_nonetext=uc_img, fs=None)
     out["mc_traj_xT"], out["mc_traj_draws"], out["mc_traj_samples"] = xT.numpy(), torch.stack(draws).numpy(), samples.numpy()
+    # the plain sampler's sample() with the mask / x0 blending of ddim.py:175-182 (q_sample of x0, or x0 itself with clean_cond) and the
+    # intermediates bookkeeping (log_every_t) -- unused by the guidedvd drivers (they pass mask=None) but part of the sampler's surface
+    import lvdm.models.samplers.ddim as ddim_mod
+    from lvdm.models.samplers.ddim import DDIMSampler as PlainSampler
+
+    class CPUPlain(PlainSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    def q_sample(x0, t, noise=None):
+        e = lambda a: a.gather(-1, t).reshape(t.shape[0], 1, 1, 1, 1)
+        noise = torch.full_like(x0, 0.25) if noise is None else noise          # (deterministic stand-in draw: the reference draws randn here)
+        return e(duck.sqrt_alphas_cumprod) * x0 + e(duck.sqrt_one_minus_alphas_cumprod) * noise
+    duck.q_sample = q_sample
+    mask = (torch.rand(1, 1, 5, 6, 7, generator=g) > 0.5).float()
+    x0 = torch.randn(1, 4, 5, 6, 7, generator=g)
+    out["mask"], out["mask_x0"] = mask.numpy(), x0.numpy()
+    for tag, clean in (("blend", False), ("clean", True)):
+        it2 = iter(draws)
+        ddim_mod.noise_like = lambda shape, device, repeat=False: next(it2)
+        s = CPUPlain(duck)
+        samples, inter = s.sample(S=6, batch_size=1, shape=(4, 5, 6, 7), conditioning=cond, verbose=False, unconditional_guidance_scale=7.5,
+                                  unconditional_conditioning=uc, eta=1.0, x_T=xT, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                  mask=mask, x0=x0, log_every_t=2, fs=None, **({"clean_cond": True} if clean else {}))
+        out[f"mask_{tag}_samples"] = samples.numpy()
+        out[f"mask_{tag}_n_inter"] = np.array([len(inter["x_inter"]), len(inter["pred_x0"])])
+        out[f"mask_{tag}_last_pred_x0"] = inter["pred_x0"][-1].numpy()
     assert all(np.isfinite(v).all() for v in out.values())
     np.savez_compressed(os.path.join(HERE, "multicond_ref.npz"), **out)
     print("wrote multicond_ref.npz:", {k: v.shape for k, v in out.items()})

@@ -682,3 +682,31 @@ def test_guidance_weight_schedule_matches_the_references_own_function():
     lg = LossGuidance(ddim_steps=50, recur_steps=2, device="cpu", scale_guidance_weight=True)
     got = np.array([lg.guidance_weight_fn(int(s)) for s in GD["weight_steps"]])
     np.testing.assert_allclose(got, GD["weight_values"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("tag,clean", [("blend", False), ("clean", True)])
+def test_plain_sampler_mask_blending_and_intermediates_match_reference(tag, clean):
+    """DDIMSampler.sample() with `mask` / `x0` (ddim.py:175-182: the noised original -- or, with clean_cond, x0 itself -- is blended into the latent before
+    every step) and the `intermediates` bookkeeping under log_every_t, against the reference's own sampler on the duck model.  Unused by the guidedvd drivers
+    (they pass mask=None), part of the sampler's surface."""
+    from lvdm_amd.samplers import DDIMSampler
+    duck = _Duck()
+
+    def q_sample(x0, t, noise=None):     # the deterministic stand-in draw the golden's duck uses
+        e = lambda a: a.gather(-1, t).reshape(t.shape[0], 1, 1, 1, 1)
+        noise = torch.full_like(x0, 0.25) if noise is None else noise
+        return e(duck.sqrt_alphas_cumprod) * x0 + e(duck.sqrt_one_minus_alphas_cumprod) * noise
+    duck.q_sample = q_sample
+    x, cond, uc = _duck_inputs()
+    s = DDIMSampler(duck)
+    draws = iter(torch.tensor(MC["mc_traj_draws"]))
+    s._randn = lambda shape, device: next(draws)
+    kw = {"clean_cond": True} if clean else {}
+    samples, inter = s.sample(S=6, batch_size=1, shape=(4, 5, 6, 7), conditioning=cond, verbose=False, unconditional_guidance_scale=7.5,
+                              unconditional_conditioning=uc, eta=1.0, x_T=torch.tensor(MC["mc_traj_xT"]), timestep_spacing="uniform_trailing",
+                              guidance_rescale=0.7, mask=torch.tensor(MC["mask"]), x0=torch.tensor(MC["mask_x0"]), log_every_t=2, fs=None, **kw)
+    ref = MC[f"mask_{tag}_samples"]
+    np.testing.assert_allclose(samples.numpy(), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+    assert [len(inter["x_inter"]), len(inter["pred_x0"])] == MC[f"mask_{tag}_n_inter"].tolist()
+    lp = MC[f"mask_{tag}_last_pred_x0"]
+    np.testing.assert_allclose(inter["pred_x0"][-1].numpy(), lp, rtol=2e-4, atol=2e-5 * np.abs(lp).max())
