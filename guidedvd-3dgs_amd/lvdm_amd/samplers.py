@@ -287,6 +287,11 @@ def guidance_gradient_scale(G):
     return torch.where(ok, torch.exp2(expo.clamp(-lim, lim)), torch.ones_like(gmax))
 
 
+#: the guided sampler applies its guidance for `GUIDANCE_INDEX_START > index >= GUIDANCE_INDEX_END` only (ddim_guidance.py:234-235: `start = 101`,
+#: `end = -1`): every step of the drivers' 50-step runs, not the earliest steps of a run with more than 101 DDIM steps.
+GUIDANCE_INDEX_START, GUIDANCE_INDEX_END = 101, -1
+
+
 class DDIMSamplerGuidance(DDIMSampler):
     """ddim_guidance.py: the guided step differentiates pred_x0 w.r.t. x_t through BOTH U-Net evaluations
     and back-propagates the per-frame decoder-space loss gradient (Algorithm 1, L11-L13 of the paper)."""
@@ -395,6 +400,13 @@ class DDIMSamplerGuidance(DDIMSampler):
                 dir_xt = k["dir_coef"] * e_t
                 nz = self._randn(x.shape, x.device) if noise is None else noise
                 x_prev = k["sqrt_a_prev"] * pred_x0 + dir_xt + k["sigma_t"] * temperature * nz
+            if not (GUIDANCE_INDEX_START > index >= GUIDANCE_INDEX_END):
+                # outside the reference's index window (ddim_guidance.py:234-235,304,329): no decode, no loss, no U-Net backward -- the plain
+                # update, re-noised for the next pass exactly as inside the window (same draw order)
+                with torch.no_grad():
+                    rz = self._randn(x.shape, x.device) if renoise is None else renoise
+                    x = float(np.sqrt(np.float32(beta_t))) * x_prev + float(np.sqrt(np.float32(1 - beta_t))) * rz
+                continue
             # decode + loss gradient w.r.t. the (detached) x0 latent, frame by frame in the reference (ddim_guidance.py:
             # 296-317) to bound memory; here `decode_group` frames share one decoder forward/backward.  A frame's loss
             # depends on its own latent only (per-sample norms), so the gradient of the summed losses IS the per-frame

@@ -116,6 +116,36 @@ def main():
         out[f"mask_{tag}_samples"] = samples.numpy()
         out[f"mask_{tag}_n_inter"] = np.array([len(inter["x_inter"]), len(inter["pred_x0"])])
         out[f"mask_{tag}_last_pred_x0"] = inter["pred_x0"][-1].numpy()
+    # the guided sampler OUTSIDE its index window (ddim_guidance.py:234-235,304,329: `start = 101`, `end = -1`; guidance is applied only for
+    # start > index >= end, i.e. never skipped by the 50-step runs of the drivers, skipped for the early steps of a run with more than 101 steps):
+    # the step then is the plain update, twice re-noised with recur_steps = 2, and the loss object is never called
+    import lvdm.models.samplers.ddim_guidance as ddg_mod
+    from lvdm.models.samplers.ddim_guidance import DDIMSamplerGuidance
+
+    class CPUGuided(DDIMSamplerGuidance):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    class NeverCalled:
+        verbose, scale_guidance_weight, save_dir, mean_loss = False, False, None, False
+
+        def __init__(self, recur):
+            self.recur_steps = recur
+
+        def __call__(self, *a, **k):
+            raise AssertionError("the guidance loss must not be evaluated outside the index window")
+
+    duck.first_stage_model.requires_grad_(True)
+    for recur in (1, 2):
+        it3 = iter(draws)
+        ddg_mod.noise_like = lambda shape, device, repeat=False: next(it3)
+        s = CPUGuided(duck)
+        s.make_schedule(120, "uniform_trailing", 1.0, verbose=False)
+        index = 110
+        t = torch.full((1,), int(s.ddim_timesteps[index]), dtype=torch.long)
+        xp, p0 = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                                 guidance_rescale=0.7, loss_guidance_fn=NeverCalled(recur))
+        out[f"outside_r{recur}_xprev"], out[f"outside_r{recur}_x0"] = xp.numpy(), p0.numpy()
     assert all(np.isfinite(v).all() for v in out.values())
     np.savez_compressed(os.path.join(HERE, "multicond_ref.npz"), **out)
     print("wrote multicond_ref.npz:", {k: v.shape for k, v in out.items()})

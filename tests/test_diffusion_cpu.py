@@ -710,3 +710,31 @@ def test_plain_sampler_mask_blending_and_intermediates_match_reference(tag, clea
     assert [len(inter["x_inter"]), len(inter["pred_x0"])] == MC[f"mask_{tag}_n_inter"].tolist()
     lp = MC[f"mask_{tag}_last_pred_x0"]
     np.testing.assert_allclose(inter["pred_x0"][-1].numpy(), lp, rtol=2e-4, atol=2e-5 * np.abs(lp).max())
+
+
+@pytest.mark.parametrize("recur", [1, 2])
+def test_guided_sampler_outside_its_index_window_matches_reference(recur):
+    """ddim_guidance.py:234-235,304,329: the guidance is applied for 101 > index >= -1 only.  A 120-step schedule at index 110: the reference makes the
+    plain update (twice, re-noised, with recur_steps = 2) and never evaluates the loss -- neither does this sampler (found in round 6 while pinning the
+    sampler's surface: until then the window was not restated, which only differs for runs of more than 101 steps)."""
+    from lvdm_amd.samplers import DDIMSamplerGuidance
+
+    class NeverCalled:
+        verbose, scale_guidance_weight, save_dir, mean_loss, recur_steps = False, False, None, False, recur
+
+        def __call__(self, *a, **k):
+            raise AssertionError("the guidance loss must not be evaluated outside the index window")
+
+    duck = _Duck()
+    s = DDIMSamplerGuidance(duck)
+    s.make_schedule(120, "uniform_trailing", 1.0)
+    x, cond, uc = _duck_inputs()
+    draws = iter(torch.tensor(MC["mc_traj_draws"]))
+    s._randn = lambda shape, device: next(draws)
+    index = 110
+    t = torch.full((1,), int(s.ddim_timesteps[index]), dtype=torch.long)
+    xp, p0 = s.p_sample_ddim(x, cond, t, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc, guidance_rescale=0.7,
+                             loss_guidance_fn=NeverCalled())
+    for got, key in ((xp, "xprev"), (p0, "x0")):
+        ref = MC[f"outside_r{recur}_{key}"]
+        np.testing.assert_allclose(got.numpy(), ref, rtol=3e-5, atol=3e-6 * np.abs(ref).max())
