@@ -51,4 +51,23 @@ for tag, cfg_img in (("cfg3", 3.0), ("cfg1", 1.0)):
         print(tag, res.shape, float(res.abs().mean()))
     except Exception as e:   # cfg_img == 1.0: the reference hands None to apply_model as the third conditioning
         print(tag, "reference raised", type(e).__name__, str(e)[:120])
+# branches of image_guided_synthesis the drivers' settings do not take (diffusion_utils.py:131-133 no text input, :163-169 uncond_type
+# "zero_embed", :194 n_samples > 1, :161 / 171-172 classifier-free guidance off), with the reference's plain sampler
+class CPUPlain(du.DDIMSampler):
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+
+du.DDIMSampler = CPUPlain
+for tag, kw in (("notext", dict(text_input=False)), ("zero_embed", dict(uncond_type="zero_embed")), ("two_samples", dict(n_samples=2)),
+                ("cfg_off", dict(scale=1.0))):
+    duck.uncond_type = kw.get("uncond_type", "empty_seq")
+    torch.manual_seed(123)
+    prompt = "A room" if tag == "notext" else o.prompt      # (a prompt whose stand-in embedding differs from the empty one's: it must be ignored)
+    res = du.image_guided_synthesis(duck, [prompt], videos, noise_shape, kw.get("n_samples", o.n_samples), o.ddim_steps, o.ddim_eta,
+                                    kw.get("scale", o.unconditional_guidance_scale), o.cfg_img, o.frame_stride, kw.get("text_input", o.text_input), False,
+                                    o.timestep_spacing, o.guidance_rescale, [0], None, True)
+    out[f"{tag}_video"] = res.detach().numpy()
+    print(tag, res.shape, float(res.abs().mean()))
+duck.uncond_type = "empty_seq"
 np.savez_compressed(os.path.join(HERE, "pipeline_multicond_ref.npz"), **out)

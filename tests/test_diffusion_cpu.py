@@ -738,3 +738,26 @@ def test_guided_sampler_outside_its_index_window_matches_reference(recur):
     for got, key in ((xp, "xprev"), (p0, "x0")):
         ref = MC[f"outside_r{recur}_{key}"]
         np.testing.assert_allclose(got.numpy(), ref, rtol=3e-5, atol=3e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag,kw", [("notext", dict(text_input=False)), ("zero_embed", dict(uncond_type="zero_embed")), ("two_samples", dict(n_samples=2)),
+                                    ("cfg_off", dict(scale=1.0))])
+def test_pipeline_entry_branches_the_drivers_do_not_take_match_the_reference(tag, kw):
+    """image_guided_synthesis off the drivers' settings (diffusion_utils.py:131-133 prompts ignored without text input, :163-169 uncond_type "zero_embed",
+    :194 several samples per call, :161,171-172 classifier-free guidance off) against the videos the REFERENCE's function produced with its own plain
+    sampler on the stand-in model (tests/golden/make_golden_pipeline_multicond.py)."""
+    import pipeline_duck as pd
+    from lvdm_amd import pipeline
+    from lvdm_amd.schedule import DiffusionSchedule
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_multicond_ref.npz"))[f"{tag}_video"]
+    duck = pd.PipeDuck(DiffusionSchedule())
+    duck.uncond_type = kw.get("uncond_type", "empty_seq")
+    renderings, guide, masks, noise_shape = pd.inputs()
+    o = pd.Opts
+    videos = (renderings * 2. - 1.).permute(3, 0, 1, 2).unsqueeze(0)
+    torch.manual_seed(123)
+    got = pipeline.image_guided_synthesis(duck, ["A room" if tag == "notext" else o.prompt], videos, noise_shape, kw.get("n_samples", o.n_samples),
+                                          o.ddim_steps, o.ddim_eta, kw.get("scale", o.unconditional_guidance_scale), o.cfg_img, o.frame_stride,
+                                          kw.get("text_input", o.text_input), False, o.timestep_spacing, o.guidance_rescale, [0], None, True)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.detach().numpy(), ref, rtol=0, atol=5e-5)
