@@ -100,7 +100,7 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { ret
 // WM: wave rows (channel halves) -- 2: 8 waves, one workgroup per CU, a RING of four 32-channel K slots (below); 1: 4 waves, two
 // workgroups per CU (one's epilogue stores drain under the other's K loop), two K stages of 32 channels.
 //
-// The 8-wave K loop (RING).  A trace of the two-stage form (profiles/r06_gemm_wave_timeline_ktile.txt) showed what a K-tile costs beyond
+// The 8-wave K loop (RING).  A trace of the two-stage form (tests/scripts/r4_gemm_trace.py on a -DGVD_GEMM_TRACE build; the round-6 printout stayed in a session's scratch directory) showed what a K-tile costs beyond
 // its MFMAs: the two waves of a SIMD run their MFMA streams one after the other (the older wave wins the pipe), the older one then waits at
 // the K-tile's barrier, and after the barrier BOTH wait for their first operand fragments -- ~500 of 2750 cycles per 64-channel K-tile with
 // no MFMA in flight on the SIMD.  Here K is cut in 32-channel half-tiles h = 0, 1, ... living in slot h & 3 of a ring of four; during half-tile
