@@ -63,3 +63,23 @@ def test_newest_profile_picks_the_latest_round():
     keys = json.load(open(path))
     assert any(k.startswith("attn i4ELi2") for k in keys) and "gemm L0 out-proj 230400x320x320 +residual" in keys   # what bench.py looks up in it
     assert bench.newest_profile("no_such_suffix.json") == (None, None)
+
+
+def test_every_profile_file_the_documents_cite_exists():
+    """Evidence hygiene (verdict r5 item 7): a `profiles/...` path quoted in DESIGN.md / README.md / INTEGRATION.md / a source comment must be a committed
+    file.  Glob-like mentions (`r05_*`, `rNN_...`, `{a,b}`) are patterns, not citations; the three round-6 files below are named as the OUTPUT of scripts
+    that have not run (no GPU access in the session that wrote them) and are listed here so that nothing else can hide behind that excuse."""
+    import re
+    pending = {"profiles/r06_gemm_vs_hipblaslt.txt", "profiles/r06_guard.log"}
+    texts = [os.path.join(ROOT, f) for f in ("DESIGN.md", "README.md", "INTEGRATION.md", "bench.py")]
+    for d in ("guidedvd-3dgs_amd/csrc", "guidedvd-3dgs_amd/lvdm_amd", "guidedvd-3dgs_amd/diff_gaussian_rasterization"):
+        texts += [os.path.join(ROOT, d, f) for f in os.listdir(os.path.join(ROOT, d)) if f.endswith((".hip", ".h", ".cpp", ".py"))]
+    missing = []
+    for t in texts:
+        for m in re.finditer(r"profiles/[A-Za-z0-9_./*{},<>-]+", open(t, errors="replace").read()):
+            p = m.group(0).rstrip(".,;:)")
+            if any(c in p for c in "*{<") or "rNN" in p or p.endswith("/") or p in pending:
+                continue
+            if not os.path.exists(os.path.join(ROOT, p)):
+                missing.append((os.path.relpath(t, ROOT), p))
+    assert not missing, missing
