@@ -243,7 +243,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             _drain_status()
             u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
             geom_t, img_t = u8(L.gvd_raster_geometry_bytes(P, W, H)), u8(L.gvd_raster_image_bytes(W, H))
-            bin_t = u8(L.gvd_raster_binning_bytes(_CAPACITY))
+            # (a forward no backward will follow touches keys / list / bucket / cull bytes only: the compact form holds those at the same offsets)
+            bin_t = u8(L.gvd_raster_binning_bytes(_CAPACITY) if expect_backward else L.gvd_raster_binning_bytes_no_backward(_CAPACITY))
             status = torch.empty(1, dtype=torch.int32, device=dev)
             rc = L.gvd_raster_forward_capped(geom_t.data_ptr(), bin_t.data_ptr(), img_t.data_ptr(), _CAPACITY, P, int(degree), M,
                                              _ptr(bg), W, H, _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa), _ptr(sc),
