@@ -47,17 +47,17 @@ size_t red_zone()
     return g_rz;
 }
 
-void report(const Block& b, const char* side, size_t first, size_t last, size_t count)
+void report(const Block& b, const char* side, long long first, long long last, size_t count)
 {
     ++g_violations;
     fprintf(stderr, "[gvd_guard] VIOLATION: block #%llu of %zu bytes (device %d): %zu byte(s) of the red zone %s the body were overwritten, "
                     "first at offset %+lld, last at %+lld relative to the body's %s\n",
-            b.serial, b.size, b.device, count, side, (long long)first, (long long)last, side[0] == 'b' ? "start" : "end");
+            b.serial, b.size, b.device, count, side, first, last, side[0] == 'b' ? "start" : "end");
     const char* log = getenv("GVD_GUARD_LOG");
     if (log) {
         FILE* f = fopen(log, "a");
         if (f) {
-            fprintf(f, "violation block=%llu size=%zu side=%s first=%lld last=%lld count=%zu\n", b.serial, b.size, side, (long long)first, (long long)last, count);
+            fprintf(f, "violation block=%llu size=%zu side=%s first=%lld last=%lld count=%zu\n", b.serial, b.size, side, first, last, count);
             fclose(f);
         }
     }
@@ -73,7 +73,7 @@ void check_block(const Block& b)
         size_t first = 0, last = 0, n = 0;
         for (size_t i = 0; i < rz; ++i)
             if (h[i] != kPoison) { if (!n) first = i; last = i; ++n; }
-        if (n) report(b, "before", (size_t)0 - (rz - first), (size_t)0 - (rz - last), n);   // negative offsets from the body's start
+        if (n) report(b, "before", (long long)first - (long long)rz, (long long)last - (long long)rz, n);   // negative offsets from the body's start
     }
     // behind the body: from the first byte past `size` (the rounding slack belongs to the zone) to the end of the block
     const size_t tail_off = rz + b.size;
@@ -83,7 +83,7 @@ void check_block(const Block& b)
         size_t first = 0, last = 0, n = 0;
         for (size_t i = 0; i < tail; ++i)
             if (h[i] != kPoison) { if (!n) first = i; last = i; ++n; }
-        if (n) report(b, "after", first, last, n);
+        if (n) report(b, "after", (long long)first, (long long)last, n);
     }
 }
 
