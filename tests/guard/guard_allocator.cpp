@@ -10,7 +10,26 @@
 //   * a read far past the end leaves the mapping (each block is its own allocation) and faults.
 // Usage: tests/scripts/r6_guard_run.py <script> [args] installs it before the first device allocation and runs the script under it.
 // No product code knows about it.  Build: hipcc -shared -fPIC (tests/guard/build.sh); only the HIP runtime API is used.
+#ifdef GVD_GUARD_HOST_FAKE
+// Host-only build for the CPU test of the allocator's OWN logic (red-zone arithmetic, detection, reporting): the six HIP calls it makes are mapped to
+// malloc / memset / memcpy.  tests/test_guard_allocator_gpu.py::test_guard_allocator_logic_on_the_host builds and drives this form; the real build
+// (tests/guard/build.sh) uses the HIP runtime.
+#include <sys/types.h>
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipMemcpyDeviceToHost = 2 };
+#include <stdlib.h>
+#include <string.h>
+static hipError_t hipMalloc(void** p, size_t n) { return posix_memalign(p, 4096, n) == 0 ? hipSuccess : 2; }   // (hipMalloc returns page-aligned blocks)
+static hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+static hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static hipError_t hipSetDevice(int) { return hipSuccess; }
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
