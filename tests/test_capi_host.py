@@ -143,6 +143,22 @@ def test_no_backward_chunk_is_a_ninth_of_the_size_and_never_passes_for_a_full_on
     assert all(b > a for a, b in zip(sizes, sizes[1:]))   # strictly increasing: the size names the capacity
 
 
+def test_chunk_size_decode_over_random_capacities(capi):
+    """400 random capacities up to 2^31 through both layout forms: the byte size names the capacity exactly, sizes one byte off name nothing, and the
+    two forms never share a size (full: multiple of 64; without the backward's records: 2 mod 4)."""
+    import random
+    L = capi.lib()
+    rng = random.Random(20260930)
+    for _ in range(400):
+        r = rng.choice((rng.randrange(0, 70), rng.randrange(0, 1 << 20), rng.randrange(0, 1 << 31)))
+        full, compact = L.gvd_raster_binning_bytes(r), L.gvd_raster_binning_bytes_no_backward(r)
+        assert full % 64 == 0 and compact % 4 == 2 and compact < full
+        assert L.gvd_raster_binning_capacity(full) == max(r, 1) and L.gvd_raster_binning_capacity(compact) == max(r, 1)
+        assert L.gvd_raster_binning_capacity(full + 1) == 0xffffffff and L.gvd_raster_binning_capacity(compact - 1) == 0xffffffff
+        if r > 1:
+            assert L.gvd_raster_binning_bytes(r - 1) < full and L.gvd_raster_binning_bytes_no_backward(r - 1) < compact
+
+
 def test_compiled_operator_loads_and_fails_loudly_without_a_device(capi):
     """lib/_gvd_raster_torch.so (csrc/raster_torch_ext.cpp, built by __graft_entry__.build_raster_torch_ext) imports, resolves its C-ABI
     entry points from libgvd_raster.so and refuses CPU tensors with the binding's message -- no silent fallback."""
