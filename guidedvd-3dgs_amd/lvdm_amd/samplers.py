@@ -4,7 +4,9 @@
                               unconditional_conditioning, fs, timestep_spacing, guidance_rescale, **kwargs)
         -> (samples, {'x_inter': [...], 'pred_x0': [...]})                    lvdm/models/samplers/ddim.py:61-134
     DDIMSamplerGuidance: same, with the scene-grounding guidance of ddim_guidance.py:205-363 when
-        `loss_guidance_fn` is passed in kwargs.
+        `loss_guidance_fn` is passed in kwargs (applied for 101 > index >= -1 only, :234-235).
+    DDIMSamplerMultiCond: the three-way text x image classifier-free guidance of ddim_multiplecond.py:210-286
+        (`cfg_img`, kwargs['unconditional_conditioning_img_nonetext']); what `multiple_cond_cfg` selects.
 
 Differences from the reference, none of which change results:
   * tables live on `model.device` (the reference hard-codes "cuda", ddim.py:18-22);
